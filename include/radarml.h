@@ -1,0 +1,194 @@
+/*
+ * radarml.h -- C ABI of libradarml_hip.so, the MI355X (gfx950) implementation of the
+ * radar-ml batched hot path: 3-D radar volume -> (xz, yz, xy) projections -> feature
+ * rows -> RBF-SVM / linear decision function -> labels.
+ *
+ * The reference (goruck/radar-ml) is pure Python and has no FFI of its own; its
+ * boundary for this path is three Python call surfaces.  Each entry
+ * point below names the reference site it replaces (paths relative to the reference
+ * tree; "sk:" = the scikit-learn package the reference calls into).  The Python side
+ * binds these with ctypes (radar-ml_amd/_lib.py; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every function returns RML_OK (0) or a negative rml_status; no exceptions, no
+ *     aborts, nothing printed.  rml_last_error() returns a thread-local message.
+ *   - all array arguments are CALLER-OWNED DEVICE pointers unless a parameter is
+ *     documented "host".  The library never frees caller memory.
+ *   - launches are asynchronous on the caller's hipStream_t (passed as void*; NULL =
+ *     the default stream).  A context is bound to one device.
+ *   - layouts: volumes V[b][i][j][k] float32, C-contiguous, (x=theta index i,
+ *     y=phi index j, z=range index k).  Feature rows are [xz | yz | xy] (the tuple
+ *     order of common.py:40), each plane C-order, i.e. exactly
+ *     np.concatenate((xz, yz, xy), axis=None) of common.py:146.
+ */
+#ifndef RADARML_H
+#define RADARML_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rml_status {
+    RML_OK = 0,
+    RML_ERR_INVALID = -1,      /* bad argument (NULL pointer, non-positive size, ...) */
+    RML_ERR_UNSUPPORTED = -2,  /* shape / mode this build has no kernel for          */
+    RML_ERR_HIP = -3,          /* a HIP runtime call failed (see rml_last_error)     */
+    RML_ERR_NOMEM = -4,
+    RML_ERR_STATE = -5         /* e.g. exact-integer path requested on a model that is not integer valued */
+} rml_status;
+
+typedef struct rml_ctx rml_ctx;
+typedef struct rml_svm rml_svm;
+typedef struct rml_linear rml_linear;
+
+/* projection modes */
+#define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V        */
+#define RML_MODE_SLICE 1   /* reference-faithful plane slices through (i,j,k): predict.py:102-107       */
+#define RML_MODE_SUM   2   /* sum-projection (the reductions of common.py:51-53), float32 accumulation  */
+
+/* projection mask bits, positional order of common.ProjMask (common.py:40) */
+#define RML_MASK_XZ 1u
+#define RML_MASK_YZ 2u
+#define RML_MASK_XY 4u
+#define RML_MASK_ALL 7u
+
+/* kernel types of the SVC grid in train.py:474-476 */
+#define RML_KERNEL_RBF    0
+#define RML_KERNEL_LINEAR 1
+
+/* GEMM path selection for rml_svm_decision */
+#define RML_PATH_AUTO  0   /* exact-integer path when model and rows are integer valued, else f32 */
+#define RML_PATH_F32   1   /* v_mfma_f32_32x32x2_f32, centred operands                            */
+#define RML_PATH_I8    2   /* v_mfma_i32_16x16x64_i8 on u8 codes, exact int32 dot products        */
+
+const char* rml_version(void);
+const char* rml_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+int rml_ctx_create(int device, rml_ctx** out);
+int rml_ctx_destroy(rml_ctx* ctx);
+int rml_ctx_device(const rml_ctx* ctx);
+
+/* Feature-row length for a grid and mask: X*Z + Y*Z + X*Y over the selected planes
+ * (train_svc.log:19 "Feature vector length: 10010" at (22,31,176)). */
+int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask);
+
+/* ---- projection + feature assembly ---------------------------------------------------
+ * Replaces, for a batch of B frames, the inline slicing of predict.py:102-107 /
+ * ground_truth_samples.py:413-419 (mode SLICE), the max-projection named by
+ * BASELINE.json (mode MAX) and the reductions of common.py:51-53 (mode SUM), followed by
+ * common.process_samples at zoom 1 (common.py:141-148): mask-select, ravel, concatenate
+ * in (xz,yz,xy) order, optional "/ RADAR_MAX" (scale_div = 255.0f; 0 or 1 = no scaling;
+ * a true float32 division, bit-identical to NumPy's).
+ *
+ *   V        B*X*Y*Z float32
+ *   ijk      B*3 int32 (mode SLICE only; negative indices wrap like Python's)
+ *   feat     B*ld_feat float32 or NULL, row b at feat + b*ld_feat (ld_feat >= D)
+ *   feat_q   B*ld_q uint8 or NULL: the same rows as integer codes c = value (before
+ *            scaling), stored biased for the signed i8 MFMA (byte = c XOR 0x80 = int8 c-128),
+ *            pad columns [D, ld_q) zeroed; valid for a row iff row_flags[b]==1.
+ *            Needs ld_q % 4 == 0 and a 4-byte aligned base.
+ *   row_isum / row_isq   B int32 / B int64 or NULL: sum c and sum c^2 of each code row
+ *   row_flags            B int32 or NULL: 1 iff every selected value of the row is an
+ *            integer in [0,255] (the exact-integer SVM path may then be used)
+ */
+int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                const int32_t* ijk, float scale_div, uint32_t mask,
+                float* feat, int64_t ld_feat,
+                uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
+                void* stream);
+
+/* The three planes as separate arrays (B,X,Z) (B,Y,Z) (B,X,Y); any may be NULL.
+ * Same modes; no scaling.  (The tuple a reference caller packs at predict.py:113.) */
+int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                       const int32_t* ijk, float* xz, float* yz, float* xy, void* stream);
+
+/* DerivedTarget.get_derived_targets, common.py:49-80, batched: the three energy
+ * profiles (sum over the other two axes) and their top-num_targets indices, ascending
+ * by value (argpartition(-n)[-n:] then argsort).  Ties: the LOWER index ranks lower.
+ *   ijk      B*num_targets*3 int32   (t-th row = t-th entry of each of the three index lists,
+ *                                     zipped as common.py:80)
+ *   profiles B*(X+Y+Z) float32 or NULL: [s_theta | s_phi | s_r] per frame
+ */
+int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z,
+                       int num_targets, int32_t* ijk, float* profiles, void* stream);
+
+/* Assemble feature rows from already separate projection planes (the list-of-tuples
+ * input of common.process_samples, common.py:123-149, stacked per plane), zoom 1.
+ * Planes are (B,X,Z),(B,Y,Z),(B,X,Y) float32; NULL for a masked-out plane. */
+int rml_assemble_features(rml_ctx* ctx, const float* xz, const float* yz, const float* xy,
+                          int64_t B, int X, int Y, int Z, float scale_div, uint32_t mask,
+                          float* feat, int64_t ld_feat, void* stream);
+
+/* Quantise float32 feature rows to uint8 codes + row stats, for callers that bring (N,D)
+ * features instead of volumes.  A value v is on the code grid iff it is bit-identical to
+ * float32(c / scale_div) for an integer c in [0,255] (scale_div = 255: the "p / 255." of
+ * train.py:667; scale_div <= 1: v == c).  flags as in rml_project. */
+int rml_quantize_rows(rml_ctx* ctx, const float* feat, int64_t N, int64_t D, int64_t ld_feat,
+                      float scale_div, uint8_t* feat_q, int64_t ld_q,
+                      int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream);
+
+/* ---- RBF / linear SVC (libsvm C-SVC, one-vs-one) ------------------------------------------
+ * rml_svm_load ingests the arrays of a fitted sklearn SVC (HOST pointers, float64, the
+ * private libsvm-order attributes): support_vectors_ (M,D), _dual_coef_ (C-1,M),
+ * _intercept_ (P=C(C-1)/2), _n_support (C), _gamma; optional sigmoid calibrators
+ * a_, b_ (C each) of CalibratedClassifierCV (train.py:722-724).  It builds the device
+ * copies both GEMM paths need (float32 centred SVs + norms; uint8 codes when every SV
+ * is an integer multiple of 1/code_scale).
+ */
+int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D,
+                 const double* dual_coef, const double* intercept, const int32_t* n_support,
+                 int n_classes, int kernel, double gamma, double code_scale /* e.g. 255, or 1 */,
+                 const double* calib_a, const double* calib_b, rml_svm** out);
+int rml_svm_free(rml_ctx* ctx, rml_svm* m);
+int rml_svm_is_exact(const rml_svm* m);   /* 1 when the uint8-code path is available */
+int64_t rml_svm_num_sv(const rml_svm* m);
+int64_t rml_svm_dim(const rml_svm* m);
+
+/* SVC.decision_function / SVC.predict / CalibratedClassifierCV.predict_proba / .predict
+ * (train.py:217,723-724; predict.py:60) for N feature rows:
+ *   sk:svm/src/libsvm/svm.cpp:461-475,514  K = exp(-gamma * ||x - sv||^2)
+ *   sk:svm/src/libsvm/svm.cpp:2864-2890    dec[p] = sum coef*K - rho[p]; vote
+ *   sk:utils/multiclass.py:542-584         ovr = votes + s/(3(|s|+1))
+ *   sk:calibration.py:727-784,928-942      expit(-(a*T+b)), normalise, argmax
+ * Inputs: either feat (float32 rows, general path) or feat_q (+row stats, exact path).
+ * Outputs (any may be NULL): dec_ovo N*P f64, dec_ovr N*C f64, proba N*C f64,
+ * label_vote N int32 (class index of SVC.predict), label_calib N int32 (class index of
+ * the calibrated predict; requires calibrators).
+ */
+int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
+                     const float* feat, int64_t ld_feat,
+                     const uint8_t* feat_q, int64_t ld_q, const int32_t* row_isum, const int64_t* row_isq,
+                     const int32_t* row_flags,
+                     int64_t N,
+                     double* dec_ovo, double* dec_ovr, double* proba,
+                     int32_t* label_vote, int32_t* label_calib, void* stream);
+
+/* Fused front door: volumes -> projection (mode, mask fixed at load: D must match) ->
+ * SVM outputs, features never returned to the caller.  Workspace is owned by the ctx and
+ * grows on demand. */
+int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, int64_t B, int X, int Y, int Z,
+                    int mode, const int32_t* ijk, float scale_div, uint32_t mask,
+                    double* dec_ovo, double* dec_ovr, double* proba,
+                    int32_t* label_vote, int32_t* label_calib, void* stream);
+
+/* ---- linear classifier (SGDClassifier(loss='log'), train.py:350-381; predict 421,433) --- */
+int rml_linear_load(rml_ctx* ctx, const double* coef /* host (C,D) */, const double* intercept /* host C */,
+                    int n_classes, int64_t D, const double* calib_a, const double* calib_b, rml_linear** out);
+int rml_linear_free(rml_ctx* ctx, rml_linear* m);
+int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, int64_t ld_feat, int64_t N,
+                        double* dec /* N*C */, double* proba /* N*C or NULL */, int32_t* label /* argmax dec */,
+                        int32_t* label_calib, void* stream);
+
+/* ---- synthetic data (bench / tests) --------------------------------------- */
+int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
+                      int n_classes, float* V, int32_t* cls /* B or NULL */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADARML_H */

@@ -1,0 +1,133 @@
+"""ctypes binding of libradarml_hip.so (the C ABI declared in include/radarml.h).
+
+The product path has no CPU fallback: if the library cannot be loaded, or a call fails, a
+``RadarMLError`` is raised.  PyTorch-ROCm is used only as the device allocator / stream
+provider; tensors cross the boundary as raw device pointers.
+"""
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libradarml_hip.so")
+
+
+class RadarMLError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+_ctx = {}
+
+c_void_p, c_int, c_int64, c_uint32, c_uint64, c_float, c_double = (
+    C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double)
+
+# name -> (restype, argtypes): exactly the declarations of include/radarml.h
+SIGNATURES = {
+    "rml_version": (C.c_char_p, []),
+    "rml_last_error": (C.c_char_p, []),
+    "rml_ctx_create": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "rml_ctx_destroy": (c_int, [c_void_p]),
+    "rml_ctx_device": (c_int, [c_void_p]),
+    "rml_feature_len": (c_int64, [c_int, c_int, c_int, c_uint32]),
+    "rml_project": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
+                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_project_planes": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rml_assemble_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
+                                      c_uint32, c_void_p, c_int64, c_void_p]),
+    "rml_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_int64,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_svm_load": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                             c_double, c_double, c_void_p, c_void_p, C.POINTER(c_void_p)]),
+    "rml_svm_free": (c_int, [c_void_p, c_void_p]),
+    "rml_svm_is_exact": (c_int, [c_void_p]),
+    "rml_svm_num_sv": (c_int64, [c_void_p]),
+    "rml_svm_dim": (c_int64, [c_void_p]),
+    "rml_svm_decision": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
+                                c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_linear_load": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, C.POINTER(c_void_p)]),
+    "rml_linear_free": (c_int, [c_void_p, c_void_p]),
+    "rml_linear_decision": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+}
+
+MODE_MAX, MODE_SLICE, MODE_SUM = 0, 1, 2
+MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM}
+KERNEL_RBF, KERNEL_LINEAR = 0, 1
+PATH_AUTO, PATH_F32, PATH_I8 = 0, 1, 2
+PATHS = {"auto": PATH_AUTO, "f32": PATH_F32, "i8": PATH_I8}
+
+
+def load():
+    """Load the shared library (building nothing: run ``__graft_entry__.build()`` or
+    ``python radar-ml_amd/build.py`` first).  Raises RadarMLError when it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RadarMLError(
+                "libradarml_hip.so is not built (%s missing): run `python radar-ml_amd/build.py`; "
+                "there is no CPU fallback for the HIP path" % LIB_PATH)
+        # import torch first so that the process-wide HIP runtime (SONAME libamdhip64.so.*) is the one
+        # torch allocates with; our library then binds to the same runtime and can use torch's pointers.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is part of the image
+            pass
+        try:
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise RadarMLError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise RadarMLError("libradarml_hip.so does not export %s" % name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().rml_last_error()
+        raise RadarMLError("%s failed (status %d): %s" % (what or "radarml call", rc, msg.decode() if msg else ""))
+
+
+def context(device=None):
+    """One rml_ctx per device, created on first use."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
+    if device is None:
+        device = torch.cuda.current_device()
+    elif isinstance(device, torch.device):
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    lib = load()
+    with _lock:
+        if device not in _ctx:
+            h = c_void_p()
+            check(lib.rml_ctx_create(int(device), C.byref(h)), "rml_ctx_create")
+            _ctx[device] = h
+        return _ctx[device]
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

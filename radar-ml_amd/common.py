@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's ``common.py`` for the hot path.
+
+Same names, argument meaning and defaults as goruck/radar-ml ``common.py`` (file:line cited
+per symbol); the array work runs in the HIP kernels of ``libradarml_hip.so``.  The geometry
+helpers are scalar float64 host code exactly as in the reference (they are not a hot loop).
+"""
+import collections
+
+import numpy as np
+
+from . import _lib
+
+# Radar scan arena in spherical coordinates -- common.py:25-27
+R_MIN, R_MAX, R_RES = 10, 360, 2
+THETA_MIN, THETA_MAX, THETA_RES = -42, 42, 4
+PHI_MIN, PHI_MAX, PHI_RES = -30, 30, 2
+# common.py:30-31
+RADAR_MIN = 0.
+RADAR_MAX = 255.
+
+# common.py:40 / common.py:43 -- positional order (xz, yz, xy)
+ProjMask = collections.namedtuple('ProjMask', ['xz', 'yz', 'xy'])
+ProjZoom = collections.namedtuple('ProjZoom', ['xz', 'yz', 'xy'])
+
+
+def _mask_bits(proj_mask):
+    bits = 0
+    for i in range(3):
+        if proj_mask[i]:
+            bits |= 1 << i
+    if bits == 0:
+        raise ValueError("proj_mask selects no projection")
+    return bits
+
+
+def feature_len(size_x, size_y, size_z, proj_mask=ProjMask(True, True, True)):
+    """Length of a feature row: X*Z + Y*Z + X*Y over the selected planes (10010 at (22,31,176))."""
+    return int(_lib.load().rml_feature_len(size_x, size_y, size_z, _mask_bits(proj_mask)))
+
+
+# --------------------------------------------------------------------------------------------
+# geometry: common.py:93-121 (scalar host code, float64 like the reference)
+# --------------------------------------------------------------------------------------------
+def cartesian_to_spherical(x, y, z):
+    """common.py:93-97."""
+    r = np.sqrt(np.power(x, 2) + np.power(y, 2) + np.power(z, 2))
+    phi = np.arctan2(y, z)
+    theta = np.arcsin(x / r)
+    return (r, np.rad2deg(theta), np.rad2deg(phi))
+
+
+def spherical_to_cartesian(r, theta, phi):
+    """common.py:99-104."""
+    theta_rad, phi_rad = np.deg2rad(theta), np.deg2rad(phi)
+    x = r * np.sin(theta_rad)
+    y = r * np.cos(theta_rad) * np.sin(phi_rad)
+    z = r * np.cos(theta_rad) * np.cos(phi_rad)
+    return (x, y, z)
+
+
+def calculate_matrix_indices(x, y, z, size_x, size_y, size_z):
+    """common.py:106-121.  Scalars give a tuple of Python ints (truncation toward zero, no
+    clamping, exactly like ``int()``); arrays give an (n,3) int32 array (batched form used
+    to feed ``project(mode='slice')``)."""
+    r, theta, phi = cartesian_to_spherical(x, y, z)
+    fi = (theta - THETA_MIN) * (size_x - 1) / (THETA_MAX - THETA_MIN)
+    fj = (phi - PHI_MIN) * (size_y - 1) / (PHI_MAX - PHI_MIN)
+    fk = (r - R_MIN) * (size_z - 1) / (R_MAX - R_MIN)
+    if np.ndim(fi) == 0:
+        return (int(fi), int(fj), int(fk))
+    return np.stack([np.trunc(fi), np.trunc(fj), np.trunc(fk)], axis=-1).astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# device helpers
+# --------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _as_device_f32(a, device=None):
+    """numpy / torch (any device, any real dtype) -> contiguous float32 CUDA tensor."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if device is None:
+        device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return t.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+
+
+def project(volumes, mode="max", ijk=None, return_numpy=None):
+    """Batched 3-D -> 2-D projections: returns the reference's tuple ``(xz, yz, xy)``.
+
+    mode='slice': ``yz=V[i,:,:]``, ``xz=V[:,j,:]``, ``xy=V[:,:,k]`` per frame at ``ijk[b]``
+    (predict.py:102-107, ground_truth_samples.py:413-419; negative indices wrap like
+    Python's).  mode='max': the max-projection named by BASELINE.json.  mode='sum': the
+    reductions of common.py:51-53.  ``volumes`` is (B,X,Y,Z) or (X,Y,Z); numpy in -> numpy
+    out, torch CUDA in -> torch CUDA out.
+    """
+    torch = _torch()
+    lib = _lib.load()
+    is_np = not isinstance(volumes, torch.Tensor)
+    if return_numpy is None:
+        return_numpy = is_np
+    single = (volumes.ndim == 3)
+    v = _as_device_f32(volumes)
+    if single:
+        v = v.unsqueeze(0)
+    if v.ndim != 4:
+        raise ValueError("volumes must be (B,X,Y,Z) or (X,Y,Z)")
+    B, X, Y, Z = v.shape
+    dev = v.device
+    ctx = _lib.context(dev)
+    m = _lib.MODES[mode]
+    ijk_t = None
+    if m == _lib.MODE_SLICE:
+        if ijk is None:
+            raise ValueError("mode='slice' needs ijk")
+        ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
+            device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
+        if ijk_t.shape[0] != B:
+            raise ValueError("ijk must have one (i,j,k) per frame")
+        chk = ijk_t.cpu().numpy()
+        for ax, size in enumerate((X, Y, Z)):
+            if (chk[:, ax] >= size).any() or (chk[:, ax] < -size).any():
+                raise IndexError("index out of bounds for axis %d with size %d" % (ax, size))
+    xz = torch.empty((B, X, Z), dtype=torch.float32, device=dev)
+    yz = torch.empty((B, Y, Z), dtype=torch.float32, device=dev)
+    xy = torch.empty((B, X, Y), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_project_planes(ctx, _lib.ptr(v), B, X, Y, Z, m, _lib.ptr(ijk_t), _lib.ptr(xz), _lib.ptr(yz),
+                                          _lib.ptr(xy), _lib.stream_ptr(dev)), "rml_project_planes")
+    out = (xz, yz, xy)
+    if single:
+        out = tuple(o[0] for o in out)
+    if return_numpy:
+        out = tuple(o.cpu().numpy() for o in out)
+    return out
+
+
+def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, yz=True, xy=True), scale=False,
+                    out=None, codes=False):
+    """Fused batched front door: (B,X,Y,Z) volumes -> (B,D) float32 feature rows in one pass over
+    the volumes (projection + ``process_samples`` at zoom 1).  Returns a CUDA tensor; with
+    ``codes=True`` returns ``(feat, codes_u8, row_isum, row_isq, row_flags)`` for the exact SVM path.
+    """
+    torch = _torch()
+    lib = _lib.load()
+    v = _as_device_f32(volumes)
+    if v.ndim == 3:
+        v = v.unsqueeze(0)
+    B, X, Y, Z = v.shape
+    dev = v.device
+    ctx = _lib.context(dev)
+    bits = _mask_bits(proj_mask)
+    D = int(lib.rml_feature_len(X, Y, Z, bits))
+    m = _lib.MODES[mode]
+    ijk_t = None
+    if m == _lib.MODE_SLICE:
+        if ijk is None:
+            raise ValueError("mode='slice' needs ijk")
+        ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
+            device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
+    feat = out if out is not None else torch.empty((B, D), dtype=torch.float32, device=dev)
+    q = isum = isq = flags = None
+    ldq = 0
+    if codes:
+        ldq = (D + 127) // 128 * 128
+        q = torch.empty((B, ldq), dtype=torch.uint8, device=dev)
+        isum = torch.empty((B,), dtype=torch.int32, device=dev)
+        isq = torch.empty((B,), dtype=torch.int64, device=dev)
+        flags = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_project(ctx, _lib.ptr(v), B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
+                                   bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                   _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
+    if codes:
+        return feat, q, isum, isq, flags
+    return feat
+
+
+def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
+                    proj_zoom=ProjZoom(xz=[1.0, 1.0], yz=[1.0, 1.0], xy=[1.0, 1.0]), scale=False):
+    """Prepare samples for training or predictions -- drop-in for common.py:123-149.
+
+    Args:
+        samples (list of tuples of np arrays): radar projections [(xz, yz, xy)].
+        proj_mask (tuple of bool): projection(s) to use (xz, yz, xy) -- indexed positionally.
+        proj_zoom (tuple of list of floats): projection zoom factors (xz, yz, xy).
+        scale (bool): if True scales each feature to [0, 1] (``/ RADAR_MAX``).
+
+    Returns:
+        np.ndarray (N, D) float32, rows = np.concatenate((xz, yz, xy) selected, axis=None).
+
+    Zoom 1.0 (the value calc_proj_zoom produces whenever the predict arena equals the train
+    arena, predict.log:21) is handled as the identity: SciPy's order-3 spline round trip at
+    zoom 1 differs from it by <= 1.3e-13 absolute on 0..255 data.  Non-unit
+    zoom (order-3 spline resampling) is the next row of SURVEY.md §8(f) and raises here.
+    """
+    torch = _torch()
+    lib = _lib.load()
+    for i in range(3):
+        if proj_mask[i] and any(abs(float(z) - 1.0) > 1e-12 for z in proj_zoom[i]):
+            raise NotImplementedError(
+                "proj_zoom != 1.0 (spline resampling) is not implemented on the HIP path yet")
+    samples = list(samples)
+    n = len(samples)
+    if n == 0:
+        return np.array([])          # np.array([]) is what the reference returns for no samples
+    planes = []
+    for i in range(3):
+        if not proj_mask[i]:
+            planes.append(None)
+            continue
+        shp = np.shape(samples[0][i])
+        if len(shp) != 2:
+            raise ValueError("projection %d of sample 0 is not 2-D" % i)
+        for s in samples:
+            if np.shape(s[i]) != shp:
+                # the reference's np.array([...]) raises on ragged rows
+                raise ValueError("setting an array element with a sequence: ragged projection shapes")
+        planes.append(np.stack([np.asarray(s[i], dtype=np.float32) for s in samples]))
+    # grid sizes from the selected planes: xz (X,Z), yz (Y,Z), xy (X,Y)
+    X = planes[0].shape[1] if planes[0] is not None else (planes[2].shape[1] if planes[2] is not None else 1)
+    Z = planes[0].shape[2] if planes[0] is not None else (planes[1].shape[2] if planes[1] is not None else 1)
+    Y = planes[1].shape[1] if planes[1] is not None else (planes[2].shape[2] if planes[2] is not None else 1)
+    expect = [(X, Z), (Y, Z), (X, Y)]
+    for i in range(3):
+        if planes[i] is not None and tuple(planes[i].shape[1:]) != expect[i]:
+            raise ValueError("projection shapes are inconsistent: got %s for plane %d, expected %s"
+                             % (planes[i].shape[1:], i, expect[i]))
+    bits = _mask_bits(proj_mask)
+    D = int(lib.rml_feature_len(X, Y, Z, bits))
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    ctx = _lib.context(dev)
+    dplanes = [None if p is None else torch.from_numpy(p).to(dev) for p in planes]
+    feat = torch.empty((n, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_assemble_features(ctx, _lib.ptr(dplanes[0]), _lib.ptr(dplanes[1]), _lib.ptr(dplanes[2]), n, X, Y, Z,
+                                             float(RADAR_MAX) if scale else 0.0, bits, _lib.ptr(feat), D,
+                                             _lib.stream_ptr(dev)), "rml_assemble_features")
+    return feat.cpu().numpy()
+
+
+def derive_targets(volumes, num_targets=1, return_profiles=False):
+    """Batched DerivedTarget.get_derived_targets (common.py:49-80): (B,num_targets,3) int32
+    (i,j,k) triples, ascending by energy; optionally the three energy profiles."""
+    torch = _torch()
+    lib = _lib.load()
+    v = _as_device_f32(volumes)
+    if v.ndim == 3:
+        v = v.unsqueeze(0)
+    B, X, Y, Z = v.shape
+    dev = v.device
+    ctx = _lib.context(dev)
+    ijk = torch.empty((B, num_targets, 3), dtype=torch.int32, device=dev)
+    prof = torch.empty((B, X + Y + Z), dtype=torch.float32, device=dev) if return_profiles else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_derive_targets(ctx, _lib.ptr(v), B, X, Y, Z, int(num_targets), _lib.ptr(ijk), _lib.ptr(prof),
+                                          _lib.stream_ptr(dev)), "rml_derive_targets")
+    if return_profiles:
+        return ijk, prof
+    return ijk
+
+
+class DerivedTarget(collections.namedtuple('DerivedTarget',
+                                           ['xPosCm', 'yPosCm', 'zPosCm', 'amplitude', 'i', 'j', 'k'])):
+    """Radar targets derived from the raw image -- common.py:45-80."""
+
+    @staticmethod
+    def get_derived_targets(radar_data, size_x, size_y, size_z, num_targets=1):
+        """Same signature and return value as common.py:49; the sum reductions and the top-k run
+        on the GPU, the index -> (theta, phi, r) -> (x, y, z) mapping of ``make``
+        (common.py:62-79) on the host."""
+        ijk = derive_targets(np.asarray(radar_data).reshape(size_x, size_y, size_z), num_targets).cpu().numpy()[0]
+        out = []
+        for i, j, k in ijk:
+            i, j, k = int(i), int(j), int(k)
+            theta = THETA_MIN + i * (THETA_MAX - THETA_MIN) / (size_x - 1)
+            phi = PHI_MIN + j * (PHI_MAX - PHI_MIN) / (size_y - 1)
+            r = R_MIN + k * (R_MAX - R_MIN) / (size_z - 1)
+            x, y, z = spherical_to_cartesian(r, theta, phi)
+            out.append(DerivedTarget(xPosCm=x, yPosCm=y, zPosCm=z, amplitude=None, i=i, j=j, k=k))
+        return out

@@ -1,0 +1,97 @@
+// Context, error reporting and workspace management of libradarml_hip.so.
+#include "rml_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <new>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void rml_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int rml_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    rml_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return RML_ERR_HIP;
+}
+
+int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->ws_bytes) {
+        if (ctx->ws) {
+            // the old block may still be in use by queued work on any stream
+            RML_HIP(hipDeviceSynchronize());
+            RML_HIP(hipFree(ctx->ws));
+            ctx->ws = nullptr;
+            ctx->ws_bytes = 0;
+        }
+        size_t want = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&ctx->ws, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&ctx->ws, want);
+        }
+        if (e != hipSuccess) {
+            rml_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return RML_ERR_NOMEM;
+        }
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return RML_OK;
+}
+
+extern "C" const char* rml_version(void) { return "radarml-hip 0.1 (gfx950)"; }
+extern "C" const char* rml_last_error(void) { return g_err; }
+
+extern "C" int rml_ctx_create(int device, rml_ctx** out) {
+    RML_REQUIRE(out != nullptr, RML_ERR_INVALID, "rml_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    RML_HIP(hipGetDeviceCount(&n));
+    RML_REQUIRE(device >= 0 && device < n, RML_ERR_INVALID, "rml_ctx_create: device %d out of range (%d devices)", device, n);
+    RML_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RML_HIP(hipGetDeviceProperties(&prop, device));
+    rml_ctx* c = new (std::nothrow) rml_ctx();
+    RML_REQUIRE(c != nullptr, RML_ERR_NOMEM, "rml_ctx_create: out of host memory");
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->ev_proj[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return rml_hip_fail(e, "stream/event creation", __FILE__, __LINE__);
+    }
+    *out = c;
+    return RML_OK;
+}
+
+extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
+    if (!ctx) return RML_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_proj[i]) (void)hipEventDestroy(ctx->ev_proj[i]);
+        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    }
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    delete ctx;
+    return RML_OK;
+}
+
+extern "C" int rml_ctx_device(const rml_ctx* ctx) { return ctx ? ctx->device : RML_ERR_INVALID; }

@@ -1,0 +1,597 @@
+// 3-D radar volume -> (xz, yz, xy) projection kernels for gfx950 (MI355X).
+//
+// Reference sites replaced (paths in goruck/radar-ml):
+//   slices            predict.py:102-107, ground_truth_samples.py:413-419   (RML_MODE_SLICE)
+//   max-projection    BASELINE.json north_star / SURVEY.md §0.1 D1          (RML_MODE_MAX)
+//   sum reductions    common.py:51-53 (DerivedTarget.find_max_indices)      (RML_MODE_SUM)
+//   feature assembly  common.py:141-148 (process_samples at zoom 1): ravel + concatenate in
+//                     (xz, yz, xy) order, optional "/ RADAR_MAX" in float32
+//
+// Design (HBM-bound streaming reduction, one workgroup per frame, one pass over V):
+//   z is the contiguous axis.  Every lane loads float4 along z (16 B/lane, a wave covers
+//   64/LPR complete (i,j) rows per load instruction, LPR = lanes per row).  A workgroup's
+//   4 waves own NSLOT = 4*64/LPR row slots; slot s handles rows j = s + NSLOT*m, the same
+//   for every i, so
+//     yz[j,k] = op_i V   lives in registers of exactly one lane (NM float4 accumulators),
+//     xz[i,k] = op_j V   is reduced in-lane over m, across the row slots of a wave with
+//                        lane shuffles and across the 4 waves with LDS float atomics
+//                        (ds_max_f32 / ds_add_f32) -- no barrier inside the streaming loop,
+//     xy[i,j] = op_k V   is an in-lane float4 reduce + a butterfly over the LPR lanes of a row.
+//   The next i-plane is prefetched into registers while the current one is reduced.
+//   Epilogue: optional float32 division by RADAR_MAX (bit-identical to NumPy's), uint8 codes
+//   (biased by 128 for the signed i8 MFMA of the exact SVM path), per-row sum / sum of squares
+//   and the "all integers in [0,255]" flag, all fused -- the feature row never goes back to HBM
+//   between projection and assembly.
+//
+// Algorithmic HBM bytes per frame (mode MAX): 4*X*Y*Z read + 4*D written (+ D code bytes).
+#include "rml_internal.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct ProjParams {
+    const float* V;
+    int64_t B;
+    int X, Y, Z, ZQ;
+    const int32_t* ijk;
+    ProjOut o;
+    int vec_ok[3];   // float4 stores allowed for plane pl (16-B aligned base and stride)
+};
+
+template <int MODE> struct Op;
+template <> struct Op<RML_MODE_MAX> {
+    static __device__ __forceinline__ float ident() { return -INFINITY; }
+    static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ void lds_atomic(float* p, float v) {
+        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+template <> struct Op<RML_MODE_SUM> {
+    static __device__ __forceinline__ float ident() { return 0.0f; }
+    static __device__ __forceinline__ float f(float a, float b) { return a + b; }
+    static __device__ __forceinline__ void lds_atomic(float* p, float v) {
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+template <int MODE> __device__ __forceinline__ float4 op4(float4 a, float4 b) {
+    return make_float4(Op<MODE>::f(a.x, b.x), Op<MODE>::f(a.y, b.y), Op<MODE>::f(a.z, b.z), Op<MODE>::f(a.w, b.w));
+}
+
+// Per-thread sink for finished projection values: scaled float store, uint8 code store and
+// the row statistics of the exact-integer SVM path.
+struct Emitter {
+    const ProjParams& a;
+    int64_t b;
+    int32_t isum = 0;
+    int64_t isq = 0;
+    int ok = 1;
+    double nsq = 0.0;
+    bool want_stats;
+
+    __device__ Emitter(const ProjParams& a_, int64_t b_) : a(a_), b(b_) {
+        want_stats = a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.q[0] || a.o.q[1] || a.o.q[2];
+    }
+    __device__ __forceinline__ float scaled(float v) const {
+        // true IEEE division: bit-identical to NumPy's float32 "x / 255." (common.py:148)
+        return (a.o.scale_div > 1.0f) ? __fdiv_rn(v, a.o.scale_div) : v;
+    }
+    __device__ __forceinline__ uint32_t code(float v) {
+        int c = (int)v;
+        bool good = ((float)c == v) && c >= 0 && c <= 255;
+        ok &= good ? 1 : 0;
+        c = good ? c : 0;
+        isum += c;
+        isq += (int64_t)(c * c);
+        return (uint32_t)(c ^ 0x80);
+    }
+    // already-decided code (rml_quantize_rows)
+    __device__ __forceinline__ void put_code1(int pl, int64_t idx, int c, bool good) {
+        ok &= good ? 1 : 0;
+        c = good ? c : 0;
+        isum += c;
+        isq += (int64_t)(c * c);
+        if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)(c ^ 0x80);
+    }
+    __device__ __forceinline__ void put1(int pl, int64_t idx, float v) {
+        if (a.o.p[pl]) a.o.p[pl][b * a.o.stride[pl] + idx] = scaled(v);
+        if (a.o.row_nsq) { double t = (double)scaled(v); nsq += t * t; }
+        if (want_stats) {
+            uint32_t c = code(v);
+            if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)c;
+        }
+    }
+    // idx is a multiple of 4
+    __device__ __forceinline__ void put4(int pl, int64_t idx, float4 v) {
+        if (a.o.p[pl]) {
+            float* dst = a.o.p[pl] + b * a.o.stride[pl] + idx;
+            float4 s = make_float4(scaled(v.x), scaled(v.y), scaled(v.z), scaled(v.w));
+            if (a.o.row_nsq) {
+                nsq += (double)s.x * (double)s.x + (double)s.y * (double)s.y;
+                nsq += (double)s.z * (double)s.z + (double)s.w * (double)s.w;
+            }
+            if (a.vec_ok[pl]) {
+                *reinterpret_cast<float4*>(dst) = s;
+            } else {
+                dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
+            }
+        }
+        if (want_stats) {
+            uint32_t c0 = code(v.x), c1 = code(v.y), c2 = code(v.z), c3 = code(v.w);
+            if (a.o.q[pl]) {
+                uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
+            }
+        }
+    }
+    // block reduction of the statistics; red must hold >= 16 int64 slots; all threads call it
+    __device__ void finish(int64_t* red) {
+        if (a.o.qrow) {   // zero the pad columns [qD, qstride) of the code row (i8 value 0)
+            for (int64_t c = a.o.qD + threadIdx.x; c < a.o.qstride; c += kThreads) a.o.qrow[b * a.o.qstride + c] = 0;
+        }
+        if (a.o.prow) {   // zero the pad columns [pD, pstride) of the float row
+            for (int64_t c = a.o.pD + threadIdx.x; c < a.o.pstride; c += kThreads) a.o.prow[b * a.o.pstride + c] = 0.0f;
+        }
+        if (!(a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.row_nsq)) return;
+        int64_t s = isum, q = isq;
+        int g = ok;
+        double nn = nsq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+            g &= __shfl_xor(g, off);
+            nn += __shfl_xor(nn, off);
+        }
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double* redd = reinterpret_cast<double*>(red + 12);
+        __syncthreads();
+        if (lane == 0) { red[wave * 3 + 0] = s; red[wave * 3 + 1] = q; red[wave * 3 + 2] = g; redd[wave] = nn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t S = 0, Q = 0, G = 1;
+            double NN = 0.0;
+            for (int w = 0; w < kThreads / 64; ++w) { S += red[w * 3]; Q += red[w * 3 + 1]; G &= red[w * 3 + 2]; NN += redd[w]; }
+            if (a.o.row_isum) a.o.row_isum[b] = (int32_t)S;
+            if (a.o.row_isq) a.o.row_isq[b] = Q;
+            if (a.o.row_flags) a.o.row_flags[b] = (int32_t)G;
+            if (a.o.row_nsq) a.o.row_nsq[b] = NN;
+        }
+    }
+};
+
+// butterfly reduction over the LPR lanes of a row (all lanes end with the result)
+template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) r = Op<MODE>::f(r, __shfl_xor(r, off));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast path: Z % 4 == 0, Z/4 <= 64, Y <= NM * NSLOT.  One workgroup (256 threads) per frame.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int LPR, int NM>
+__global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
+    extern __shared__ __align__(16) float lds[];
+    if (a.o.skip_if_set && *a.o.skip_if_set) return;
+    const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
+    float* xz_lds = lds;                 // X*Z
+    float* xy_lds = lds + (size_t)X * Z; // X*Y
+    int64_t* red = reinterpret_cast<int64_t*>(xy_lds + (((size_t)X * Y + 3) & ~(size_t)3));
+
+    constexpr int RPW = 64 / LPR;       // rows per wave-load
+    constexpr int NSLOT = 4 * RPW;      // row slots per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = wave * RPW + lane / LPR;
+    const int kq = lane % LPR;
+    const bool act = kq < ZQ;
+    const int64_t b = blockIdx.x;
+    const float4* __restrict__ Vb = reinterpret_cast<const float4*>(a.V + b * (int64_t)X * Y * Z);
+
+    const float id = Op<MODE>::ident();
+    const float4 id4 = make_float4(id, id, id, id);
+    for (int idx = tid; idx < X * Z; idx += kThreads) xz_lds[idx] = id;
+    __syncthreads();
+
+    float4 yz[NM];
+    int roff[NM];
+    bool rv[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        int j = slot + NSLOT * m;
+        rv[m] = act && (j < Y);
+        roff[m] = j * ZQ + kq;
+        yz[m] = id4;
+    }
+    const int plane = Y * ZQ;
+
+    float4 cur[NM], nxt[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) cur[m] = rv[m] ? Vb[roff[m]] : id4;
+
+    for (int i = 0; i < X; ++i) {
+        if (i + 1 < X) {
+            const float4* __restrict__ Vn = Vb + (int64_t)(i + 1) * plane;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) nxt[m] = rv[m] ? Vn[roff[m]] : id4;
+        }
+        float4 p = id4;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            yz[m] = op4<MODE>(yz[m], cur[m]);
+            p = op4<MODE>(p, cur[m]);
+            float r = Op<MODE>::f(Op<MODE>::f(cur[m].x, cur[m].y), Op<MODE>::f(cur[m].z, cur[m].w));
+            r = row_reduce<MODE, LPR>(r);
+            int j = slot + NSLOT * m;
+            if (kq == 0 && j < Y) xy_lds[i * Y + j] = r;
+        }
+        // combine the row slots that share this wave, then the 4 waves through LDS atomics
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            float4 q;
+            q.x = __shfl_xor(p.x, off); q.y = __shfl_xor(p.y, off);
+            q.z = __shfl_xor(p.z, off); q.w = __shfl_xor(p.w, off);
+            p = op4<MODE>(p, q);
+        }
+        if (lane < LPR && act) {
+            float* dst = xz_lds + i * Z + 4 * kq;
+            Op<MODE>::lds_atomic(dst + 0, p.x);
+            Op<MODE>::lds_atomic(dst + 1, p.y);
+            Op<MODE>::lds_atomic(dst + 2, p.z);
+            Op<MODE>::lds_atomic(dst + 3, p.w);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) cur[m] = nxt[m];
+    }
+
+    Emitter em(a, b);
+    // yz straight from registers: lane owns (j_m, 4kq..4kq+3)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        int j = slot + NSLOT * m;
+        if (rv[m]) em.put4(1, (int64_t)j * Z + 4 * kq, yz[m]);
+    }
+    __syncthreads();
+    // xz and xy from LDS, coalesced
+    const int nxz4 = (X * Z) >> 2;
+    for (int idx = tid; idx < nxz4; idx += kThreads)
+        em.put4(0, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xz_lds + idx * 4));
+    const int nxy = X * Y;
+    const int nxy4 = nxy >> 2;
+    for (int idx = tid; idx < nxy4; idx += kThreads)
+        em.put4(2, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xy_lds + idx * 4));
+    for (int idx = nxy4 * 4 + tid; idx < nxy; idx += kThreads) em.put1(2, idx, xy_lds[idx]);
+    em.finish(red);
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic fallback: any (X,Y,Z).  Three coalesced passes over the frame (L2 resident after
+// the first), no shape restrictions.  One workgroup per frame.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
+    __shared__ int64_t red[16];
+    if (a.o.skip_if_set && *a.o.skip_if_set) return;
+    const int X = a.X, Y = a.Y, Z = a.Z;
+    const int64_t b = blockIdx.x;
+    const float* __restrict__ Vb = a.V + b * (int64_t)X * Y * Z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Emitter em(a, b);
+    const float id = Op<MODE>::ident();
+    // xz[i,k] = op_j V[i,j,k]
+    for (int idx = tid; idx < X * Z; idx += kThreads) {
+        int i = idx / Z, k = idx - i * Z;
+        float r = id;
+        for (int j = 0; j < Y; ++j) r = Op<MODE>::f(r, Vb[((int64_t)i * Y + j) * Z + k]);
+        em.put1(0, idx, r);
+    }
+    // yz[j,k] = op_i V[i,j,k]
+    for (int idx = tid; idx < Y * Z; idx += kThreads) {
+        float r = id;
+        for (int i = 0; i < X; ++i) r = Op<MODE>::f(r, Vb[(int64_t)i * Y * Z + idx]);
+        em.put1(1, idx, r);
+    }
+    // xy[i,j] = op_k V[i,j,k]: one wave per row
+    for (int row = wave; row < X * Y; row += kThreads / 64) {
+        float r = id;
+        for (int k = lane; k < Z; k += 64) r = Op<MODE>::f(r, Vb[(int64_t)row * Z + k]);
+        r = row_reduce<MODE, 64>(r);
+        if (lane == 0) em.put1(2, row, r);
+    }
+    em.finish(red);
+}
+
+// ------------------------------------------------------------------------------------------
+// Slice mode: planes through (i,j,k) of each frame, Python negative-index wrap.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
+    __shared__ int64_t red[16];
+    if (a.o.skip_if_set && *a.o.skip_if_set) return;
+    const int X = a.X, Y = a.Y, Z = a.Z;
+    const int64_t b = blockIdx.x;
+    const float* __restrict__ Vb = a.V + b * (int64_t)X * Y * Z;
+    int i = a.ijk[b * 3 + 0], j = a.ijk[b * 3 + 1], k = a.ijk[b * 3 + 2];
+    i = i < 0 ? i + X : i; j = j < 0 ? j + Y : j; k = k < 0 ? k + Z : k;
+    // out-of-range after wrapping would raise IndexError in the reference; clamp defensively
+    i = min(max(i, 0), X - 1); j = min(max(j, 0), Y - 1); k = min(max(k, 0), Z - 1);
+    const int tid = threadIdx.x;
+    Emitter em(a, b);
+    for (int idx = tid; idx < X * Z; idx += kThreads) {          // xz = V[:, j, :]
+        int ii = idx / Z, kk = idx - ii * Z;
+        em.put1(0, idx, Vb[((int64_t)ii * Y + j) * Z + kk]);
+    }
+    for (int idx = tid; idx < Y * Z; idx += kThreads)            // yz = V[i, :, :]
+        em.put1(1, idx, Vb[(int64_t)i * Y * Z + idx]);
+    for (int idx = tid; idx < X * Y; idx += kThreads)            // xy = V[:, :, k]
+        em.put1(2, idx, Vb[(int64_t)idx * Z + k]);
+    em.finish(red);
+}
+
+// planes -> rows (common.process_samples at zoom 1 on already separate projections)
+__global__ __launch_bounds__(kThreads) void k_assemble(const float* xz, const float* yz, const float* xy, ProjParams a) {
+    __shared__ int64_t red[16];
+    const int X = a.X, Y = a.Y, Z = a.Z;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    Emitter em(a, b);
+    if (xz) for (int idx = tid; idx < X * Z; idx += kThreads) em.put1(0, idx, xz[b * (int64_t)X * Z + idx]);
+    if (yz) for (int idx = tid; idx < Y * Z; idx += kThreads) em.put1(1, idx, yz[b * (int64_t)Y * Z + idx]);
+    if (xy) for (int idx = tid; idx < X * Y; idx += kThreads) em.put1(2, idx, xy[b * (int64_t)X * Y + idx]);
+    em.finish(red);
+}
+
+// float rows -> codes + stats (rml_quantize_rows).  A value is on the code grid iff it is
+// bit-identical to float32(c / scale_div) (the "p / 255." of train.py:667) or to c itself.
+__global__ __launch_bounds__(kThreads) void k_quantize_rows(const float* feat, int64_t D, int64_t ld, float scale_div, ProjParams a) {
+    __shared__ int64_t red[16];
+    const int64_t b = blockIdx.x;
+    Emitter em(a, b);
+    const bool scaled = scale_div > 1.0f;
+    for (int64_t idx = threadIdx.x; idx < D; idx += kThreads) {
+        float v = feat[b * ld + idx];
+        float c = rintf(scaled ? v * scale_div : v);
+        float back = scaled ? __fdiv_rn(c, scale_div) : c;
+        bool good = (back == v) && c >= 0.0f && c <= 255.0f;
+        em.put_code1(0, idx, good ? (int)c : 0, good);
+    }
+    em.finish(red);
+}
+
+// energy profiles + top-n indices from the sum planes (common.py:51-55, 80)
+__global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const float* yzs, int X, int Y, int Z,
+                                                      int ntgt, int32_t* ijk, float* profiles) {
+    extern __shared__ float prof[];   // X + Y + Z
+    const int64_t b = blockIdx.x;
+    const float* xz = xzs + b * (int64_t)X * Z;
+    const float* yz = yzs + b * (int64_t)Y * Z;
+    const int lane = threadIdx.x;
+    float* s_theta = prof; float* s_phi = prof + X; float* s_r = prof + X + Y;
+    for (int i = lane; i < X; i += 64) { float s = 0; for (int k = 0; k < Z; ++k) s += xz[i * Z + k]; s_theta[i] = s; }
+    for (int j = lane; j < Y; j += 64) { float s = 0; for (int k = 0; k < Z; ++k) s += yz[j * Z + k]; s_phi[j] = s; }
+    for (int k = lane; k < Z; k += 64) { float s = 0; for (int j = 0; j < Y; ++j) s += yz[j * Z + k]; s_r[k] = s; }
+    __syncthreads();
+    if (profiles) for (int t = lane; t < X + Y + Z; t += 64) profiles[b * (int64_t)(X + Y + Z) + t] = prof[t];
+    __syncthreads();
+    if (lane < 3) {
+        float* s = lane == 0 ? s_theta : (lane == 1 ? s_phi : s_r);
+        int L = lane == 0 ? X : (lane == 1 ? Y : Z);
+        // repeated arg-max; result list ascending by value (largest last), ties: higher index = larger
+        for (int t = 0; t < ntgt; ++t) {
+            int best = -1; float bv = -INFINITY;
+            for (int q = 0; q < L; ++q) {
+                float v = s[q];
+                if (v != v) v = -INFINITY;
+                if (best < 0 || v >= bv) { bv = v; best = q; }
+            }
+            ijk[(b * ntgt + (ntgt - 1 - t)) * 3 + lane] = best;
+            s[best] = -INFINITY;
+        }
+    }
+}
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <int MODE, int LPR>
+int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t st) {
+    dim3 grid((unsigned)pp.B), block(kThreads);
+    if (nm <= 4) {
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, 4>), grid, block, lds_bytes, st, pp);
+    } else if (nm <= 8) {
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, 8>), grid, block, lds_bytes, st, pp);
+    } else {
+        return 1;
+    }
+    return 0;
+}
+
+template <int MODE>
+int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
+    const int X = pp.X, Y = pp.Y, Z = pp.Z;
+    *used_fast = false;
+    bool fast_ok = (Z % 4 == 0) && (Z / 4 <= 64) && ((reinterpret_cast<uintptr_t>(pp.V) & 15) == 0);
+    size_t lds_bytes = ((size_t)X * Z + (((size_t)X * Y + 3) & ~(size_t)3)) * 4 + 16 * 8;
+    if (lds_bytes > 150 * 1024) fast_ok = false;
+    if (fast_ok) {
+        int zq = Z / 4;
+        int lpr = next_pow2(zq); if (lpr < 16) lpr = 16;
+        int nslot = 4 * (64 / lpr);
+        int nm = (Y + nslot - 1) / nslot;
+        int rc = 1;
+        if (lpr == 16) rc = launch_fast_nm<MODE, 16>(pp, nm, lds_bytes, st);
+        else if (lpr == 32) rc = launch_fast_nm<MODE, 32>(pp, nm, lds_bytes, st);
+        else rc = launch_fast_nm<MODE, 64>(pp, nm, lds_bytes, st);
+        if (rc == 0) { *used_fast = true; return 0; }
+    }
+    hipLaunchKernelGGL((k_project_generic<MODE>), dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
+    return 0;
+}
+
+void fill_params(ProjParams& pp, const float* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
+    pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.o = o;
+    for (int pl = 0; pl < 3; ++pl)
+        pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
+}
+
+}  // namespace
+
+static int set_fast_attr_once() {
+    // allow > 64 KB dynamic LDS for the fast kernels (gfx950 has 160 KB per CU)
+    static bool done = false;
+    if (done) return 0;
+#define RML_SET_ATTR(MODE, LPR, NM) \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    RML_SET_ATTR(RML_MODE_MAX, 16, 4); RML_SET_ATTR(RML_MODE_MAX, 16, 8);
+    RML_SET_ATTR(RML_MODE_MAX, 32, 4); RML_SET_ATTR(RML_MODE_MAX, 32, 8);
+    RML_SET_ATTR(RML_MODE_MAX, 64, 4); RML_SET_ATTR(RML_MODE_MAX, 64, 8);
+    RML_SET_ATTR(RML_MODE_SUM, 16, 4); RML_SET_ATTR(RML_MODE_SUM, 16, 8);
+    RML_SET_ATTR(RML_MODE_SUM, 32, 4); RML_SET_ATTR(RML_MODE_SUM, 32, 8);
+    RML_SET_ATTR(RML_MODE_SUM, 64, 4); RML_SET_ATTR(RML_MODE_SUM, 64, 8);
+#undef RML_SET_ATTR
+    (void)hipGetLastError();
+    done = true;
+    return 0;
+}
+
+int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                       const int32_t* ijk, const ProjOut& o, hipStream_t st) {
+    (void)ctx;
+    if (B == 0) return RML_OK;
+    ProjParams pp;
+    fill_params(pp, V, B, X, Y, Z, ijk, o);
+    set_fast_attr_once();
+    bool fast = false;
+    if (mode == RML_MODE_MAX) launch_mode<RML_MODE_MAX>(pp, st, &fast);
+    else if (mode == RML_MODE_SUM) launch_mode<RML_MODE_SUM>(pp, st, &fast);
+    else if (mode == RML_MODE_SLICE) {
+        RML_REQUIRE(ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
+        hipLaunchKernelGGL(k_project_slice, dim3((unsigned)B), dim3(kThreads), 0, st, pp);
+    } else {
+        RML_REQUIRE(false, RML_ERR_INVALID, "rml_project: unknown mode %d", mode);
+    }
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// ---- exported entry points ------------------------------------------------------------------
+static int plane_len(int pl, int X, int Y, int Z) { return pl == 0 ? X * Z : (pl == 1 ? Y * Z : X * Y); }
+
+extern "C" int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask) {
+    int64_t d = 0;
+    for (int pl = 0; pl < 3; ++pl) if (mask & (1u << pl)) d += plane_len(pl, X, Y, Z);
+    return d;
+}
+
+extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                           const int32_t* ijk, float scale_div, uint32_t mask,
+                           float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
+                           int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
+    RML_REQUIRE(ctx && V && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project: bad arguments");
+    RML_REQUIRE((mask & RML_MASK_ALL) != 0, RML_ERR_INVALID, "rml_project: empty projection mask");
+    RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_project: B too large for one launch");
+    const int64_t D = rml_feature_len(X, Y, Z, mask);
+    RML_REQUIRE(!feat || ld_feat >= D, RML_ERR_INVALID, "rml_project: ld_feat < D");
+    RML_REQUIRE(!feat_q || (ld_q >= D && ld_q % 4 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 3) == 0),
+                RML_ERR_INVALID, "rml_project: feat_q needs ld_q >= D, ld_q %% 4 == 0 and 4-byte alignment");
+    RML_HIP(hipSetDevice(ctx->device));
+    ProjOut o{};
+    int64_t off = 0;
+    for (int pl = 0; pl < 3; ++pl) {
+        if (mask & (1u << pl)) {
+            o.p[pl] = feat ? feat + off : nullptr;
+            o.stride[pl] = ld_feat;
+            o.q[pl] = feat_q ? feat_q + off : nullptr;
+            off += plane_len(pl, X, Y, Z);
+        }
+    }
+    o.qstride = ld_q;
+    o.qrow = feat_q; o.qD = D;
+    o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
+    o.scale_div = scale_div;
+    return rml_launch_project(ctx, V, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                                  const int32_t* ijk, float* xz, float* yz, float* xy, void* stream) {
+    RML_REQUIRE(ctx && V && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project_planes: bad arguments");
+    RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_project_planes: B too large for one launch");
+    RML_HIP(hipSetDevice(ctx->device));
+    ProjOut o{};
+    o.p[0] = xz; o.stride[0] = (int64_t)X * Z;
+    o.p[1] = yz; o.stride[1] = (int64_t)Y * Z;
+    o.p[2] = xy; o.stride[2] = (int64_t)X * Y;
+    o.scale_div = 0.0f;
+    return rml_launch_project(ctx, V, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z,
+                                  int num_targets, int32_t* ijk, float* profiles, void* stream) {
+    RML_REQUIRE(ctx && V && ijk && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_derive_targets: bad arguments");
+    RML_REQUIRE(num_targets >= 1 && num_targets <= X && num_targets <= Y && num_targets <= Z, RML_ERR_INVALID,
+                "rml_derive_targets: num_targets out of range");
+    RML_HIP(hipSetDevice(ctx->device));
+    if (B == 0) return RML_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // workspace: sum planes xz (B,X,Z) and yz (B,Y,Z)
+    size_t need = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
+    void* ws = nullptr;
+    int rc = rml_ws_reserve(ctx, need, &ws);
+    if (rc) return rc;
+    float* xzs = static_cast<float*>(ws);
+    float* yzs = xzs + (size_t)B * X * Z;
+    ProjOut o{};
+    o.p[0] = xzs; o.stride[0] = (int64_t)X * Z;
+    o.p[1] = yzs; o.stride[1] = (int64_t)Y * Z;
+    o.scale_div = 0.0f;
+    rc = rml_launch_project(ctx, V, B, X, Y, Z, RML_MODE_SUM, nullptr, o, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_profiles_topk, dim3((unsigned)B), dim3(64), (size_t)(X + Y + Z) * sizeof(float), st,
+                       xzs, yzs, X, Y, Z, num_targets, ijk, profiles);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int rml_assemble_features(rml_ctx* ctx, const float* xz, const float* yz, const float* xy,
+                                     int64_t B, int X, int Y, int Z, float scale_div, uint32_t mask,
+                                     float* feat, int64_t ld_feat, void* stream) {
+    RML_REQUIRE(ctx && feat && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_assemble_features: bad arguments");
+    RML_REQUIRE((mask & RML_MASK_ALL) != 0, RML_ERR_INVALID, "rml_assemble_features: empty mask");
+    const float* src[3] = {xz, yz, xy};
+    for (int pl = 0; pl < 3; ++pl)
+        RML_REQUIRE(!(mask & (1u << pl)) || src[pl], RML_ERR_INVALID, "rml_assemble_features: selected plane %d is NULL", pl);
+    const int64_t D = rml_feature_len(X, Y, Z, mask);
+    RML_REQUIRE(ld_feat >= D, RML_ERR_INVALID, "rml_assemble_features: ld_feat < D");
+    RML_HIP(hipSetDevice(ctx->device));
+    if (B == 0) return RML_OK;
+    ProjOut o{};
+    int64_t off = 0;
+    for (int pl = 0; pl < 3; ++pl)
+        if (mask & (1u << pl)) { o.p[pl] = feat + off; o.stride[pl] = ld_feat; off += plane_len(pl, X, Y, Z); }
+    o.scale_div = scale_div;
+    ProjParams pp;
+    fill_params(pp, nullptr, B, X, Y, Z, nullptr, o);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)B), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       (mask & 1u) ? xz : nullptr, (mask & 2u) ? yz : nullptr, (mask & 4u) ? xy : nullptr, pp);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int rml_quantize_rows(rml_ctx* ctx, const float* feat, int64_t N, int64_t D, int64_t ld_feat,
+                                 float scale_div, uint8_t* feat_q, int64_t ld_q,
+                                 int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
+    RML_REQUIRE(ctx && feat && feat_q && N >= 0 && D > 0 && ld_feat >= D && ld_q >= D, RML_ERR_INVALID,
+                "rml_quantize_rows: bad arguments");
+    RML_HIP(hipSetDevice(ctx->device));
+    if (N == 0) return RML_OK;
+    ProjOut o{};
+    o.q[0] = feat_q; o.qstride = ld_q; o.qrow = feat_q; o.qD = D;
+    o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
+    o.scale_div = 0.0f;
+    ProjParams pp;
+    fill_params(pp, nullptr, N, 1, 1, 1, nullptr, o);
+    hipLaunchKernelGGL(k_quantize_rows, dim3((unsigned)N), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       feat, D, ld_feat, scale_div, pp);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libradarml_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/radarml.h"
+
+struct rml_ctx {
+    int device = 0;
+    int num_cu = 256;
+    // grow-on-demand device workspace for the fused front doors (owned by the ctx)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm
+    hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
+};
+
+void rml_set_error(const char* fmt, ...);
+int rml_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define RML_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t _e = (call);                                              \
+        if (_e != hipSuccess) return rml_hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define RML_REQUIRE(cond, status, ...)      \
+    do {                                    \
+        if (!(cond)) {                      \
+            rml_set_error(__VA_ARGS__);     \
+            return (status);                \
+        }                                   \
+    } while (0)
+
+int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out);
+
+// ---- projection (project.hip) -------------------------------------------------------------
+struct ProjOut {
+    // destination of each plane for frame b: p[pl] + b*stride[pl] (float) ; NULL = plane not wanted
+    float* p[3];
+    int64_t stride[3];
+    // uint8 codes of the same values (before scaling); NULL = not wanted
+    uint8_t* q[3];
+    int64_t qstride;
+    uint8_t* qrow;     // base of the code rows (pad columns [qD, qstride) are zeroed), or NULL
+    int64_t qD;
+    int32_t* row_isum;
+    int64_t* row_isq;
+    int32_t* row_flags;
+    float scale_div;   // 0/1 => none
+    // float row bookkeeping for the SVM front door: zero the pad columns [pD, stride) of the
+    // float row at prow + b*pstride, and the float64 squared norm of the (scaled) row
+    float* prow;
+    int64_t pD, pstride;
+    double* row_nsq;
+    // predication: the whole launch is a no-op when *skip_if_set != 0 (device flag)
+    const int32_t* skip_if_set;
+};
+
+int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+                       const int32_t* ijk, const ProjOut& o, hipStream_t st);
+
+// ---- SVM (svm.hip) ------------------------------------------------------------------------
+struct rml_svm {
+    int64_t M = 0, Mpad = 0, D = 0;
+    int64_t Dq = 0;               // code row bytes   = round_up(D, 128)
+    int64_t Df = 0;               // float row length = round_up(D, 32)
+    int C = 0, P = 0, PT = 0, kernel = 0;
+    double gamma = 0, code_scale = 1;
+    bool exact = false, has_calib = false;
+    // device buffers
+    float* sv_f32 = nullptr;      // Mpad x Df, zero padded
+    double* sv_nsq = nullptr;     // Mpad  ||sv||^2 (float64)
+    uint8_t* sv_q = nullptr;      // Mpad x Dq codes XOR 0x80 (= int8 code-128); pad = 0
+    double* sv_term_q = nullptr;  // Mpad  exact-path per-SV term (see svm.hip)
+    double* W = nullptr;          // PT x Mpad per-pair SV weights (zero padded)
+    double* intercept = nullptr;  // P
+    double* calib = nullptr;      // 2*C (a then b)
+    uint32_t mask_hint = 0;
+};
+
+struct rml_linear {
+    int64_t D = 0;
+    int C = 0;
+    bool has_calib = false;
+    double* coef = nullptr;       // C x D
+    double* intercept = nullptr;  // C
+    double* calib = nullptr;      // 2*C
+};

@@ -1,0 +1,832 @@
+// RBF / linear C-SVC decision function on gfx950 matrix cores.
+//
+// Reference arithmetic replaced (sk: = scikit-learn, the reference's SVM dependency):
+//   sk:svm/src/libsvm/svm.cpp:461-475,514   K[n,m] = exp(-gamma * ||x_n - sv_m||^2)      (RBF)
+//   sk:svm/src/libsvm/svm.cpp:457            K[n,m] = x_n . sv_m                          (linear)
+//   sk:svm/src/libsvm/svm.cpp:2847-2890      dec[n,p] = sum_m coef*K - rho[p]; OvO vote
+//   sk:utils/multiclass.py:542-584           ovr = votes + s/(3(|s|+1))
+//   sk:calibration.py:727-784,928-942        expit(-(a*T+b)), normalise, clip, argmax
+// called from train.py:217,723-724 and predict.py:60.
+//
+// libsvm walks samples x SVs x D serially in float64.  Here the sample x SV inner products are
+// one GEMM on the matrix cores and everything after it is a fused float64 epilogue; the N x M
+// kernel matrix never exists in memory.
+//
+//   ||x - s||^2 = ||x||^2 + ||s||^2 - 2 x.s
+//
+// Two operand paths share one kernel skeleton (tiles staged by LDS-DMA, 128-byte rows):
+//   I8   radar features are integer codes c in [0,255] (optionally scaled by 1/255), so
+//        x.s is EXACT in int32 on v_mfma_i32_32x32x32_i8.  Codes are stored biased
+//        (byte = c ^ 0x80 = int8 c-128):  sum (a-128)(b-128) = sum ab - 128 (sum a + sum b) + 128^2 D.
+//        d^2 is then an exact integer, evaluated in float64.
+//   F32  general rows on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate), norms
+//        in float64.
+// Epilogue (float64): K = exp(-gamma d^2); per-pair weights W[p][m] (the libsvm pair loop
+// unrolled into a P x M matrix at load) -> S[n][p] += W[p][m] K.  The MFMA is issued with the
+// SV tile as the A (row) operand and the sample tile as the B (column) operand, so that a lane
+// owns ONE sample column and 16 SV rows per accumulator: the sum over SVs is in-lane, only a
+// 2-lane + 2-wave reduction per workgroup remains.  Per-SV-tile partial sums are written to
+// HBM (ST x N x P float64, fixed order) and summed by the finishing kernel in tile order, so
+// results are deterministic run to run.
+//
+// Workgroup tile 128 SVs x 128 samples, 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32.
+// K-step = 128 bytes per row (128 codes or 32 floats).  LDS image of a tile: row-major
+// [128 rows][128 B] with the 16-byte chunk index XOR-swizzled by (row>>1)&7, which makes the
+// ds_read_b128 fragment reads (lane = row, 16 B each) bank-conflict free.  LDS-DMA writes
+// lane-linear, so the swizzle is applied to the per-lane GLOBAL source address and again on
+// the read (both-sides rule).  Double-buffered: the DMA of K-step t+1 is in flight while the
+// MFMAs of K-step t run.  Block index -> (sample tile, SV tile) is XCD-aware: the 16 SV tiles
+// that share a sample tile run on one XCD so the sample K-slices are L2 hits.
+#include "rml_internal.h"
+#include <math.h>
+#include <vector>
+#include <type_traits>
+#include <algorithm>
+#include <new>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 128;         // rows per operand tile
+constexpr int kStepBytes = 128;    // K-step bytes per row
+constexpr int kTileBytes = kTile * kStepBytes;   // 16 KiB
+constexpr int PATH_I8 = 0, PATH_F32 = 1;
+
+struct GemmArgs {
+    const uint8_t* sv; int64_t ld_sv;     // SV operand, bytes per row
+    const uint8_t* x;  int64_t ld_x;      // sample operand, bytes per row
+    int KT;                                // K-steps
+    int64_t N;                             // valid sample rows
+    int ST, FT;                            // SV tiles, sample tiles
+    const int32_t* tile_exact; int want;   // process sample tile ft iff tile_exact[ft] == want (NULL: all)
+    const int32_t* x_isum; const int64_t* x_isq;   // exact path row statistics
+    const double* x_nsq;                            // f32 path row norms
+    const double* sv_term;                 // Mpad per-SV term (path/kernel specific)
+    const double* W; int64_t Mpad;         // PT x Mpad pair weights
+    double gs;                             // gamma/scale^2 (rbf) ; 1/scale^2 (linear, exact path)
+    int kernel;
+    double* partial; int64_t Npart;        // ST x Npart x PT
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int PATH, int PT>
+__global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware mapping: blocks b, b+8, b+16, ... share an XCD; give them the same sample tile
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int ftile = (slot / a.ST) * 8 + xcd;
+    const int stile = slot % a.ST;
+    if (ftile >= a.FT) return;
+    if (a.tile_exact && a.tile_exact[ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kTile;
+    const int64_t m0 = (int64_t)stile * kTile;
+
+    // per-SV epilogue table in LDS: [128][1+PT] float64
+    double* svw = reinterpret_cast<double*>(smem + 4 * kTileBytes);
+    for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
+    }
+
+    // staging addresses: 16 wave-instructions of 1 KiB per operand tile, 4 per wave
+    const uint8_t* gsv[4];
+    const uint8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;          // 16-byte slot in the LDS image
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * 2 * kTileBytes;
+        const int64_t ko = (int64_t)kt * kStepBytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gsv[q] + ko, base + (wave * 4 + q) * 1024);
+            glds16(gx[q] + ko, base + kTileBytes + (wave * 4 + q) * 1024);
+        }
+    };
+
+    // fragment read offsets (bytes within a tile image); lane = row, swizzled chunk
+    int aoff[2], asw[2], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int ra = wr * 64 + t * 32 + (lane & 31);
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+        boff[t] = rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+
+    using acc_t = typename std::conditional<PATH == PATH_I8, v16i, v16f>::type;
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    stage(0, 0);
+    for (int kt = 0; kt < a.KT; ++kt) {
+        __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
+        if (kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* sA = smem + (kt & 1) * 2 * kTileBytes;
+        const unsigned char* sB = sA + kTileBytes;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = 2 * kk + chalf;
+            v4i af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
+                bf[t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (PATH == PATH_I8) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(af[i][c]), __int_as_float(bf[j][c]),
+                                                                            acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- fused float64 epilogue ----------------------------------------------------------
+    // The accumulators go through LDS once (the four 16 KiB tile images are free now and are
+    // exactly 128 x 128 x 4 B) so that the epilogue can use its own thread mapping: thread t
+    // owns sample column n = t & 127 and the SV half h = t >> 7, i.e. 64 in-lane SV rows, reads
+    // G[m][n] with consecutive lanes on consecutive banks and the per-SV table as broadcasts.
+    __syncthreads();                           // everyone is done reading the tile images
+    {
+        int* gl = reinterpret_cast<int*>(smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                    const int nl = wc * 64 + j * 32 + (lane & 31);
+                    int bits;
+                    if constexpr (PATH == PATH_I8) bits = acc[i][j][r]; else bits = __float_as_int(acc[i][j][r]);
+                    gl[ml * kTile + nl] = bits;
+                }
+    }
+    __syncthreads();
+    const int nl = tid & 127, h = tid >> 7;
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    int64_t n = f0 + nl;
+    const int64_t nc = n < a.N ? n : a.N - 1;
+    double xt;
+    if constexpr (PATH == PATH_I8) {
+        // d^2 = (isq_x - 256 isum_x) + (isq_s - 256 isum_s + 32768 D) - 2 G'
+        xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+    } else {
+        xt = rbf ? a.x_nsq[nc] : 0.0;
+    }
+    double S[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) S[p] = 0.0;
+    const int* gcol = reinterpret_cast<const int*>(smem) + nl;
+#pragma unroll 2
+    for (int mm = 0; mm < 64; ++mm) {
+        const int ml = h * 64 + mm;
+        const double* e = svw + ml * (1 + PT);
+        const int bits = gcol[ml * kTile];
+        const double g = (PATH == PATH_I8) ? (double)bits : (double)__int_as_float(bits);
+        double kv;
+        if (rbf) {
+            double d2 = xt + e[0] - 2.0 * g;
+            d2 = d2 > 0.0 ? d2 : 0.0;
+            kv = exp(-a.gs * d2);
+        } else {
+            kv = (PATH == PATH_I8) ? (g + xt + e[0]) * a.gs : g;
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+    }
+    double* xch = svw + kTile * (1 + PT);      // [128][PT]
+    if (h == 1) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) xch[nl * PT + p] = S[p];
+    }
+    __syncthreads();
+    if (h == 0 && n < a.N) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[p] + xch[nl * PT + p];
+    }
+}
+
+// ---- row preparation for callers that bring float32 feature rows -------------------------
+// One workgroup per row: zero-padded float copy (ld = Df), float64 norm, codes + statistics.
+__global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t ld, int64_t D, float code_scale,
+                                                      float* f32, int64_t Df, double* nsq,
+                                                      uint8_t* q, int64_t Dq, int32_t* isum, int64_t* isq, int32_t* flags) {
+    __shared__ int64_t red[16];
+    const int64_t b = blockIdx.x;
+    const bool scaled = code_scale > 1.0f;
+    int32_t s = 0; int64_t sq = 0; int ok = 1; double nn = 0.0;
+    for (int64_t idx = threadIdx.x; idx < Dq || idx < Df; idx += 256) {
+        float v = idx < D ? feat[b * ld + idx] : 0.0f;
+        if (idx < Df) f32[b * Df + idx] = v;
+        nn += (double)v * (double)v;
+        if (q && idx < Dq) {
+            uint8_t code = 0;
+            if (idx < D) {
+                float c = rintf(scaled ? v * code_scale : v);
+                float back = scaled ? __fdiv_rn(c, code_scale) : c;
+                bool good = (back == v) && c >= 0.0f && c <= 255.0f;
+                int ci = good ? (int)c : 0;
+                ok &= good ? 1 : 0;
+                s += ci; sq += (int64_t)(ci * ci);
+                code = (uint8_t)(ci ^ 0x80);
+            }
+            q[b * Dq + idx] = code;
+        }
+    }
+    int64_t s64 = s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s64 += __shfl_xor(s64, off); sq += __shfl_xor(sq, off); ok &= __shfl_xor(ok, off); nn += __shfl_xor(nn, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* redd = reinterpret_cast<double*>(red + 12);
+    if (lane == 0) { red[wave * 3] = s64; red[wave * 3 + 1] = sq; red[wave * 3 + 2] = ok; redd[wave] = nn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t S = 0, Q = 0, G = 1; double NN = 0;
+        for (int w = 0; w < 4; ++w) { S += red[w * 3]; Q += red[w * 3 + 1]; G &= red[w * 3 + 2]; NN += redd[w]; }
+        if (isum) isum[b] = (int32_t)S;
+        if (isq) isq[b] = Q;
+        if (flags) flags[b] = q ? (int32_t)G : 0;
+        nsq[b] = NN;
+    }
+}
+
+// tile_exact[ft] = policy(flags of the 128 rows of tile ft); *all_exact = AND over tiles
+__global__ void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force f32,2 force i8*/,
+                             int model_exact, int32_t* tile_exact, int32_t* all_exact) {
+    const int ft = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ft >= FT) return;
+    int e;
+    if (policy == 1) e = 0;
+    else if (policy == 2) e = 1;
+    else {
+        e = model_exact && flags != nullptr;
+        if (e) {
+            int64_t r0 = (int64_t)ft * kTile, r1 = r0 + kTile < N ? r0 + kTile : N;
+            for (int64_t r = r0; r < r1; ++r) e &= (flags[r] != 0);
+        }
+    }
+    tile_exact[ft] = e;
+    if (!e && all_exact) atomicAnd(all_exact, 0);
+}
+
+__global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
+
+// ---- finishing kernel: fixed-order sum of the SV-tile partials + libsvm/sklearn tail ------
+struct FinishArgs {
+    const double* partial; int64_t Npart; int ST, PT;
+    int64_t N; int C, P;
+    const double* intercept; const double* calib; int has_calib;
+    const int32_t* row_flags; const int32_t* tile_exact;   // forced-i8 validity (rows with flag 0 -> NaN)
+    int forced_i8;
+    double* dec_ovo; double* dec_ovr; double* proba; int32_t* label_vote; int32_t* label_calib;
+};
+
+__device__ __forceinline__ double expit_d(double x) {
+    if (x >= 0.0) return 1.0 / (1.0 + exp(-x));
+    double e = exp(x);
+    return e / (1.0 + e);
+}
+
+constexpr int kMaxC = 4, kMaxP = 6;
+
+__global__ __launch_bounds__(256) void k_svm_finish(FinishArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const int C = a.C, P = a.P;
+    double dec[kMaxP];
+    for (int p = 0; p < P; ++p) {
+        double s = 0.0;
+        for (int st = 0; st < a.ST; ++st) s += a.partial[((int64_t)st * a.Npart + n) * a.PT + p];
+        dec[p] = s + a.intercept[p];           // sum -= rho[p]  (rho = -intercept_)
+    }
+    bool valid = true;
+    if (a.forced_i8 && a.row_flags) valid = a.row_flags[n] != 0;
+    if (!valid) for (int p = 0; p < P; ++p) dec[p] = NAN;
+    if (a.dec_ovo) for (int p = 0; p < P; ++p) a.dec_ovo[n * P + p] = dec[p];
+
+    // libsvm vote: dec > 0 -> ++vote[i] else ++vote[j]; first maximum wins (svm.cpp:2884-2894)
+    int vote[kMaxC];
+    for (int c = 0; c < C; ++c) vote[c] = 0;
+    {
+        int p = 0;
+        for (int i = 0; i < C; ++i)
+            for (int j = i + 1; j < C; ++j, ++p) { if (dec[p] > 0) ++vote[i]; else ++vote[j]; }
+    }
+    int best = 0;
+    for (int c = 1; c < C; ++c) if (vote[c] > vote[best]) best = c;
+    if (a.label_vote) a.label_vote[n] = valid ? best : -1;
+
+    double T[kMaxC];
+    if (C == 2) {
+        // sklearn flips the sign for binary problems (sk:svm/_base.py:546-547): T = -dec
+        T[0] = -dec[0];
+        if (a.dec_ovr) a.dec_ovr[n] = T[0];
+    } else {
+        // _ovr_decision_function(dec < 0, -dec, C)
+        double soc[kMaxC]; double vt[kMaxC];
+        for (int c = 0; c < C; ++c) { soc[c] = 0.0; vt[c] = 0.0; }
+        int p = 0;
+        for (int i = 0; i < C; ++i)
+            for (int j = i + 1; j < C; ++j, ++p) {
+                double conf = -dec[p];
+                soc[i] -= conf; soc[j] += conf;
+                if (dec[p] < 0) vt[j] += 1.0; else vt[i] += 1.0;
+            }
+        for (int c = 0; c < C; ++c) T[c] = vt[c] + soc[c] / (3.0 * (fabs(soc[c]) + 1.0));
+        if (!valid) for (int c = 0; c < C; ++c) T[c] = NAN;
+        if (a.dec_ovr) for (int c = 0; c < C; ++c) a.dec_ovr[n * C + c] = T[c];
+    }
+    if (a.has_calib && (a.proba || a.label_calib)) {
+        double pr[kMaxC];
+        if (C == 2) {
+            pr[1] = expit_d(-(a.calib[0] * T[0] + a.calib[C + 0]));
+            pr[0] = 1.0 - pr[1];
+        } else {
+            double den = 0.0;
+            for (int c = 0; c < C; ++c) { pr[c] = expit_d(-(a.calib[c] * T[c] + a.calib[C + c])); den += pr[c]; }
+            for (int c = 0; c < C; ++c) pr[c] = (den != 0.0) ? pr[c] / den : 1.0 / C;
+        }
+        for (int c = 0; c < C; ++c) if (pr[c] > 1.0 && pr[c] <= 1.0 + 1e-5) pr[c] = 1.0;
+        if (a.proba) for (int c = 0; c < C; ++c) a.proba[n * C + c] = valid ? pr[c] : NAN;
+        int bc = 0;
+        for (int c = 1; c < C; ++c) if (pr[c] > pr[bc]) bc = c;
+        if (a.label_calib) a.label_calib[n] = valid ? bc : -1;
+    }
+}
+
+// ---- linear classifier: one wave per row, float64 accumulation ----------------------------
+__global__ __launch_bounds__(256) void k_linear(const float* feat, int64_t ld, int64_t N, int64_t D, int C,
+                                                const double* coef, const double* intercept, const double* calib, int has_calib,
+                                                double* dec, double* proba, int32_t* label, int32_t* label_calib) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    double s[kMaxC];
+    for (int c = 0; c < C; ++c) s[c] = 0.0;
+    for (int64_t d = lane; d < D; d += 64) {
+        double x = (double)feat[n * ld + d];
+        for (int c = 0; c < C; ++c) s[c] = fma(x, coef[c * D + d], s[c]);
+    }
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[c] += __shfl_xor(s[c], off);
+        s[c] += intercept[c];
+    }
+    if (lane != 0) return;
+    if (C == 2) {
+        // binary SGD: coef_ has one row (class 1 score)
+        if (dec) dec[n] = s[0];
+        if (label) label[n] = s[0] > 0 ? 1 : 0;
+        if (has_calib) {
+            double p1 = expit_d(-(calib[0] * s[0] + calib[C]));
+            if (proba) { proba[n * 2] = 1.0 - p1; proba[n * 2 + 1] = p1; }
+            if (label_calib) label_calib[n] = p1 > 1.0 - p1 ? 1 : 0;
+        }
+        return;
+    }
+    if (dec) for (int c = 0; c < C; ++c) dec[n * C + c] = s[c];
+    int b = 0;
+    for (int c = 1; c < C; ++c) if (s[c] > s[b]) b = c;
+    if (label) label[n] = b;
+    if (has_calib && (proba || label_calib)) {
+        double pr[kMaxC]; double den = 0.0;
+        for (int c = 0; c < C; ++c) { pr[c] = expit_d(-(calib[c] * s[c] + calib[C + c])); den += pr[c]; }
+        for (int c = 0; c < C; ++c) pr[c] = (den != 0.0) ? pr[c] / den : 1.0 / C;
+        for (int c = 0; c < C; ++c) if (pr[c] > 1.0 && pr[c] <= 1.0 + 1e-5) pr[c] = 1.0;
+        if (proba) for (int c = 0; c < C; ++c) proba[n * C + c] = pr[c];
+        int bc = 0;
+        for (int c = 1; c < C; ++c) if (pr[c] > pr[bc]) bc = c;
+        if (label_calib) label_calib[n] = bc;
+    }
+}
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+template <typename T> int dev_upload(T** dst, const std::vector<T>& h) {
+    RML_HIP(hipMalloc(reinterpret_cast<void**>(dst), h.size() * sizeof(T)));
+    RML_HIP(hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RML_OK;
+}
+
+template <int PATH>
+int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + 2 * m->PT) * sizeof(double);
+    const int FT8 = (int)round_up(ga.FT, 8);
+    dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
+#define RML_GEMM_CASE(PTV)                                                                                         \
+    case PTV: {                                                                                                    \
+        static bool attr_done = false;                                                                             \
+        if (!attr_done) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm<PATH, PTV>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                      \
+            attr_done = true;                                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_svm_gemm<PATH, PTV>), grid, block, lds, st, ga);                                     \
+    } break;
+    switch (m->PT) {
+        RML_GEMM_CASE(1)
+        RML_GEMM_CASE(3)
+        RML_GEMM_CASE(6)
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count");
+    }
+#undef RML_GEMM_CASE
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// Workspace carved from the ctx block for one chunk of CH rows.
+struct ChunkWs {
+    uint8_t* q; float* f32; int32_t* isum; int64_t* isq; double* nsq; int32_t* flags;
+    int32_t* tile_exact; int32_t* all_exact; double* partial;
+    size_t bytes;
+};
+
+ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32) {
+    ChunkWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return base ? base + o : (unsigned char*)nullptr; };
+    w.q = (uint8_t*)take(need_q ? (size_t)CH * m->Dq : 0);
+    w.f32 = (float*)take(need_f32 ? (size_t)CH * m->Df * 4 : 0);
+    w.isum = (int32_t*)take((size_t)CH * 4);
+    w.isq = (int64_t*)take((size_t)CH * 8);
+    w.nsq = (double*)take((size_t)CH * 8);
+    w.flags = (int32_t*)take((size_t)CH * 4);
+    w.tile_exact = (int32_t*)take((size_t)(CH / kTile + 1) * 4);
+    w.all_exact = (int32_t*)take(256);
+    w.partial = (double*)take((size_t)(m->Mpad / kTile) * CH * m->PT * 8);
+    w.bytes = off;
+    return w;
+}
+
+struct DecisionOut {
+    double* dec_ovo; double* dec_ovr; double* proba; int32_t* label_vote; int32_t* label_calib;
+    DecisionOut at(int64_t r0, int C, int P) const {
+        DecisionOut o = *this;
+        if (o.dec_ovo) o.dec_ovo += r0 * P;
+        if (o.dec_ovr) o.dec_ovr += r0 * (C == 2 ? 1 : C);
+        if (o.proba) o.proba += r0 * C;
+        if (o.label_vote) o.label_vote += r0;
+        if (o.label_calib) o.label_calib += r0;
+        return o;
+    }
+};
+
+// GEMM(s) + finish for one chunk whose operands are already in place.
+int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
+              const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st) {
+    const int FT = (int)((n + kTile - 1) / kTile);
+    const int ST = (int)(m->Mpad / kTile);
+    const bool run_i8 = m->exact && q && policy != 1;
+    const bool run_f32 = f32 && policy != 2;
+    RML_REQUIRE(run_i8 || run_f32, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
+    hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, flags, n, FT,
+                       run_i8 ? (run_f32 ? policy : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
+    GemmArgs ga{};
+    ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
+    ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
+    if (run_i8) {
+        ga.sv = m->sv_q; ga.ld_sv = m->Dq; ga.x = q; ga.ld_x = ld_q; ga.KT = (int)(m->Dq / kStepBytes);
+        ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
+        const double sc2 = m->code_scale * m->code_scale;
+        ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
+        int rc = launch_gemm<PATH_I8>(m, ga, st);
+        if (rc) return rc;
+    }
+    if (run_f32) {
+        ga.sv = reinterpret_cast<const uint8_t*>(m->sv_f32); ga.ld_sv = m->Df * 4;
+        ga.x = reinterpret_cast<const uint8_t*>(f32); ga.ld_x = m->Df * 4; ga.KT = (int)(m->Df * 4 / kStepBytes);
+        ga.want = 0; ga.x_nsq = nsq; ga.sv_term = m->sv_nsq; ga.gs = m->gamma;
+        int rc = launch_gemm<PATH_F32>(m, ga, st);
+        if (rc) return rc;
+    }
+    FinishArgs fa{};
+    fa.partial = w.partial; fa.Npart = n; fa.ST = ST; fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
+    fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
+    fa.row_flags = flags; fa.tile_exact = w.tile_exact; fa.forced_i8 = (run_i8 && !run_f32);
+    fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
+    fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
+    hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+}  // namespace
+
+// ---- model load ---------------------------------------------------------------------------
+extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D,
+                            const double* dual_coef, const double* intercept, const int32_t* n_support,
+                            int n_classes, int kernel, double gamma, double code_scale,
+                            const double* calib_a, const double* calib_b, rml_svm** out) {
+    RML_REQUIRE(ctx && sv && dual_coef && intercept && n_support && out, RML_ERR_INVALID, "rml_svm_load: NULL argument");
+    RML_REQUIRE(M > 0 && D > 0, RML_ERR_INVALID, "rml_svm_load: empty model");
+    RML_REQUIRE(n_classes >= 2 && n_classes <= kMaxC, RML_ERR_UNSUPPORTED, "rml_svm_load: %d classes (supported: 2..%d)", n_classes, kMaxC);
+    RML_REQUIRE(kernel == RML_KERNEL_RBF || kernel == RML_KERNEL_LINEAR, RML_ERR_UNSUPPORTED, "rml_svm_load: kernel %d", kernel);
+    RML_REQUIRE((calib_a == nullptr) == (calib_b == nullptr), RML_ERR_INVALID, "rml_svm_load: calib_a/calib_b must both be given");
+    int64_t msum = 0;
+    for (int c = 0; c < n_classes; ++c) { RML_REQUIRE(n_support[c] >= 0, RML_ERR_INVALID, "rml_svm_load: negative n_support"); msum += n_support[c]; }
+    RML_REQUIRE(msum == M, RML_ERR_INVALID, "rml_svm_load: sum(n_support)=%lld != M=%lld", (long long)msum, (long long)M);
+    *out = nullptr;
+    RML_HIP(hipSetDevice(ctx->device));
+    rml_svm* m = new (std::nothrow) rml_svm();
+    RML_REQUIRE(m != nullptr, RML_ERR_NOMEM, "rml_svm_load: out of host memory");
+    m->M = M; m->D = D; m->C = n_classes; m->P = n_classes * (n_classes - 1) / 2;
+    m->PT = m->P <= 1 ? 1 : (m->P <= 3 ? 3 : 6);
+    m->kernel = kernel; m->gamma = gamma; m->code_scale = code_scale > 1.0 ? code_scale : 1.0;
+    m->Mpad = round_up(M, kTile); m->Dq = round_up(D, kStepBytes); m->Df = round_up(D, 32);
+    m->has_calib = calib_a != nullptr;
+
+    // per-pair SV weights: the pair loop of svm_predict_values (svm.cpp:2864-2883)
+    std::vector<double> W((size_t)m->PT * m->Mpad, 0.0);
+    {
+        std::vector<int64_t> start(n_classes, 0);
+        for (int c = 1; c < n_classes; ++c) start[c] = start[c - 1] + n_support[c - 1];
+        int p = 0;
+        for (int i = 0; i < n_classes; ++i)
+            for (int j = i + 1; j < n_classes; ++j, ++p) {
+                for (int64_t k = 0; k < n_support[i]; ++k) W[(size_t)p * m->Mpad + start[i] + k] = dual_coef[(size_t)(j - 1) * M + start[i] + k];
+                for (int64_t k = 0; k < n_support[j]; ++k) W[(size_t)p * m->Mpad + start[j] + k] = dual_coef[(size_t)i * M + start[j] + k];
+            }
+    }
+    // float operand + norms
+    std::vector<float> svf((size_t)m->Mpad * m->Df, 0.0f);
+    std::vector<double> nsq(m->Mpad, 0.0);
+    // exact codes: every SV must be bit-identical to float32(c/scale) (or to c when unscaled)
+    std::vector<uint8_t> svq((size_t)m->Mpad * m->Dq, 0);
+    std::vector<double> term(m->Mpad, 0.0);
+    bool exact = true;
+    const float fscale = (float)m->code_scale;
+    for (int64_t r = 0; r < M; ++r) {
+        double nn = 0.0; int64_t isum = 0, isq = 0;
+        for (int64_t d = 0; d < D; ++d) {
+            const double v = sv[(size_t)r * D + d];
+            const float vf = (float)v;
+            svf[(size_t)r * m->Df + d] = vf;
+            nn += (double)vf * (double)vf;
+            if (exact) {
+                double c = nearbyint(v * m->code_scale);
+                bool good = c >= 0.0 && c <= 255.0;
+                if (good) {
+                    double back = m->code_scale > 1.0 ? (double)((float)c / fscale) : c;
+                    good = (back == v);
+                }
+                if (!good) exact = false;
+                else { int ci = (int)c; svq[(size_t)r * m->Dq + d] = (uint8_t)(ci ^ 0x80); isum += ci; isq += (int64_t)ci * ci; }
+            }
+        }
+        nsq[r] = nn;
+        // RBF:    d^2 = (isq_x - 256 isum_x) + [isq_s - 256 isum_s + 32768 D] - 2 G'
+        // linear: x.s = G' + 128 isum_x + [128 isum_s - 16384 D]
+        term[r] = (kernel == RML_KERNEL_RBF) ? (double)(isq - 256 * isum + 32768 * D) : (double)(128 * isum - 16384 * D);
+    }
+    m->exact = exact;
+    int rc = RML_OK;
+    do {
+        if ((rc = dev_upload(&m->W, W))) break;
+        if ((rc = dev_upload(&m->sv_f32, svf))) break;
+        if ((rc = dev_upload(&m->sv_nsq, nsq))) break;
+        if (exact) {
+            if ((rc = dev_upload(&m->sv_q, svq))) break;
+            if ((rc = dev_upload(&m->sv_term_q, term))) break;
+        }
+        std::vector<double> ic(intercept, intercept + m->P);
+        if ((rc = dev_upload(&m->intercept, ic))) break;
+        if (m->has_calib) {
+            std::vector<double> cal(2 * n_classes);
+            const int ncal = n_classes == 2 ? 1 : n_classes;
+            for (int c = 0; c < n_classes; ++c) { cal[c] = c < ncal ? calib_a[c] : 0.0; cal[n_classes + c] = c < ncal ? calib_b[c] : 0.0; }
+            if ((rc = dev_upload(&m->calib, cal))) break;
+        }
+    } while (0);
+    if (rc) { rml_svm_free(ctx, m); return rc; }
+    *out = m;
+    return RML_OK;
+}
+
+extern "C" int rml_svm_free(rml_ctx* ctx, rml_svm* m) {
+    if (!m) return RML_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {m->sv_f32, m->sv_nsq, m->sv_q, m->sv_term_q, m->W, m->intercept, m->calib};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    delete m;
+    return RML_OK;
+}
+
+extern "C" int rml_svm_is_exact(const rml_svm* m) { return m && m->exact ? 1 : 0; }
+extern "C" int64_t rml_svm_num_sv(const rml_svm* m) { return m ? m->M : 0; }
+extern "C" int64_t rml_svm_dim(const rml_svm* m) { return m ? m->D : 0; }
+
+// ---- decision on caller-provided rows -----------------------------------------------------
+extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
+                                const float* feat, int64_t ld_feat,
+                                const uint8_t* feat_q, int64_t ld_q, const int32_t* row_isum, const int64_t* row_isq,
+                                const int32_t* row_flags, int64_t N,
+                                double* dec_ovo, double* dec_ovr, double* proba,
+                                int32_t* label_vote, int32_t* label_calib, void* stream) {
+    RML_REQUIRE(ctx && m && N >= 0, RML_ERR_INVALID, "rml_svm_decision: bad arguments");
+    RML_REQUIRE(feat || feat_q, RML_ERR_INVALID, "rml_svm_decision: need feat or feat_q");
+    RML_REQUIRE(!feat || ld_feat >= m->D, RML_ERR_INVALID, "rml_svm_decision: ld_feat < D");
+    RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_I8, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
+    RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_svm_decision: model has no calibrators");
+    RML_REQUIRE(path != RML_PATH_I8 || m->exact, RML_ERR_STATE, "rml_svm_decision: exact path requested but the model is not on the code grid");
+    if (!feat) {
+        RML_REQUIRE(m->exact, RML_ERR_STATE, "rml_svm_decision: code rows given but the model is not on the code grid");
+        RML_REQUIRE(path != RML_PATH_F32, RML_ERR_INVALID, "rml_svm_decision: f32 path needs float rows");
+        RML_REQUIRE(row_isum && row_isq, RML_ERR_INVALID, "rml_svm_decision: code rows need row_isum/row_isq");
+        RML_REQUIRE(ld_q >= m->Dq && ld_q % 16 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 15) == 0, RML_ERR_INVALID,
+                    "rml_svm_decision: code rows need ld_q >= %lld, ld_q %% 16 == 0 and 16-byte alignment", (long long)m->Dq);
+    }
+    RML_HIP(hipSetDevice(ctx->device));
+    if (N == 0) return RML_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
+    const bool need_q = feat != nullptr && m->exact && path != RML_PATH_F32;
+    const bool need_f32 = feat != nullptr;
+    ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32);
+    void* ws = nullptr;
+    int rc = rml_ws_reserve(ctx, probe.bytes, &ws);
+    if (rc) return rc;
+    ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, need_f32);
+    DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
+    const int policy = path;   // 0 auto, 1 f32, 2 i8
+    for (int64_t r0 = 0; r0 < N; r0 += CH) {
+        const int64_t n = std::min(CH, N - r0);
+        if (feat) {
+            hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)n), dim3(256), 0, st, feat + r0 * ld_feat, ld_feat, m->D,
+                               (float)m->code_scale, w.f32, m->Df, w.nsq, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags);
+            RML_HIP(hipGetLastError());
+            rc = run_chunk(m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st);
+        } else {
+            rc = run_chunk(m, 2, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
+                           nullptr, nullptr, w, out.at(r0, m->C, m->P), st);
+        }
+        if (rc) return rc;
+    }
+    return RML_OK;
+}
+
+// ---- fused front door: volumes -> projection -> SVM ---------------------------------------
+extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, int64_t B, int X, int Y, int Z,
+                               int mode, const int32_t* ijk, float scale_div, uint32_t mask,
+                               double* dec_ovo, double* dec_ovr, double* proba,
+                               int32_t* label_vote, int32_t* label_calib, void* stream) {
+    RML_REQUIRE(ctx && m && V && B >= 0, RML_ERR_INVALID, "rml_project_svm: bad arguments");
+    RML_REQUIRE(rml_feature_len(X, Y, Z, mask) == m->D, RML_ERR_INVALID, "rml_project_svm: grid/mask give D=%lld, model has D=%lld",
+                (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
+    RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
+    RML_REQUIRE(mode != RML_MODE_SLICE || ijk, RML_ERR_INVALID, "rml_project_svm: mode SLICE needs ijk");
+    // the code grid of the features must be the model's: codes are the unscaled values
+    const bool scaled = scale_div > 1.0f;
+    const bool grid_ok = m->exact && ((scaled && (double)scale_div == m->code_scale) || (!scaled && m->code_scale == 1.0));
+    RML_HIP(hipSetDevice(ctx->device));
+    if (B == 0) return RML_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
+    const int64_t CH = std::min<int64_t>(round_up(B, kTile), 4096);
+    ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
+    void* ws = nullptr;
+    int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
+    if (rc) return rc;
+    ChunkWs w2[2] = {carve(m, CH, static_cast<unsigned char*>(ws), grid_ok, true),
+                     carve(m, CH, static_cast<unsigned char*>(ws) + probe.bytes, grid_ok, true)};
+    DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
+    const int64_t frame_elems = (int64_t)X * Y * Z;
+    hipStream_t aux = ctx->aux_stream;
+    hipEvent_t* ev_proj = ctx->ev_proj;
+    hipEvent_t* ev_done = ctx->ev_done;
+    // aux must start after everything already queued on st
+    RML_HIP(hipEventRecord(ctx->ev_fork, st));
+    RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    int64_t c = 0;
+    for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
+        const int64_t n = std::min(CH, B - r0);
+        const ChunkWs& w = w2[c & 1];
+        if (c >= 2) RML_HIP(hipStreamWaitEvent(st, ev_done[c & 1], 0));    // workspace reuse
+        const int FT = (int)((n + kTile - 1) / kTile);
+        ProjOut o{};
+        int64_t off = 0;
+        for (int pl = 0; pl < 3; ++pl)
+            if (mask & (1u << pl)) {
+                o.q[pl] = grid_ok ? w.q + off : nullptr;
+                off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
+            }
+        o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
+        o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
+        const float* Vc = V + r0 * frame_elems;
+        const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
+        if (grid_ok) {
+            // pass 1: codes + statistics only (the exact path needs nothing else)
+            rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, o, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
+            hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, w.flags, n, FT, 0, 1, w.tile_exact, w.all_exact);
+        }
+        // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
+        ProjOut of{};
+        off = 0;
+        for (int pl = 0; pl < 3; ++pl)
+            if (mask & (1u << pl)) {
+                of.p[pl] = w.f32 + off; of.stride[pl] = m->Df;
+                off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
+            }
+        of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
+        of.skip_if_set = grid_ok ? w.all_exact : nullptr;
+        if (!grid_ok) of.row_flags = w.flags;
+        rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, of, st);
+        if (rc) return rc;
+        RML_HIP(hipEventRecord(ev_proj[c & 1], st));
+        RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
+        rc = run_chunk(m, grid_ok ? 0 : 1, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
+                       out.at(r0, m->C, m->P), aux);
+        if (rc) return rc;
+        RML_HIP(hipEventRecord(ev_done[c & 1], aux));
+    }
+    // join: the caller's stream continues after the last GEMMs
+    RML_HIP(hipEventRecord(ctx->ev_join, aux));
+    RML_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    return RML_OK;
+}
+
+// ---- linear classifier --------------------------------------------------------------------
+extern "C" int rml_linear_load(rml_ctx* ctx, const double* coef, const double* intercept, int n_classes, int64_t D,
+                               const double* calib_a, const double* calib_b, rml_linear** out) {
+    RML_REQUIRE(ctx && coef && intercept && out && D > 0, RML_ERR_INVALID, "rml_linear_load: bad arguments");
+    RML_REQUIRE(n_classes >= 2 && n_classes <= kMaxC, RML_ERR_UNSUPPORTED, "rml_linear_load: %d classes", n_classes);
+    RML_REQUIRE((calib_a == nullptr) == (calib_b == nullptr), RML_ERR_INVALID, "rml_linear_load: calib_a/calib_b must both be given");
+    *out = nullptr;
+    RML_HIP(hipSetDevice(ctx->device));
+    rml_linear* m = new (std::nothrow) rml_linear();
+    RML_REQUIRE(m != nullptr, RML_ERR_NOMEM, "rml_linear_load: out of host memory");
+    m->D = D; m->C = n_classes; m->has_calib = calib_a != nullptr;
+    const int rows = n_classes == 2 ? 1 : n_classes;
+    std::vector<double> cf((size_t)n_classes * D, 0.0), ic(n_classes, 0.0);
+    std::copy(coef, coef + (size_t)rows * D, cf.begin());
+    std::copy(intercept, intercept + rows, ic.begin());
+    int rc = dev_upload(&m->coef, cf);
+    if (!rc) rc = dev_upload(&m->intercept, ic);
+    if (!rc && m->has_calib) {
+        std::vector<double> cal(2 * n_classes, 0.0);
+        for (int c = 0; c < rows; ++c) { cal[c] = calib_a[c]; cal[n_classes + c] = calib_b[c]; }
+        rc = dev_upload(&m->calib, cal);
+    }
+    if (rc) { rml_linear_free(ctx, m); return rc; }
+    *out = m;
+    return RML_OK;
+}
+
+extern "C" int rml_linear_free(rml_ctx* ctx, rml_linear* m) {
+    if (!m) return RML_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (m->coef) (void)hipFree(m->coef);
+    if (m->intercept) (void)hipFree(m->intercept);
+    if (m->calib) (void)hipFree(m->calib);
+    delete m;
+    return RML_OK;
+}
+
+extern "C" int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, int64_t ld_feat, int64_t N,
+                                   double* dec, double* proba, int32_t* label, int32_t* label_calib, void* stream) {
+    RML_REQUIRE(ctx && m && feat && N >= 0 && ld_feat >= m->D, RML_ERR_INVALID, "rml_linear_decision: bad arguments");
+    RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_linear_decision: model has no calibrators");
+    RML_HIP(hipSetDevice(ctx->device));
+    if (N == 0) return RML_OK;
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       feat, ld_feat, N, m->D, m->C, m->coef, m->intercept, m->calib, (int)m->has_calib, dec, proba, label, label_calib);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

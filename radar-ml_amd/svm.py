@@ -1,0 +1,305 @@
+"""sklearn-protocol classifiers backed by the HIP SVM kernels.
+
+The reference pickles a fitted ``CalibratedClassifierCV`` wrapping an ``SVC`` (or an
+``SGDClassifier``) and calls ``.predict`` / ``.predict_proba`` on it (train.py:217,722-731;
+predict.py:60).  ``from_sklearn(obj)`` ingests such a fitted object and returns an object with
+the same protocol (``predict``, ``predict_proba``, ``decision_function``, ``classes_``) whose
+arithmetic runs on the GPU.  Fitting stays on the CPU with scikit-learn.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .common import ProjMask, RADAR_MAX, _as_device_f32, _mask_bits
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _detect_code_scale(sv):
+    """255.0 when every SV is bit-identical to float32(c/255) (train.py:667 scaling), 1.0 when it
+    is an integer code itself, else 0.0 (general float path only)."""
+    sv = np.asarray(sv, dtype=np.float64)
+    for scale in (255.0, 1.0):
+        c = np.rint(sv * scale)
+        if c.min() < 0 or c.max() > 255:
+            continue
+        back = (c.astype(np.float32) / np.float32(scale)).astype(np.float64) if scale > 1 else c
+        if np.array_equal(back, sv):
+            return scale
+    return 0.0
+
+
+class _Base:
+    classes_ = None
+
+    def _rows(self, X):
+        """Accept numpy or torch, any real dtype -> (N,D) float32 CUDA tensor."""
+        torch = _torch()
+        if not isinstance(X, torch.Tensor):
+            X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("Expected 2D array, got %dD array instead" % X.ndim)
+        if X.shape[1] != self.n_features_in_:
+            raise ValueError("X has %d features, but %s is expecting %d features as input."
+                             % (X.shape[1], type(self).__name__, self.n_features_in_))
+        return _as_device_f32(X)
+
+
+class GpuSVC(_Base):
+    """GPU twin of a fitted ``sklearn.svm.SVC`` (C-SVC, one-vs-one, RBF or linear kernel)."""
+
+    def __init__(self, support_vectors, dual_coef, intercept, n_support, gamma, classes, kernel="rbf",
+                 calib_a=None, calib_b=None, decision_function_shape="ovr", device=None, path="auto"):
+        torch = _torch()
+        lib = _lib.load()
+        sv = _f64(support_vectors)
+        self.classes_ = np.asarray(classes)
+        self.n_features_in_ = sv.shape[1]
+        self.decision_function_shape = decision_function_shape
+        self.kernel = kernel
+        self.gamma = float(gamma)
+        self.path = path
+        C_ = len(self.classes_)
+        dc, ic, ns = _f64(dual_coef), _f64(intercept), np.ascontiguousarray(n_support, dtype=np.int32)
+        if dc.shape != (C_ - 1, sv.shape[0]):
+            raise ValueError("dual_coef must be (n_classes-1, n_SV) in libsvm order (SVC._dual_coef_)")
+        self._dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = _lib.context(self._dev)
+        self.code_scale = _detect_code_scale(sv)
+        ca = cb = None
+        if calib_a is not None:
+            ca, cb = _f64(calib_a), _f64(calib_b)
+        h = C.c_void_p()
+        with torch.cuda.device(self._dev):
+            _lib.check(lib.rml_svm_load(
+                self._ctx, sv.ctypes.data, sv.shape[0], sv.shape[1], dc.ctypes.data, ic.ctypes.data, ns.ctypes.data, C_,
+                _lib.KERNEL_RBF if kernel == "rbf" else _lib.KERNEL_LINEAR, float(gamma),
+                self.code_scale if self.code_scale > 0 else 1.0,
+                ca.ctypes.data if ca is not None else None, cb.ctypes.data if cb is not None else None, C.byref(h)),
+                "rml_svm_load")
+        self._h = h
+        self.has_calibration = ca is not None
+        self.exact = bool(lib.rml_svm_is_exact(h)) and self.code_scale > 0
+        self.n_sv = sv.shape[0]
+
+    # -- construction from scikit-learn -----------------------------------------------------
+    @classmethod
+    def from_sklearn(cls, clf, calib=None, **kw):
+        """clf: fitted sklearn.svm.SVC.  calib: optional (a, b) arrays of the sigmoid calibrators."""
+        kernel = clf.kernel
+        if kernel not in ("rbf", "linear"):
+            raise NotImplementedError("SVC kernel %r (the reference's grid uses linear and rbf: train.py:474-476)" % kernel)
+        a = b = None
+        if calib is not None:
+            a, b = calib
+        return cls(clf.support_vectors_, clf._dual_coef_, clf._intercept_, clf._n_support, clf._gamma, clf.classes_,
+                   kernel=kernel, calib_a=a, calib_b=b,
+                   decision_function_shape=getattr(clf, "decision_function_shape", "ovr"), **kw)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().rml_svm_free(self._ctx, self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- raw device call --------------------------------------------------------------------
+    def _decide(self, Xd, want_proba=False, path=None):
+        torch = _torch()
+        lib = _lib.load()
+        N = Xd.shape[0]
+        C_ = len(self.classes_)
+        P = C_ * (C_ - 1) // 2
+        dev = Xd.device
+        ovo = torch.empty((N, P), dtype=torch.float64, device=dev)
+        ovr = torch.empty((N,) if C_ == 2 else (N, C_), dtype=torch.float64, device=dev)
+        vote = torch.empty((N,), dtype=torch.int32, device=dev)
+        proba = lab = None
+        if want_proba:
+            proba = torch.empty((N, C_), dtype=torch.float64, device=dev)
+            lab = torch.empty((N,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_svm_decision(
+                self._ctx, self._h, _lib.PATHS[path or self.path], _lib.ptr(Xd), Xd.stride(0), None, 0, None, None, None, N,
+                _lib.ptr(ovo), _lib.ptr(ovr), _lib.ptr(proba), _lib.ptr(vote), _lib.ptr(lab), _lib.stream_ptr(dev)),
+                "rml_svm_decision")
+        return ovo, ovr, vote, proba, lab
+
+    def decide_volumes(self, volumes, mode="max", ijk=None, proj_mask=ProjMask(True, True, True), scale=True,
+                       want_proba=None):
+        """Fused batched path: (B,X,Y,Z) volumes -> projection -> SVM, features never leave the GPU.
+        Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib])."""
+        torch = _torch()
+        lib = _lib.load()
+        v = _as_device_f32(volumes)
+        if v.ndim == 3:
+            v = v.unsqueeze(0)
+        B, X, Y, Z = v.shape
+        dev = v.device
+        C_ = len(self.classes_)
+        P = C_ * (C_ - 1) // 2
+        if want_proba is None:
+            want_proba = self.has_calibration
+        ijk_t = None
+        if ijk is not None:
+            ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
+                device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
+        out = {
+            "dec_ovo": torch.empty((B, P), dtype=torch.float64, device=dev),
+            "dec_ovr": torch.empty((B,) if C_ == 2 else (B, C_), dtype=torch.float64, device=dev),
+            "label_vote": torch.empty((B,), dtype=torch.int32, device=dev),
+        }
+        if want_proba:
+            out["proba"] = torch.empty((B, C_), dtype=torch.float64, device=dev)
+            out["label_calib"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_project_svm(
+                self._ctx, self._h, _lib.ptr(v), B, X, Y, Z, _lib.MODES[mode], _lib.ptr(ijk_t),
+                float(RADAR_MAX) if scale else 0.0, _mask_bits(proj_mask),
+                _lib.ptr(out["dec_ovo"]), _lib.ptr(out["dec_ovr"]), _lib.ptr(out.get("proba")),
+                _lib.ptr(out["label_vote"]), _lib.ptr(out.get("label_calib")), _lib.stream_ptr(dev)), "rml_project_svm")
+        return out
+
+    # -- sklearn protocol -------------------------------------------------------------------
+    def decision_function(self, X):
+        """SVC.decision_function (sk:svm/_base.py:760-790): (N,C) 'ovr' scores (or the raw
+        (N,P) libsvm pair values for decision_function_shape='ovo'; (N,) for 2 classes)."""
+        ovo, ovr, _, _, _ = self._decide(self._rows(X))
+        if len(self.classes_) > 2 and self.decision_function_shape == "ovo":
+            return ovo.cpu().numpy()
+        return ovr.cpu().numpy()
+
+    def predict(self, X):
+        """SVC.predict: libsvm one-vs-one vote (sk:svm/src/libsvm/svm.cpp:2884-2894)."""
+        _, _, vote, _, _ = self._decide(self._rows(X))
+        return self.classes_.take(vote.cpu().numpy().astype(np.intp))
+
+
+class GpuCalibratedClassifier(_Base):
+    """GPU twin of ``CalibratedClassifierCV(estimator, cv='prefit')`` with sigmoid calibrators
+    (the object the reference pickles: train.py:722-731).  Wraps a GpuSVC or GpuLinearClassifier."""
+
+    def __init__(self, estimator):
+        self.estimator = estimator
+        self.classes_ = estimator.classes_
+        self.n_features_in_ = estimator.n_features_in_
+
+    def predict_proba(self, X):
+        """sk:calibration.py:492-518,727-784."""
+        return self.estimator._proba(self._rows(X))[0].cpu().numpy()
+
+    def predict(self, X):
+        """sk:calibration.py:520-537: classes_[argmax(predict_proba)]."""
+        lab = self.estimator._proba(self._rows(X))[1]
+        return self.classes_.take(lab.cpu().numpy().astype(np.intp))
+
+    def decision_function(self, X):
+        return self.estimator.decision_function(X)
+
+
+def _svc_proba(self, Xd):
+    _, _, _, proba, lab = self._decide(Xd, want_proba=True)
+    return proba, lab
+
+
+GpuSVC._proba = _svc_proba
+
+
+class GpuLinearClassifier(_Base):
+    """GPU twin of a fitted ``SGDClassifier`` (train.py:350-381): decision = X @ coef_.T + intercept_,
+    predict = argmax (train.py:421,433)."""
+
+    def __init__(self, coef, intercept, classes, calib_a=None, calib_b=None, device=None):
+        torch = _torch()
+        lib = _lib.load()
+        cf, ic = _f64(coef), _f64(intercept)
+        self.classes_ = np.asarray(classes)
+        self.n_features_in_ = cf.shape[1]
+        C_ = len(self.classes_)
+        self._dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = _lib.context(self._dev)
+        ca = cb = None
+        if calib_a is not None:
+            ca, cb = _f64(calib_a), _f64(calib_b)
+        h = C.c_void_p()
+        with torch.cuda.device(self._dev):
+            _lib.check(lib.rml_linear_load(self._ctx, cf.ctypes.data, ic.ctypes.data, C_, cf.shape[1],
+                                           ca.ctypes.data if ca is not None else None,
+                                           cb.ctypes.data if cb is not None else None, C.byref(h)), "rml_linear_load")
+        self._h = h
+        self.has_calibration = ca is not None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().rml_linear_free(self._ctx, self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _run(self, Xd, want_proba=False):
+        torch = _torch()
+        lib = _lib.load()
+        N = Xd.shape[0]
+        C_ = len(self.classes_)
+        dev = Xd.device
+        dec = torch.empty((N,) if C_ == 2 else (N, C_), dtype=torch.float64, device=dev)
+        lab = torch.empty((N,), dtype=torch.int32, device=dev)
+        proba = labc = None
+        if want_proba:
+            proba = torch.empty((N, C_), dtype=torch.float64, device=dev)
+            labc = torch.empty((N,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_linear_decision(self._ctx, self._h, _lib.ptr(Xd), Xd.stride(0), N, _lib.ptr(dec), _lib.ptr(proba),
+                                               _lib.ptr(lab), _lib.ptr(labc), _lib.stream_ptr(dev)), "rml_linear_decision")
+        return dec, lab, proba, labc
+
+    def decision_function(self, X):
+        return self._run(self._rows(X))[0].cpu().numpy()
+
+    def predict(self, X):
+        lab = self._run(self._rows(X))[1]
+        return self.classes_.take(lab.cpu().numpy().astype(np.intp))
+
+    def _proba(self, Xd):
+        _, _, proba, labc = self._run(Xd, want_proba=True)
+        return proba, labc
+
+
+def from_sklearn(obj, **kw):
+    """Ingest the fitted object the reference pickles (train.py:729-731) or a bare estimator.
+
+    CalibratedClassifierCV(prefit, sigmoid) -> GpuCalibratedClassifier; SVC -> GpuSVC;
+    SGDClassifier -> GpuLinearClassifier."""
+    name = type(obj).__name__
+    if name == "CalibratedClassifierCV":
+        ccs = obj.calibrated_classifiers_
+        if len(ccs) != 1:
+            raise NotImplementedError("only cv='prefit' calibration (one calibrated classifier) is used by the reference")
+        cc = ccs[0]
+        if getattr(cc, "method", "sigmoid") != "sigmoid":
+            raise NotImplementedError("only sigmoid calibration (the sklearn default the reference uses)")
+        a = np.array([c.a_ for c in cc.calibrators])
+        b = np.array([c.b_ for c in cc.calibrators])
+        est = cc.estimator
+        if type(est).__name__ == "FrozenEstimator":
+            est = est.estimator
+        if type(est).__name__ == "SVC":
+            return GpuCalibratedClassifier(GpuSVC.from_sklearn(est, calib=(a, b), **kw))
+        if type(est).__name__ == "SGDClassifier":
+            return GpuCalibratedClassifier(GpuLinearClassifier(est.coef_, est.intercept_, est.classes_, a, b, **kw))
+        raise NotImplementedError("calibrated %s" % type(est).__name__)
+    if name == "SVC":
+        return GpuSVC.from_sklearn(obj, **kw)
+    if name == "SGDClassifier":
+        return GpuLinearClassifier(obj.coef_, obj.intercept_, obj.classes_, **kw)
+    raise NotImplementedError("cannot ingest %s" % name)

@@ -1,0 +1,13 @@
+"""Import shim: the package directory is ``radar-ml_amd/`` (not a valid Python identifier),
+so ``import radar_ml_amd`` loads it from there under the importable name."""
+import importlib.util
+import os
+import sys
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_pkg_dir = os.path.join(_here, "radar-ml_amd")
+_spec = importlib.util.spec_from_file_location(
+    "radar_ml_amd", os.path.join(_pkg_dir, "__init__.py"), submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["radar_ml_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,187 @@
+"""HIP SVM kernels against scikit-learn's golden outputs and the float64 oracle.
+
+Bar (BASELINE.json north_star): class labels bit-exact, decision-function scores within 1e-5."""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import load_golden, svm_model_arrays
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5       # north_star: "decision-function scores within 1e-5"
+
+
+def _model(rml, g, **kw):
+    m = svm_model_arrays(g)
+    return rml.GpuSVC(m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["classes"],
+                      kernel=m["kernel"], calib_a=m["calib_a"], calib_b=m["calib_b"], **kw), m
+
+
+def _test_rows(g, name):
+    if name == "real_xy_svm.npz":
+        q = g["xy_u8"].reshape(len(g["xy_u8"]), -1)[g["test_idx"]]
+    else:
+        q = g["test_feat_u8"]
+    return q.astype(np.float32) / np.float32(255.0)
+
+
+@pytest.mark.parametrize("name", ["svm_small.npz", "svm_small_linear.npz", "svm_small_xy.npz", "svm_walabot.npz",
+                                  "real_xy_svm.npz"])
+@pytest.mark.parametrize("path", ["auto", "f32", "i8"])
+def test_golden_parity_with_sklearn(rml, name, path):
+    g = load_golden(name)
+    svc, m = _model(rml, g, path=path)
+    assert svc.exact and svc.code_scale == 255.0
+    X = _test_rows(g, name)
+    svc.decision_function_shape = "ovo"
+    ovo = svc.decision_function(X)
+    svc.decision_function_shape = "ovr"
+    ovr = svc.decision_function(X)
+    assert ovo.dtype == np.float64 and ovr.shape == g["dec_ovr"].shape
+    assert np.abs(ovo - g["dec_ovo"]).max() <= TOL
+    assert np.abs(ovr - g["dec_ovr"]).max() <= TOL
+    np.testing.assert_array_equal(svc.predict(X), g["label_vote"])            # bit-exact labels
+    cal = rml.GpuCalibratedClassifier(svc)
+    proba = cal.predict_proba(X)
+    assert np.abs(proba - g["proba"]).max() <= TOL
+    np.testing.assert_array_equal(cal.predict(X), g["label_calib"])
+    if path == "i8":
+        # exact integer distances: only float64 round-off and sklearn's own float32 inputs remain
+        assert np.abs(ovo - g["dec_ovo"]).max() <= 2e-6
+
+
+def test_general_float_rows_vs_oracle(rml):
+    """Non-integer features (e.g. augmented / zoomed data): f32 MFMA path vs the float64 oracle."""
+    g = load_golden("svm_small.npz")
+    svc, m = _model(rml, g)
+    rng = np.random.default_rng(5)
+    X = _test_rows(g, "svm_small.npz")
+    X = np.clip(X + rng.normal(0, 0.02, X.shape).astype(np.float32) * (X > 0), 0, 1).astype(np.float32)
+    want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"])
+    svc.decision_function_shape = "ovo"
+    got = svc.decision_function(X)
+    assert np.abs(got - want).max() <= TOL
+    C = len(m["classes"])
+    np.testing.assert_array_equal(svc.predict(X), m["classes"][O.svm_vote_labels(want, C)])
+    proba = rml.GpuCalibratedClassifier(svc).predict_proba(X)
+    wantp = O.calibrated_proba(O.ovr_decision_function(want, C), m["calib_a"], m["calib_b"])
+    assert np.abs(proba - wantp).max() <= TOL
+
+
+def test_non_grid_model_uses_f32_path(rml):
+    g = load_golden("svm_small.npz")
+    m = svm_model_arrays(g)
+    sv = m["sv"] * 1.0000001            # no longer on the k/255 grid
+    svc = rml.GpuSVC(sv, m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["classes"])
+    assert not svc.exact
+    X = _test_rows(g, "svm_small.npz")
+    want = O.svm_decision_ovo(X, sv, m["dual_coef"], m["intercept"], m["n_support"], m["gamma"])
+    svc.decision_function_shape = "ovo"
+    assert np.abs(svc.decision_function(X) - want).max() <= TOL
+    with pytest.raises(rml.RadarMLError):
+        svc._decide(svc._rows(X), path="i8")
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 300])
+def test_ragged_batch_sizes(rml, n):
+    g = load_golden("svm_small.npz")
+    svc, m = _model(rml, g)
+    X = np.tile(_test_rows(g, "svm_small.npz"), (2, 1))[:n]
+    ref = np.tile(g["dec_ovr"], (2, 1))[:n]
+    assert np.abs(svc.decision_function(X) - ref).max() <= TOL
+    np.testing.assert_array_equal(svc.predict(X), np.tile(g["label_vote"], 2)[:n])
+
+
+def test_input_validation(rml):
+    g = load_golden("svm_small.npz")
+    svc, m = _model(rml, g)
+    with pytest.raises(ValueError):
+        svc.predict(np.zeros((3, 5), np.float32))        # wrong D (sklearn raises ValueError too)
+    with pytest.raises(ValueError):
+        svc.predict(np.zeros(368, np.float32))
+    out = svc.decision_function(np.zeros((0, 368), np.float32))
+    assert out.shape == (0, 3)
+    X64 = _test_rows(g, "svm_small.npz").astype(np.float64)        # any real dtype is accepted
+    np.testing.assert_array_equal(svc.predict(X64), g["label_vote"])
+
+
+@pytest.mark.parametrize("name,shape", [("svm_small.npz", (8, 10, 16)), ("svm_walabot.npz", (22, 31, 176)),
+                                        ("svm_small_xy.npz", (8, 10, 16))])
+def test_fused_volumes_to_labels(rml, name, shape):
+    """volumes -> max-projection -> SVM in one call == sklearn on the same frames."""
+    g = load_golden(name)
+    svc, m = _model(rml, g)
+    vol = g["test_vol_u8"].astype(np.float32)
+    mask = rml.ProjMask(*[bool(b) for b in g["mask"]])
+    out = svc.decide_volumes(vol, mode="max", proj_mask=mask, scale=True)
+    assert np.abs(out["dec_ovo"].cpu().numpy() - g["dec_ovo"]).max() <= TOL
+    assert np.abs(out["dec_ovr"].cpu().numpy() - g["dec_ovr"]).max() <= TOL
+    assert np.abs(out["proba"].cpu().numpy() - g["proba"]).max() <= TOL
+    np.testing.assert_array_equal(m["classes"][out["label_vote"].cpu().numpy()], g["label_vote"])
+    np.testing.assert_array_equal(m["classes"][out["label_calib"].cpu().numpy()], g["label_calib"])
+    # a frame with a non-integer return drops its tile to the f32 path; results stay within tolerance
+    vol2 = vol.copy()
+    vol2[3, 0, 0, 0] = 0.5
+    out2 = svc.decide_volumes(vol2, mode="max", proj_mask=mask, scale=True)
+    d = np.abs(out2["dec_ovo"].cpu().numpy() - g["dec_ovo"])
+    d[3] = 0
+    assert d.max() <= TOL
+
+
+def test_fused_multi_chunk_deterministic(rml):
+    """> 1 chunk (4096 frames each) through the two-stream pipeline, twice: identical bits."""
+    import torch
+    g = load_golden("svm_small.npz")
+    svc, m = _model(rml, g)
+    B = 4096 * 2 + 300
+    v, _ = rml.synth_volumes(B, 8, 10, 16, seed=11)
+    a = svc.decide_volumes(v)
+    b = svc.decide_volumes(v)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    # against separate projection + decision on a slab
+    feat = rml.process_volumes(v[4000:4400], scale=True)
+    svc.decision_function_shape = "ovo"
+    sep = svc.decision_function(feat)
+    np.testing.assert_array_equal(a["dec_ovo"][4000:4400].cpu().numpy(), sep)
+    want = O.svm_decision_ovo(feat.cpu().numpy(), m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"])
+    assert np.abs(sep - want).max() <= TOL
+    np.testing.assert_array_equal(a["label_vote"][4000:4400].cpu().numpy(), O.svm_vote_labels(want, 3))
+
+
+def test_linear_classifier_golden(rml):
+    g = load_golden("linear_golden.npz")
+    clf = rml.GpuLinearClassifier(g["coef"], g["intercept"], g["classes"], g["calib_a"], g["calib_b"])
+    X = g["test_feat_u8"].astype(np.float32) / np.float32(255.0)
+    assert np.abs(clf.decision_function(X) - g["dec"]).max() <= 1e-9
+    np.testing.assert_array_equal(clf.predict(X), g["label"])
+    cal = rml.GpuCalibratedClassifier(clf)
+    assert np.abs(cal.predict_proba(X) - g["proba"]).max() <= 1e-9
+    np.testing.assert_array_equal(cal.predict(X), g["label_calib"])
+
+
+def test_from_sklearn_roundtrip(rml):
+    sklearn = pytest.importorskip("sklearn")
+    import warnings
+    from sklearn import svm
+    from sklearn.calibration import CalibratedClassifierCV
+    vol, cls = O.synth_volumes(21, 500, 8, 10, 16)
+    xz, yz, xy = O.project_max(vol)
+    F = O.features_from_projections(xz, yz, xy, scale=True)
+    clf = svm.SVC(kernel="rbf", C=10, gamma=0.05, class_weight="balanced").fit(F[:350], cls[:350])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cal = CalibratedClassifierCV(estimator=clf, cv="prefit").fit(F[350:420], cls[350:420])
+    gpu = rml.from_sklearn(cal)
+    Xt = F[420:]
+    np.testing.assert_array_equal(gpu.predict(Xt), cal.predict(Xt))
+    assert np.abs(gpu.predict_proba(Xt) - cal.predict_proba(Xt)).max() <= TOL
+    assert np.abs(gpu.decision_function(Xt) - clf.decision_function(Xt)).max() <= TOL
+    np.testing.assert_array_equal(rml.from_sklearn(clf).predict(Xt), clf.predict(Xt))
+    # predict.classifier surface (predict.py:56-70)
+    class LE:
+        classes_ = np.array(["cat", "dog", "person"])
+    name, p = rml.classifier(Xt[0], gpu, LE())
+    pr = cal.predict_proba(Xt[:1])[0]
+    assert abs(p - pr.max()) <= TOL and name == (LE.classes_[pr.argmax()] if pr.max() >= 0.7 else "Unknown")
