@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the radar-ml hot path on MI355X: radar frames/s, 3-D volume -> max-projection ->
+RBF-SVM label (BASELINE.json metric; workload = configs[2]: projection + RBF-SVM decision function,
+3 classes, ~2k support vectors, batch 65 536 frames of 64x64x128 resident in HBM per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the rank's resident batch (frames shard across ranks,
+weak scaling, no data-path collective; the per-frame labels are all-gathered over RCCL at the end
+of every step, inside the timed region).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (configs[2]: 65536)")
+    ap.add_argument("--grid", default="64x64x128", help="XxYxZ; 22x31x176 = Walabot arena grid")
+    ap.add_argument("--train", type=int, default=3400, help="synthetic frames used to fit the SVC (CPU plumbing)")
+    ap.add_argument("--gamma", type=float, default=0.01)
+    ap.add_argument("--parity", type=int, default=512, help="frames checked against the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~15 s)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def fit_model(rml, torch, X, Y, Z, ntrain, gamma, seed, dev):
+    """CPU plumbing (BASELINE config 1 / SURVEY §8d): fit the reference's model object -- SVC(rbf, C=10,
+    class_weight='balanced') + CalibratedClassifierCV(prefit, sigmoid) (train.py:478-482,722-724) -- on
+    synthetic max-projection features.  The Gram matrix is formed on the GPU with torch (float64, exact
+    on the integer codes) and handed to scikit-learn's SMO as a precomputed kernel: same optimisation
+    problem, minutes faster than libsvm's own kernel evaluations at D = 20 480."""
+    import warnings
+    from sklearn import svm
+    from sklearn.calibration import CalibratedClassifierCV
+    nval = max(300, ntrain // 8)
+    v, cls = rml.synth_volumes(ntrain + nval, X, Y, Z, seed=seed, frame0=1 << 40)
+    feat = rml.process_volumes(v, mode="max", scale=False)              # integer codes 0..255, float32
+    del v
+    F = feat.to(torch.float64)
+    G = F @ F.T
+    sq = torch.diagonal(G).clone()
+    d2 = (sq[:, None] + sq[None, :] - 2.0 * G) / (255.0 * 255.0)
+    K = torch.exp(-gamma * d2.clamp_(min=0)).cpu().numpy()
+    del G, d2, F
+    y = cls.cpu().numpy()
+    tr, va = slice(0, ntrain), slice(ntrain, ntrain + nval)
+    clf = svm.SVC(kernel="precomputed", C=10.0, class_weight="balanced", cache_size=2000)
+    clf.fit(K[tr, tr], y[tr])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cal = CalibratedClassifierCV(estimator=clf, cv="prefit").fit(K[va, tr], y[va])
+    cc = cal.calibrated_classifiers_[0]
+    sup = clf.support_
+    codes = feat[tr][torch.as_tensor(sup, device=feat.device, dtype=torch.long)].cpu().numpy().astype(np.uint8)
+    kfrac = float((K[tr, tr] > 1e-6).mean())
+    model = dict(
+        sv_u8=codes, dual_coef=clf._dual_coef_.copy(), intercept=clf._intercept_.copy(),
+        n_support=clf._n_support.astype(np.int32), gamma=float(gamma), classes=clf.classes_.copy(),
+        calib_a=np.array([c.a_ for c in cc.calibrators]), calib_b=np.array([c.b_ for c in cc.calibrators]),
+        val_acc=float((cal.predict(K[va, tr]) == y[va]).mean()), kfrac=kfrac)
+    return model
+
+
+def sv_f64(model):
+    # train.py:667 scaling: float32(code / 255), widened to float64 as libsvm sees it
+    return (model["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import radar_ml_amd as rml
+    from radar_ml_amd import _lib
+
+    X, Y, Z = (int(t) for t in a.grid.lower().split("x"))
+    D = rml.feature_len(X, Y, Z)
+    frame_bytes = 4 * X * Y * Z
+
+    # ---- model: rank 0 fits, everyone gets the same arrays ---------------------------------
+    t0 = time.time()
+    obj = [None]
+    if rank == 0:
+        obj[0] = fit_model(rml, torch, X, Y, Z, a.train, a.gamma, a.seed, dev)
+    if world > 1:
+        dist.broadcast_object_list(obj, src=0)
+    model = obj[0]
+    fit_s = time.time() - t0
+    svc = rml.GpuSVC(sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"], model["gamma"],
+                     model["classes"], calib_a=model["calib_a"], calib_b=model["calib_b"])
+    assert svc.exact, "synthetic radar codes must be on the integer grid"
+    M = int(model["sv_u8"].shape[0])
+    torch.cuda.empty_cache()
+
+    # ---- resident batch ---------------------------------------------------------------------
+    free, total = torch.cuda.mem_get_info(dev)
+    reserve = 6 << 30
+    B = int(min(a.frames, max(128, (free - reserve) // frame_bytes)))
+    V, cls = rml.synth_volumes(B, X, Y, Z, seed=a.seed, frame0=rank * a.frames, device=dev)
+    lib = _lib.load()
+    ctx = _lib.context(dev)
+    gathered = torch.empty((world * B,), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        out = svc.decide_volumes(V, mode="max", scale=True, want_proba=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out["label_calib"])
+        return out
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    lib.rml_profile_enable(ctx, 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    nl, ms, nf = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+    lib.rml_profile_read(ctx, ctypes.byref(nl), ctypes.byref(ms), ctypes.byref(nf))
+    lib.rml_profile_enable(ctx, 0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (projection; HBM-bound) ---------------------------
+    # algorithmic bytes per frame of the fused path: the volume read + 16 B of outputs
+    alg_bytes_frame = frame_bytes + 16
+    launches = max(1, nl.value)
+    avg_ms = ms.value / launches
+    frames_per_launch = nf.value / launches
+    achieved = alg_bytes_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("project_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_project_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
+                "algorithmic_bytes_per_frame": alg_bytes_frame}
+
+    # ---- parity gate on a slab of the very frames the GPU classified ----------------------
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as OC
+    npar = min(a.parity, B)
+    vh = V[:npar].cpu().numpy()
+    threads = len(os.sched_getaffinity(0))
+    xz, yz, xy = OC.project_max(vh, threads=threads)
+    fh = OC.features(xz, yz, xy, scale=True)
+    ref = OC.svm(fh, sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"], model["gamma"],
+                 "rbf", model["calib_a"], model["calib_b"], threads=threads)
+    parity = {
+        "frames": int(npar),
+        "label_vote_mismatch": int((out["label_vote"][:npar].cpu().numpy() != ref["label_vote"]).sum()),
+        "label_calib_mismatch": int((out["label_calib"][:npar].cpu().numpy() != ref["label_calib"]).sum()),
+        "dec_ovo_max_abs_err": float(np.abs(out["dec_ovo"][:npar].cpu().numpy() - ref["dec_ovo"]).max()),
+        "dec_ovr_max_abs_err": float(np.abs(out["dec_ovr"][:npar].cpu().numpy() - ref["dec_ovr"]).max()),
+        "proba_max_abs_err": float(np.abs(out["proba"][:npar].cpu().numpy() - ref["proba"]).max()),
+        "accuracy_vs_synth_class": float((out["label_calib"][:npar].cpu().numpy() ==
+                                          np.searchsorted(model["classes"], cls[:npar].cpu().numpy())).mean()),
+    }
+
+    # ---- CPU baseline: the C port of the reference path on the host cores -------------------
+    cpu = None
+    if not a.no_cpu:
+        ncpu = a.cpu_frames
+        if ncpu <= 0:
+            # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~15 s
+            est = 3.0 * D * M / (1.2e9 * threads)
+            ncpu = int(max(threads * 4, min(npar, 15.0 / max(est, 1e-6))))
+        ncpu = min(ncpu, npar)
+        t1 = time.perf_counter()
+        cxz, cyz, cxy = OC.project_max(vh[:ncpu], threads=threads)
+        cf = OC.features(cxz, cyz, cxy, scale=True)
+        OC.svm(cf, sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
+               model["calib_a"], model["calib_b"], threads=threads)
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(ncpu / cdt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": "%d of the same synthetic frames, oracle/oracle.c (max-projection + float64 libsvm loops, "
+                         "OpenMP over frames), %.1f s" % (ncpu, cdt)}
+
+    frames_total = world * B * a.steps
+    value = frames_total / dt
+    line = {
+        "metric": "radar frames/s (3D-proj->SVM)", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
+        "config": {"workload": "configs[2]: max-projection + RBF-SVM decision_function, 3-class, %d SVs, "
+                               "batch %d frames/GPU of %dx%dx%d f32 resident in HBM" % (M, B, X, Y, Z),
+                   "grid": [X, Y, Z], "frames_per_gpu": B, "global_frames": world * B, "n_sv": M, "D": D,
+                   "gamma": a.gamma, "parallelism": "frames sharded x%d, labels all-gathered (RCCL)" % world
+                   if world > 1 else "single GPU"},
+        "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,13 @@ int rml_ctx_create(int device, rml_ctx** out);
 int rml_ctx_destroy(rml_ctx* ctx);
 int rml_ctx_device(const rml_ctx* ctx);
 
+/* In-situ timing of the projection launches issued by rml_project_svm (bench.py's roofline line):
+ * while enabled, a hipEvent pair is recorded around every projection launch on the stream it is
+ * launched on.  rml_profile_read synchronises, returns the number of launches, the summed
+ * elapsed time and the frames they covered, and resets the counters. */
+int rml_profile_enable(rml_ctx* ctx, int on);
+int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_ms, int64_t* frames);
+
 /* Feature-row length for a grid and mask: X*Z + Y*Z + X*Y over the selected planes
  * (train_svc.log:19 "Feature vector length: 10010" at (22,31,176)). */
 int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask);

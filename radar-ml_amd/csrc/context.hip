@@ -89,8 +89,47 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
         if (ctx->ev_proj[i]) (void)hipEventDestroy(ctx->ev_proj[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
+    return RML_OK;
+}
+
+void rml_prof_mark(rml_ctx* ctx, hipStream_t st) {
+    if (!ctx->profiling) return;
+    if (ctx->prof_used == ctx->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
+        ctx->prof_ev.push_back(e);
+    }
+    (void)hipEventRecord(ctx->prof_ev[ctx->prof_used++], st);
+}
+
+extern "C" int rml_profile_enable(rml_ctx* ctx, int on) {
+    RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_enable: ctx is NULL");
+    ctx->profiling = on != 0;
+    ctx->prof_used = 0;
+    ctx->prof_frames = 0;
+    return RML_OK;
+}
+
+extern "C" int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_ms, int64_t* frames) {
+    RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_read: ctx is NULL");
+    RML_HIP(hipSetDevice(ctx->device));
+    double tot = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        RML_HIP(hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float ms = 0.0f;
+        RML_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = tot;
+    if (frames) *frames = ctx->prof_frames;
+    ctx->prof_used = 0;
+    ctx->prof_frames = 0;
     return RML_OK;
 }
 

@@ -96,6 +96,7 @@ struct Emitter {
         if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)(c ^ 0x80);
     }
     __device__ __forceinline__ void put1(int pl, int64_t idx, float v) {
+        if (!((a.o.sel >> pl) & 1u)) return;
         if (a.o.p[pl]) a.o.p[pl][b * a.o.stride[pl] + idx] = scaled(v);
         if (a.o.row_nsq) { double t = (double)scaled(v); nsq += t * t; }
         if (want_stats) {
@@ -105,6 +106,7 @@ struct Emitter {
     }
     // idx is a multiple of 4
     __device__ __forceinline__ void put4(int pl, int64_t idx, float4 v) {
+        if (!((a.o.sel >> pl) & 1u)) return;
         if (a.o.p[pl]) {
             float* dst = a.o.p[pl] + b * a.o.stride[pl] + idx;
             float4 s = make_float4(scaled(v.x), scaled(v.y), scaled(v.z), scaled(v.w));
@@ -487,7 +489,9 @@ extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y
                            const int32_t* ijk, float scale_div, uint32_t mask,
                            float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
                            int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
-    RML_REQUIRE(ctx && V && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project: bad arguments");
+    RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project: V is NULL");
     RML_REQUIRE((mask & RML_MASK_ALL) != 0, RML_ERR_INVALID, "rml_project: empty projection mask");
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_project: B too large for one launch");
     const int64_t D = rml_feature_len(X, Y, Z, mask);
@@ -505,6 +509,7 @@ extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y
             off += plane_len(pl, X, Y, Z);
         }
     }
+    o.sel = mask & RML_MASK_ALL;
     o.qstride = ld_q;
     o.qrow = feat_q; o.qD = D;
     o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
@@ -514,20 +519,25 @@ extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y
 
 extern "C" int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
                                   const int32_t* ijk, float* xz, float* yz, float* xy, void* stream) {
-    RML_REQUIRE(ctx && V && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project_planes: bad arguments");
+    RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project_planes: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project_planes: V is NULL");
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_project_planes: B too large for one launch");
     RML_HIP(hipSetDevice(ctx->device));
     ProjOut o{};
     o.p[0] = xz; o.stride[0] = (int64_t)X * Z;
     o.p[1] = yz; o.stride[1] = (int64_t)Y * Z;
     o.p[2] = xy; o.stride[2] = (int64_t)X * Y;
+    o.sel = (xz ? 1u : 0u) | (yz ? 2u : 0u) | (xy ? 4u : 0u);
     o.scale_div = 0.0f;
     return rml_launch_project(ctx, V, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z,
                                   int num_targets, int32_t* ijk, float* profiles, void* stream) {
-    RML_REQUIRE(ctx && V && ijk && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_derive_targets: bad arguments");
+    RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_derive_targets: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(V && ijk, RML_ERR_INVALID, "rml_derive_targets: NULL argument");
     RML_REQUIRE(num_targets >= 1 && num_targets <= X && num_targets <= Y && num_targets <= Z, RML_ERR_INVALID,
                 "rml_derive_targets: num_targets out of range");
     RML_HIP(hipSetDevice(ctx->device));
@@ -543,6 +553,7 @@ extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X
     ProjOut o{};
     o.p[0] = xzs; o.stride[0] = (int64_t)X * Z;
     o.p[1] = yzs; o.stride[1] = (int64_t)Y * Z;
+    o.sel = 3u;
     o.scale_div = 0.0f;
     rc = rml_launch_project(ctx, V, B, X, Y, Z, RML_MODE_SUM, nullptr, o, st);
     if (rc) return rc;
@@ -555,7 +566,9 @@ extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X
 extern "C" int rml_assemble_features(rml_ctx* ctx, const float* xz, const float* yz, const float* xy,
                                      int64_t B, int X, int Y, int Z, float scale_div, uint32_t mask,
                                      float* feat, int64_t ld_feat, void* stream) {
-    RML_REQUIRE(ctx && feat && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_assemble_features: bad arguments");
+    RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_assemble_features: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(feat != nullptr, RML_ERR_INVALID, "rml_assemble_features: feat is NULL");
     RML_REQUIRE((mask & RML_MASK_ALL) != 0, RML_ERR_INVALID, "rml_assemble_features: empty mask");
     const float* src[3] = {xz, yz, xy};
     for (int pl = 0; pl < 3; ++pl)
@@ -568,6 +581,7 @@ extern "C" int rml_assemble_features(rml_ctx* ctx, const float* xz, const float*
     int64_t off = 0;
     for (int pl = 0; pl < 3; ++pl)
         if (mask & (1u << pl)) { o.p[pl] = feat + off; o.stride[pl] = ld_feat; off += plane_len(pl, X, Y, Z); }
+    o.sel = mask & RML_MASK_ALL;
     o.scale_div = scale_div;
     ProjParams pp;
     fill_params(pp, nullptr, B, X, Y, Z, nullptr, o);
@@ -580,12 +594,13 @@ extern "C" int rml_assemble_features(rml_ctx* ctx, const float* xz, const float*
 extern "C" int rml_quantize_rows(rml_ctx* ctx, const float* feat, int64_t N, int64_t D, int64_t ld_feat,
                                  float scale_div, uint8_t* feat_q, int64_t ld_q,
                                  int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
-    RML_REQUIRE(ctx && feat && feat_q && N >= 0 && D > 0 && ld_feat >= D && ld_q >= D, RML_ERR_INVALID,
-                "rml_quantize_rows: bad arguments");
+    RML_REQUIRE(ctx && N >= 0 && D > 0 && ld_feat >= D && ld_q >= D, RML_ERR_INVALID, "rml_quantize_rows: bad arguments");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(feat && feat_q, RML_ERR_INVALID, "rml_quantize_rows: NULL argument");
     RML_HIP(hipSetDevice(ctx->device));
     if (N == 0) return RML_OK;
     ProjOut o{};
-    o.q[0] = feat_q; o.qstride = ld_q; o.qrow = feat_q; o.qD = D;
+    o.q[0] = feat_q; o.qstride = ld_q; o.qrow = feat_q; o.qD = D; o.sel = 1u;
     o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
     o.scale_div = 0.0f;
     ProjParams pp;

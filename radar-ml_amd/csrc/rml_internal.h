@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/radarml.h"
 
 struct rml_ctx {
@@ -14,7 +15,15 @@ struct rml_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
+    // optional in-situ timing of the projection launches issued by rml_project_svm
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_ev;    // start/stop pairs
+    size_t prof_used = 0;
+    int64_t prof_frames = 0;
 };
+
+// records an event on st when profiling is on (no-op otherwise)
+void rml_prof_mark(rml_ctx* ctx, hipStream_t st);
 
 void rml_set_error(const char* fmt, ...);
 int rml_hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -40,6 +49,7 @@ struct ProjOut {
     // destination of each plane for frame b: p[pl] + b*stride[pl] (float) ; NULL = plane not wanted
     float* p[3];
     int64_t stride[3];
+    uint32_t sel;      // bit pl set: plane pl is part of the row (stored and counted in the statistics)
     // uint8 codes of the same values (before scaling); NULL = not wanted
     uint8_t* q[3];
     int64_t qstride;

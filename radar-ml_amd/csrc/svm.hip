@@ -658,6 +658,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
                                 double* dec_ovo, double* dec_ovr, double* proba,
                                 int32_t* label_vote, int32_t* label_calib, void* stream) {
     RML_REQUIRE(ctx && m && N >= 0, RML_ERR_INVALID, "rml_svm_decision: bad arguments");
+    if (N == 0) return RML_OK;
     RML_REQUIRE(feat || feat_q, RML_ERR_INVALID, "rml_svm_decision: need feat or feat_q");
     RML_REQUIRE(!feat || ld_feat >= m->D, RML_ERR_INVALID, "rml_svm_decision: ld_feat < D");
     RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_I8, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
@@ -704,7 +705,9 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
                                int mode, const int32_t* ijk, float scale_div, uint32_t mask,
                                double* dec_ovo, double* dec_ovr, double* proba,
                                int32_t* label_vote, int32_t* label_calib, void* stream) {
-    RML_REQUIRE(ctx && m && V && B >= 0, RML_ERR_INVALID, "rml_project_svm: bad arguments");
+    RML_REQUIRE(ctx && m && B >= 0, RML_ERR_INVALID, "rml_project_svm: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project_svm: V is NULL");
     RML_REQUIRE(rml_feature_len(X, Y, Z, mask) == m->D, RML_ERR_INVALID, "rml_project_svm: grid/mask give D=%lld, model has D=%lld",
                 (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
@@ -744,13 +747,17 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
                 o.q[pl] = grid_ok ? w.q + off : nullptr;
                 off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
             }
+        o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
         const float* Vc = V + r0 * frame_elems;
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
+            rml_prof_mark(ctx, st);
             rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, o, st);
+            rml_prof_mark(ctx, st);
+            if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, w.flags, n, FT, 0, 1, w.tile_exact, w.all_exact);
@@ -763,10 +770,13 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
                 of.p[pl] = w.f32 + off; of.stride[pl] = m->Df;
                 off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
             }
+        of.sel = mask & RML_MASK_ALL;
         of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
+        if (!grid_ok) rml_prof_mark(ctx, st);
         rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, of, st);
+        if (!grid_ok) { rml_prof_mark(ctx, st); if (ctx->profiling) ctx->prof_frames += n; }
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
@@ -821,7 +831,9 @@ extern "C" int rml_linear_free(rml_ctx* ctx, rml_linear* m) {
 
 extern "C" int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, int64_t ld_feat, int64_t N,
                                    double* dec, double* proba, int32_t* label, int32_t* label_calib, void* stream) {
-    RML_REQUIRE(ctx && m && feat && N >= 0 && ld_feat >= m->D, RML_ERR_INVALID, "rml_linear_decision: bad arguments");
+    RML_REQUIRE(ctx && m && N >= 0, RML_ERR_INVALID, "rml_linear_decision: bad arguments");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(feat && ld_feat >= m->D, RML_ERR_INVALID, "rml_linear_decision: bad arguments");
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_linear_decision: model has no calibrators");
     RML_HIP(hipSetDevice(ctx->device));
     if (N == 0) return RML_OK;

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_synth_scalar(uint32_t seed_lo, uint32_t
 
 extern "C" int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
                                  int n_classes, float* V, int32_t* cls, void* stream) {
+    if (ctx && B == 0) return RML_OK;
     RML_REQUIRE(ctx && V && B >= 0 && X > 0 && Y > 0 && Z > 0 && n_classes > 0, RML_ERR_INVALID, "rml_synth_volumes: bad arguments");
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_synth_volumes: B too large for one launch");
     RML_HIP(hipSetDevice(ctx->device));
