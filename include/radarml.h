@@ -61,9 +61,10 @@ typedef struct rml_linear rml_linear;
 #define RML_KERNEL_LINEAR 1
 
 /* GEMM path selection for rml_svm_decision */
-#define RML_PATH_AUTO  0   /* exact-integer path when model and rows are integer valued, else f32 */
-#define RML_PATH_F32   1   /* v_mfma_f32_32x32x2_f32, centred operands                            */
-#define RML_PATH_I8    2   /* v_mfma_i32_16x16x64_i8 on u8 codes, exact int32 dot products        */
+#define RML_PATH_AUTO  0   /* exact-integer path where model and rows are on the code grid, else f64 */
+#define RML_PATH_F32   1   /* v_mfma_f32_32x32x2_f32: opt-in, approximate (f32 accumulate, ~1e-4)     */
+#define RML_PATH_I8    2   /* v_mfma_i32_32x32x32_i8 on u8 codes, exact int32 dot products            */
+#define RML_PATH_F64   3   /* v_mfma_f64_16x16x4_f64 on widened float32 rows: libsvm-class accuracy   */
 
 const char* rml_version(void);
 const char* rml_last_error(void);

@@ -63,8 +63,8 @@ SIGNATURES = {
 MODE_MAX, MODE_SLICE, MODE_SUM = 0, 1, 2
 MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM}
 KERNEL_RBF, KERNEL_LINEAR = 0, 1
-PATH_AUTO, PATH_F32, PATH_I8 = 0, 1, 2
-PATHS = {"auto": PATH_AUTO, "f32": PATH_F32, "i8": PATH_I8}
+PATH_AUTO, PATH_F32, PATH_I8, PATH_F64 = 0, 1, 2, 3
+PATHS = {"auto": PATH_AUTO, "f32": PATH_F32, "i8": PATH_I8, "f64": PATH_F64}
 
 
 def load():

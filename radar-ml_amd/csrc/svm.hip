@@ -19,8 +19,12 @@
 //        x.s is EXACT in int32 on v_mfma_i32_32x32x32_i8.  Codes are stored biased
 //        (byte = c ^ 0x80 = int8 c-128):  sum (a-128)(b-128) = sum ab - 128 (sum a + sum b) + 128^2 D.
 //        d^2 is then an exact integer, evaluated in float64.
-//   F32  general rows on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate), norms
-//        in float64.
+//   F64  general rows (anything not on the code grid: augmented / zoomed data) on
+//        v_mfma_f64_16x16x4_f64: the float32 operands are widened to float64 in registers, the
+//        products and the accumulation are float64 -- the arithmetic class of libsvm itself, at
+//        the f64 matrix rate (78.6 TF).  This is what RML_PATH_AUTO uses for non-grid rows.
+//   F32  opt-in approximate path on v_mfma_f32_32x32x2_f32 (f32 accumulate, 2x the F64 rate;
+//        measured error of the decision values ~1e-4..1e-3, i.e. outside the 1e-5 bar).
 // Epilogue (float64): K = exp(-gamma d^2); per-pair weights W[p][m] (the libsvm pair loop
 // unrolled into a P x M matrix at load) -> S[n][p] += W[p][m] K.  The MFMA is issued with the
 // SV tile as the A (row) operand and the sample tile as the B (column) operand, so that a lane
@@ -50,11 +54,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kTile = 128;         // rows per operand tile
 constexpr int kStepBytes = 128;    // K-step bytes per row
 constexpr int kTileBytes = kTile * kStepBytes;   // 16 KiB
-constexpr int PATH_I8 = 0, PATH_F32 = 1;
+constexpr int PATH_I8 = 0, PATH_F32 = 1, PATH_F64 = 2;
 
 struct GemmArgs {
     const uint8_t* sv; int64_t ld_sv;     // SV operand, bytes per row
@@ -132,14 +137,35 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
     const int chalf = lane >> 5;
 
+    // accumulators: I8/F32: 2x2 tiles of 32x32 (16 regs each); F64: 4x4 tiles of 16x16 (4 doubles each)
     using acc_t = typename std::conditional<PATH == PATH_I8, v16i, v16f>::type;
     acc_t acc[2][2];
+    v4d accd[PATH == PATH_F64 ? 4 : 1][PATH == PATH_F64 ? 4 : 1];
+    if constexpr (PATH == PATH_F64) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) accd[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    }
+    // F64 fragment addressing: lane = (row l&15, k-group l>>4) of a 16-row tile
+    int doff_a[4], dsw_a[4], doff_b[4], dsw_b[4];
+    if constexpr (PATH == PATH_F64) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int ra = wr * 64 + t * 16 + (lane & 15);
+            int rb = wc * 64 + t * 16 + (lane & 15);
+            doff_a[t] = ra * kStepBytes; dsw_a[t] = (ra >> 1) & 7;
+            doff_b[t] = rb * kStepBytes; dsw_b[t] = (rb >> 1) & 7;
+        }
+    }
+    const int kgrp = lane >> 4;
 
     stage(0, 0);
     for (int kt = 0; kt < a.KT; ++kt) {
@@ -147,29 +173,117 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
         if (kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 2 * kTileBytes;
         const unsigned char* sB = sA + kTileBytes;
+        if constexpr (PATH == PATH_F64) {
+            // 32 floats per row per K-step = 8 chunks of 4; pass h covers chunks 4h..4h+3, one per
+            // k-group; MFMA c of a pass multiplies element c of every lane's chunk (k = 4*chunk + c).
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = 2 * kk + chalf;
-            v4i af[2], bf[2];
+            for (int hh = 0; hh < 2; ++hh) {
+                const int ch = 4 * hh + kgrp;
+                v4f af[4], bf[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
-                bf[t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (PATH == PATH_I8) {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(af[i][c]), __int_as_float(bf[j][c]),
-                                                                            acc[i][j], 0, 0, 0);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    af[t] = *reinterpret_cast<const v4f*>(sA + doff_a[t] + ((ch ^ dsw_a[t]) << 4));
+                    bf[t] = *reinterpret_cast<const v4f*>(sB + doff_b[t] + ((ch ^ dsw_b[t]) << 4));
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double ad[4], bd[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { ad[t] = (double)af[t][c]; bd[t] = (double)bf[t][c]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            accd[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[i], bd[j], accd[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ch = 2 * kk + chalf;
+                v4i af[2], bf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    af[t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
+                    bf[t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (PATH == PATH_I8) {
+                            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(af[i][c]), __int_as_float(bf[j][c]),
+                                                                                acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
         }
+    }
+
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    double* xch = svw + kTile * (1 + PT);      // [128][PT] cross-thread exchange
+    if constexpr (PATH == PATH_F64) {
+        // float64 accumulators: 128 x 128 x 8 B = 128 KiB, so the LDS round trip is done in two column
+        // halves of 64 KiB (the waves with wc == pass own that half).  Thread t then owns sample column
+        // n' = t & 63 of the half and the SV quarter t >> 6 (32 in-lane SV rows).
+        double* gd = reinterpret_cast<double*>(smem);
+        const int nq = tid & 63, qd = tid >> 6;
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if (wc == pass) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ml = wr * 64 + i * 16 + kgrp + 4 * r;     // f64 C/D map: row = (lane>>4) + 4 reg
+                            const int nl = j * 16 + (lane & 15);                //              col = lane & 15
+                            gd[ml * 64 + nl] = accd[i][j][r];
+                        }
+            }
+            __syncthreads();
+            const int64_t n = f0 + pass * 64 + nq;
+            const int64_t nc = n < a.N ? n : a.N - 1;
+            const double xt = rbf ? a.x_nsq[nc] : 0.0;
+            double S[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) S[p] = 0.0;
+#pragma unroll 2
+            for (int mm = 0; mm < 32; ++mm) {
+                const int ml = qd * 32 + mm;
+                const double* e = svw + ml * (1 + PT);
+                const double g = gd[ml * 64 + nq];
+                double kv;
+                if (rbf) {
+                    double d2 = xt + e[0] - 2.0 * g;
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    kv = exp(-a.gs * d2);
+                } else {
+                    kv = g;
+                }
+#pragma unroll
+                for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+            }
+            __syncthreads();                   // G half consumed: reuse its LDS for the exchange
+            double* x4 = gd;                   // [4 quarters][64][PT]
+#pragma unroll
+            for (int p = 0; p < PT; ++p) x4[(qd * 64 + nq) * PT + p] = S[p];
+            __syncthreads();
+            if (qd == 0 && n < a.N) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    double t = x4[(0 * 64 + nq) * PT + p] + x4[(1 * 64 + nq) * PT + p];
+                    t += x4[(2 * 64 + nq) * PT + p] + x4[(3 * 64 + nq) * PT + p];
+                    a.partial[((int64_t)stile * a.Npart + n) * PT + p] = t;
+                }
+            }
+        }
+        return;
     }
 
     // ---- fused float64 epilogue ----------------------------------------------------------
@@ -195,7 +309,6 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
     __syncthreads();
     const int nl = tid & 127, h = tid >> 7;
-    const bool rbf = (a.kernel == RML_KERNEL_RBF);
     int64_t n = f0 + nl;
     const int64_t nc = n < a.N ? n : a.N - 1;
     double xt;
@@ -226,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
     }
-    double* xch = svw + kTile * (1 + PT);      // [128][PT]
     if (h == 1) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) xch[nl * PT + p] = S[p];
@@ -510,11 +622,13 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
-    const bool run_i8 = m->exact && q && policy != 1;
-    const bool run_f32 = f32 && policy != 2;
-    RML_REQUIRE(run_i8 || run_f32, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
+    // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
+    const bool run_i8 = m->exact && q && (policy == RML_PATH_AUTO || policy == RML_PATH_I8);
+    const bool run_gen = f32 && policy != RML_PATH_I8;
+    const bool gen_f32 = (policy == RML_PATH_F32);
+    RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, flags, n, FT,
-                       run_i8 ? (run_f32 ? policy : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
+                       run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
     GemmArgs ga{};
     ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
@@ -526,17 +640,17 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
         int rc = launch_gemm<PATH_I8>(m, ga, st);
         if (rc) return rc;
     }
-    if (run_f32) {
+    if (run_gen) {
         ga.sv = reinterpret_cast<const uint8_t*>(m->sv_f32); ga.ld_sv = m->Df * 4;
         ga.x = reinterpret_cast<const uint8_t*>(f32); ga.ld_x = m->Df * 4; ga.KT = (int)(m->Df * 4 / kStepBytes);
         ga.want = 0; ga.x_nsq = nsq; ga.sv_term = m->sv_nsq; ga.gs = m->gamma;
-        int rc = launch_gemm<PATH_F32>(m, ga, st);
+        int rc = gen_f32 ? launch_gemm<PATH_F32>(m, ga, st) : launch_gemm<PATH_F64>(m, ga, st);
         if (rc) return rc;
     }
     FinishArgs fa{};
     fa.partial = w.partial; fa.Npart = n; fa.ST = ST; fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
     fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
-    fa.row_flags = flags; fa.tile_exact = w.tile_exact; fa.forced_i8 = (run_i8 && !run_f32);
+    fa.row_flags = flags; fa.tile_exact = w.tile_exact; fa.forced_i8 = (run_i8 && !run_gen);
     fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
     fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
     hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
@@ -661,12 +775,12 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (N == 0) return RML_OK;
     RML_REQUIRE(feat || feat_q, RML_ERR_INVALID, "rml_svm_decision: need feat or feat_q");
     RML_REQUIRE(!feat || ld_feat >= m->D, RML_ERR_INVALID, "rml_svm_decision: ld_feat < D");
-    RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_I8, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
+    RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_F64, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_svm_decision: model has no calibrators");
     RML_REQUIRE(path != RML_PATH_I8 || m->exact, RML_ERR_STATE, "rml_svm_decision: exact path requested but the model is not on the code grid");
     if (!feat) {
         RML_REQUIRE(m->exact, RML_ERR_STATE, "rml_svm_decision: code rows given but the model is not on the code grid");
-        RML_REQUIRE(path != RML_PATH_F32, RML_ERR_INVALID, "rml_svm_decision: f32 path needs float rows");
+        RML_REQUIRE(path == RML_PATH_AUTO || path == RML_PATH_I8, RML_ERR_INVALID, "rml_svm_decision: the float paths need float rows");
         RML_REQUIRE(row_isum && row_isq, RML_ERR_INVALID, "rml_svm_decision: code rows need row_isum/row_isq");
         RML_REQUIRE(ld_q >= m->Dq && ld_q % 16 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 15) == 0, RML_ERR_INVALID,
                     "rml_svm_decision: code rows need ld_q >= %lld, ld_q %% 16 == 0 and 16-byte alignment", (long long)m->Dq);
@@ -675,7 +789,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (N == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
-    const bool need_q = feat != nullptr && m->exact && path != RML_PATH_F32;
+    const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
     ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32);
     void* ws = nullptr;
@@ -683,7 +797,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (rc) return rc;
     ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, need_f32);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
-    const int policy = path;   // 0 auto, 1 f32, 2 i8
+    const int policy = path;
     for (int64_t r0 = 0; r0 < N; r0 += CH) {
         const int64_t n = std::min(CH, N - r0);
         if (feat) {
@@ -692,7 +806,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
             RML_HIP(hipGetLastError());
             rc = run_chunk(m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st);
         } else {
-            rc = run_chunk(m, 2, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
+            rc = run_chunk(m, RML_PATH_I8, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
                            nullptr, nullptr, w, out.at(r0, m->C, m->P), st);
         }
         if (rc) return rc;
@@ -780,7 +894,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
-        rc = run_chunk(m, grid_ok ? 0 : 1, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
+        rc = run_chunk(m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux);
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_done[c & 1], aux));

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmarks (BASELINE configs[1] projection-only roofline check, and the SVM GEMM).
+
+    python tools/kbench.py proj [--grid 64x64x128] [--frames 4096] [--iters 20]
+    python tools/kbench.py svm  [--grid 64x64x128] [--frames 8192] [--svs 2048] [--path i8|f32]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(torch, fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts = np.array(ts)
+    return float(np.median(ts)), float(ts.min()), float(ts.mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["proj", "svm", "copy"])
+    ap.add_argument("--grid", default="64x64x128")
+    ap.add_argument("--frames", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--svs", type=int, default=2048)
+    ap.add_argument("--path", default="i8")
+    ap.add_argument("--mode", default="max")
+    a = ap.parse_args()
+    import torch
+    import radar_ml_amd as rml
+    from radar_ml_amd import _lib
+    X, Y, Z = (int(t) for t in a.grid.split("x"))
+    D = rml.feature_len(X, Y, Z)
+    B = a.frames
+    dev = torch.device("cuda", 0)
+    if a.what == "copy":
+        n = B * X * Y * Z
+        src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        med, mn, _ = timeit(torch, lambda: dst.copy_(src), a.iters)
+        print(json.dumps({"what": "torch copy", "bytes": 8 * n, "ms": med, "GBs": 8 * n / med / 1e6}))
+        med, mn, _ = timeit(torch, lambda: src.amax(), a.iters)
+        print(json.dumps({"what": "torch amax (read only)", "bytes": 4 * n, "ms": med, "GBs": 4 * n / med / 1e6}))
+        return
+    V, cls = rml.synth_volumes(B, X, Y, Z, seed=1)
+    if a.what == "proj":
+        feat = torch.empty((B, D), dtype=torch.float32, device=dev)
+        res = []
+        for label, kw, outbytes in [("f32 rows", dict(out=feat), 4 * D), ("f32 rows /255", dict(out=feat, scale=True), 4 * D),
+                                    ("f32 rows + codes", dict(out=feat, codes=True), 4 * D + (D + 127) // 128 * 128)]:
+            med, mn, mean = timeit(torch, lambda: rml.process_volumes(V, mode=a.mode, **kw), a.iters)
+            alg = B * (4 * X * Y * Z + outbytes)
+            res.append({"what": "project %s %s" % (a.mode, label), "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4),
+                        "ms_min": round(mn, 4), "frames_per_s": round(B / med * 1e3), "alg_GBs": round(alg / med / 1e6, 1),
+                        "frac_of_8TBs": round(alg / med / 1e6 / 8000, 4)})
+        for r in res:
+            print(json.dumps(r))
+    else:
+        rng = np.random.default_rng(0)
+        M = a.svs
+        feat, q, isum, isq, flags = rml.process_volumes(V, mode="max", scale=True, codes=True)
+        svq = (q[:M, :D] ^ 0x80).cpu().numpy() if M <= B else None
+        sv = (svq.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+        ns = np.array([M // 3, M // 3, M - 2 * (M // 3)], dtype=np.int32)
+        dc = rng.uniform(-10, 10, (2, M))
+        svc = rml.GpuSVC(sv, dc, np.array([0.1, -0.2, 0.3]), ns, 0.01, np.arange(3), path=a.path)
+        Xd = feat
+        med, mn, mean = timeit(torch, lambda: svc._decide(Xd), max(3, a.iters // 4))
+        ops = 2.0 * B * M * D
+        print(json.dumps({"what": "svm decision path=%s (incl. row prep)" % a.path, "N": B, "M": M, "D": D, "ms_med": round(med, 3),
+                          "frames_per_s": round(B / med * 1e3), "T_op_s": round(ops / med / 1e9, 1)}))
+
+
+if __name__ == "__main__":
+    main()
