@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--grid", default="64x64x128", help="XxYxZ; 22x31x176 = Walabot arena grid")
     ap.add_argument("--train", type=int, default=3400, help="synthetic frames used to fit the SVC (CPU plumbing)")
     ap.add_argument("--gamma", type=float, default=0.01)
-    ap.add_argument("--parity", type=int, default=512, help="frames checked against the CPU oracle")
+    ap.add_argument("--parity", type=int, default=4096, help="frames checked against the CPU oracle")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
@@ -216,7 +216,7 @@ def main():
         if ncpu <= 0:
             # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~15 s
             est = 3.0 * D * M / (1.2e9 * threads)
-            ncpu = int(max(threads * 4, min(npar, 15.0 / max(est, 1e-6))))
+            ncpu = int(max(threads * 4, min(npar, 20.0 / max(est, 1e-6))))
         ncpu = min(ncpu, npar)
         t1 = time.perf_counter()
         cxz, cyz, cxy = OC.project_max(vh[:ncpu], threads=threads)

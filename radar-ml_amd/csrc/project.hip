@@ -174,10 +174,12 @@ template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r
 // ------------------------------------------------------------------------------------------
 // Fast path: Z % 4 == 0, Z/4 <= 64, Y <= NM * NSLOT.  One workgroup (256 threads) per frame.
 // ------------------------------------------------------------------------------------------
-template <int MODE, int LPR, int NM>
+// PRED = launch predicated on a device flag (a separate instantiation so that profiles do not mix the
+// no-op launches of the predicated second pass of rml_project_svm with the real ones).
+template <int MODE, int LPR, int NM, bool PRED>
 __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     extern __shared__ __align__(16) float lds[];
-    if (a.o.skip_if_set && *a.o.skip_if_set) return;
+    if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
     float* xz_lds = lds;                 // X*Z
     float* xy_lds = lds + (size_t)X * Z; // X*Y
@@ -395,16 +397,26 @@ __global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const fl
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+template <int MODE, int LPR, int NM>
+void launch_fast_pred(const ProjParams& pp, size_t lds_bytes, hipStream_t st) {
+    dim3 grid((unsigned)pp.B), block(kThreads);
+    // > 64 KB of dynamic LDS needs the attribute (gfx950 has 160 KB per CU); harmless otherwise
+    if (pp.o.skip_if_set) {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, true>), grid, block, lds_bytes, st, pp);
+    } else {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, false>), grid, block, lds_bytes, st, pp);
+    }
+}
+
 template <int MODE, int LPR>
 int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t st) {
-    dim3 grid((unsigned)pp.B), block(kThreads);
-    if (nm <= 4) {
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, 4>), grid, block, lds_bytes, st, pp);
-    } else if (nm <= 8) {
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, 8>), grid, block, lds_bytes, st, pp);
-    } else {
-        return 1;
-    }
+    if (nm <= 4) launch_fast_pred<MODE, LPR, 4>(pp, lds_bytes, st);
+    else if (nm <= 8) launch_fast_pred<MODE, LPR, 8>(pp, lds_bytes, st);
+    else return 1;
     return 0;
 }
 
@@ -438,31 +450,12 @@ void fill_params(ProjParams& pp, const float* V, int64_t B, int X, int Y, int Z,
 
 }  // namespace
 
-static int set_fast_attr_once() {
-    // allow > 64 KB dynamic LDS for the fast kernels (gfx950 has 160 KB per CU)
-    static bool done = false;
-    if (done) return 0;
-#define RML_SET_ATTR(MODE, LPR, NM) \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    RML_SET_ATTR(RML_MODE_MAX, 16, 4); RML_SET_ATTR(RML_MODE_MAX, 16, 8);
-    RML_SET_ATTR(RML_MODE_MAX, 32, 4); RML_SET_ATTR(RML_MODE_MAX, 32, 8);
-    RML_SET_ATTR(RML_MODE_MAX, 64, 4); RML_SET_ATTR(RML_MODE_MAX, 64, 8);
-    RML_SET_ATTR(RML_MODE_SUM, 16, 4); RML_SET_ATTR(RML_MODE_SUM, 16, 8);
-    RML_SET_ATTR(RML_MODE_SUM, 32, 4); RML_SET_ATTR(RML_MODE_SUM, 32, 8);
-    RML_SET_ATTR(RML_MODE_SUM, 64, 4); RML_SET_ATTR(RML_MODE_SUM, 64, 8);
-#undef RML_SET_ATTR
-    (void)hipGetLastError();
-    done = true;
-    return 0;
-}
-
 int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st) {
     (void)ctx;
     if (B == 0) return RML_OK;
     ProjParams pp;
     fill_params(pp, V, B, X, Y, Z, ijk, o);
-    set_fast_attr_once();
     bool fast = false;
     if (mode == RML_MODE_MAX) launch_mode<RML_MODE_MAX>(pp, st, &fast);
     else if (mode == RML_MODE_SUM) launch_mode<RML_MODE_SUM>(pp, st, &fast);

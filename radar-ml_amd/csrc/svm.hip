@@ -396,23 +396,23 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t
     }
 }
 
-// tile_exact[ft] = policy(flags of the 128 rows of tile ft); *all_exact = AND over tiles
-__global__ void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force f32,2 force i8*/,
-                             int model_exact, int32_t* tile_exact, int32_t* all_exact) {
-    const int ft = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ft >= FT) return;
+// tile_exact[ft] = policy(flags of the 128 rows of tile ft); *all_exact = AND over tiles.
+// One 128-thread block per tile, one row flag per thread.
+__global__ __launch_bounds__(128) void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force general,2 force i8*/,
+                                                    int model_exact, int32_t* tile_exact, int32_t* all_exact) {
+    const int ft = blockIdx.x;
     int e;
     if (policy == 1) e = 0;
     else if (policy == 2) e = 1;
     else {
-        e = model_exact && flags != nullptr;
-        if (e) {
-            int64_t r0 = (int64_t)ft * kTile, r1 = r0 + kTile < N ? r0 + kTile : N;
-            for (int64_t r = r0; r < r1; ++r) e &= (flags[r] != 0);
-        }
+        const int64_t r = (int64_t)ft * kTile + threadIdx.x;
+        int mine = (model_exact && flags != nullptr) ? ((r < N) ? (flags[r] != 0) : 1) : 0;
+        e = __syncthreads_and(mine);
     }
-    tile_exact[ft] = e;
-    if (!e && all_exact) atomicAnd(all_exact, 0);
+    if (threadIdx.x == 0) {
+        tile_exact[ft] = e;
+        if (!e && all_exact) atomicAnd(all_exact, 0);
+    }
 }
 
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
@@ -619,7 +619,8 @@ struct DecisionOut {
 
 // GEMM(s) + finish for one chunk whose operands are already in place.
 int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
-              const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st) {
+              const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
+              bool tiles_done = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -627,8 +628,9 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     const bool run_gen = f32 && policy != RML_PATH_I8;
     const bool gen_f32 = (policy == RML_PATH_F32);
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
-    hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, flags, n, FT,
-                       run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
+    if (!tiles_done)
+        hipLaunchKernelGGL(k_tile_flags, dim3(FT), dim3(128), 0, st, flags, n, FT,
+                           run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
     GemmArgs ga{};
     ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
@@ -874,7 +876,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            hipLaunchKernelGGL(k_tile_flags, dim3((FT + 255) / 256), dim3(256), 0, st, w.flags, n, FT, 0, 1, w.tile_exact, w.all_exact);
+            hipLaunchKernelGGL(k_tile_flags, dim3(FT), dim3(128), 0, st, w.flags, n, FT, 0, 1, w.tile_exact, w.all_exact);
         }
         // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
         ProjOut of{};
@@ -895,7 +897,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
         rc = run_chunk(m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
-                       out.at(r0, m->C, m->P), aux);
+                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok);
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_done[c & 1], aux));
     }
