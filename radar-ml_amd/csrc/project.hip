@@ -176,7 +176,11 @@ template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r
 // ------------------------------------------------------------------------------------------
 // PRED = launch predicated on a device flag (a separate instantiation so that profiles do not mix the
 // no-op launches of the predicated second pass of rml_project_svm with the real ones).
-template <int MODE, int LPR, int NM, bool PRED>
+// FULL = no padding anywhere (Y == NM*NSLOT and Z/4 == LPR): the streaming loop carries no masks.
+// Loads are ALWAYS unconditional: padded rows / lanes re-read a valid neighbour (clamped offset) and
+// are neutralised afterwards (a duplicate is harmless for max; sum selects 0) -- a conditional load
+// makes hipcc branch around every load and drain vmcnt per element, which de-pipelines the stream.
+template <int MODE, int LPR, int NM, bool FULL, bool PRED>
 __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     extern __shared__ __align__(16) float lds[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = wave * RPW + lane / LPR;
     const int kq = lane % LPR;
-    const bool act = kq < ZQ;
+    const bool act = FULL || (kq < ZQ);
     const int64_t b = blockIdx.x;
     const float4* __restrict__ Vb = reinterpret_cast<const float4*>(a.V + b * (int64_t)X * Y * Z);
 
@@ -202,24 +206,25 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     float4 yz[NM];
     int roff[NM];
     bool rv[NM];
+    const int kqc = FULL ? kq : min(kq, ZQ - 1);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        int j = slot + NSLOT * m;
-        rv[m] = act && (j < Y);
-        roff[m] = j * ZQ + kq;
+        const int j = slot + NSLOT * m;
+        rv[m] = FULL || (act && (j < Y));
+        roff[m] = (FULL ? j : min(j, Y - 1)) * ZQ + kqc;
         yz[m] = id4;
     }
     const int plane = Y * ZQ;
 
-    float4 cur[NM], nxt[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) cur[m] = rv[m] ? Vb[roff[m]] : id4;
-
+#pragma unroll 2
     for (int i = 0; i < X; ++i) {
-        if (i + 1 < X) {
-            const float4* __restrict__ Vn = Vb + (int64_t)(i + 1) * plane;
+        const float4* __restrict__ Vi = Vb + (int64_t)i * plane;
+        float4 cur[NM];
 #pragma unroll
-            for (int m = 0; m < NM; ++m) nxt[m] = rv[m] ? Vn[roff[m]] : id4;
+        for (int m = 0; m < NM; ++m) cur[m] = Vi[roff[m]];
+        if constexpr (!FULL && MODE == RML_MODE_SUM) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) cur[m] = rv[m] ? cur[m] : id4;
         }
         float4 p = id4;
 #pragma unroll
@@ -228,8 +233,8 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
             p = op4<MODE>(p, cur[m]);
             float r = Op<MODE>::f(Op<MODE>::f(cur[m].x, cur[m].y), Op<MODE>::f(cur[m].z, cur[m].w));
             r = row_reduce<MODE, LPR>(r);
-            int j = slot + NSLOT * m;
-            if (kq == 0 && j < Y) xy_lds[i * Y + j] = r;
+            const int j = slot + NSLOT * m;
+            if (kq == 0 && (FULL || j < Y)) xy_lds[i * Y + j] = r;
         }
         // combine the row slots that share this wave, then the 4 waves through LDS atomics
 #pragma unroll
@@ -246,8 +251,6 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
             Op<MODE>::lds_atomic(dst + 2, p.z);
             Op<MODE>::lds_atomic(dst + 3, p.w);
         }
-#pragma unroll
-        for (int m = 0; m < NM; ++m) cur[m] = nxt[m];
     }
 
     Emitter em(a, b);
@@ -397,26 +400,29 @@ __global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const fl
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-template <int MODE, int LPR, int NM>
+template <int MODE, int LPR, int NM, bool FULL>
 void launch_fast_pred(const ProjParams& pp, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block(kThreads);
     // > 64 KB of dynamic LDS needs the attribute (gfx950 has 160 KB per CU); harmless otherwise
     if (pp.o.skip_if_set) {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, true>), grid, block, lds_bytes, st, pp);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, FULL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, FULL, true>), grid, block, lds_bytes, st, pp);
     } else {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, false>), grid, block, lds_bytes, st, pp);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, FULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, FULL, false>), grid, block, lds_bytes, st, pp);
     }
 }
 
 template <int MODE, int LPR>
 int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t st) {
-    if (nm <= 4) launch_fast_pred<MODE, LPR, 4>(pp, lds_bytes, st);
-    else if (nm <= 8) launch_fast_pred<MODE, LPR, 8>(pp, lds_bytes, st);
-    else return 1;
+    constexpr int NSLOT = 4 * (64 / LPR);
+    if (nm > 8) return 1;
+    const int NMr = nm <= 4 ? 4 : 8;
+    const bool full = (pp.ZQ == LPR) && (pp.Y == NMr * NSLOT);
+    if (NMr == 4) { if (full) launch_fast_pred<MODE, LPR, 4, true>(pp, lds_bytes, st); else launch_fast_pred<MODE, LPR, 4, false>(pp, lds_bytes, st); }
+    else          { if (full) launch_fast_pred<MODE, LPR, 8, true>(pp, lds_bytes, st); else launch_fast_pred<MODE, LPR, 8, false>(pp, lds_bytes, st); }
     return 0;
 }
 

@@ -30,8 +30,22 @@ __global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ V, si
     if (r == 12345.678f) out[blockIdx.x] = r;
 }
 
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// max over the 32 lanes of a half-wave; lanes 16..31 (48..63) end with the result
+__device__ __forceinline__ float rowmax32_dpp(float r) {
+    r = fmaxf(r, dppf<0xB1>(r));        // quad_perm [1,0,3,2]
+    r = fmaxf(r, dppf<0x4E>(r));        // quad_perm [2,3,0,1]
+    r = fmaxf(r, dppf<0x141>(r));       // row_half_mirror
+    r = fmaxf(r, dppf<0x140>(r));       // row_mirror
+    r = fmaxf(r, dppf<0x142, 0xA>(r));  // row_bcast15 into rows 1 and 3
+    return r;
+}
+
 // frame-per-block streaming, contiguous per block (the product kernel's access pattern), no reductions kept
-template <int NM, int PF, bool DO_YZ, bool DO_XZ, bool DO_XY, int WAVES>
+template <int NM, int PF, bool DO_YZ, bool DO_XZ, bool DO_XY, int WAVES, bool DPP = false>
 __global__ __launch_bounds__(WAVES * 64) void k_frame(const float4* __restrict__ V, float* out, float* outxy) {
     extern __shared__ float lds[];
     float* xz_lds = lds; float* xy_lds = lds + X * Z;
@@ -71,12 +85,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_frame(const float4* __restrict__
                 p = max4(p, c);
                 if (DO_XY) {
                     float r = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w));
+                    if (DPP) {
+                        r = rowmax32_dpp(r);
+                        if (kq == 31) xy_lds[i * Y + slot + NSLOT * m] = r;
+                    } else {
 #pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-                    if (kq == 0) xy_lds[i * Y + slot + NSLOT * m] = r;
+                        for (int off = 16; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
+                        if (kq == 0) xy_lds[i * Y + slot + NSLOT * m] = r;
+                    }
                 }
             }
-            if (DO_XZ) {
+            if (DO_XZ && DPP) {
+                // v_permlane32_swap: upper half of a <-> lower half of b; one swap + one max combines two components
+                auto sw = [](float a, float b) {
+                    auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+                };
+                float xy_ = sw(p.x, p.y);     // lanes 0-31: x combined, lanes 32-63: y combined
+                float zw_ = sw(p.z, p.w);     // lanes 0-31: z combined, lanes 32-63: w combined
+                float* d = xz_lds + i * Z + 4 * kq + (lane >> 5);
+                __hip_atomic_fetch_max(d + 0, xy_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(d + 2, zw_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (DO_XZ) {
                 float4 q;
                 q.x = __shfl_xor(p.x, 32); q.y = __shfl_xor(p.y, 32); q.z = __shfl_xor(p.z, 32); q.w = __shfl_xor(p.w, 32);
                 p = max4(p, q);
@@ -119,16 +149,18 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)B * X * Y * Z;
     float* V; CK(hipMalloc(&V, n * 4));
     CK(hipMemset(V, 0, n * 4));
+    { std::vector<float> h(1 << 22); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 24) & 255) * ((i % 61) == 0);
+      for (size_t o = 0; o < n; o += h.size()) CK(hipMemcpy(V + o, h.data(), std::min(h.size(), n - o) * 4, hipMemcpyHostToDevice)); }
     float* out; CK(hipMalloc(&out, (size_t)B * 20480 * 4));
     const double gb = n * 4 / 1e9;
     const size_t lds = (X * Z + X * Y) * 4;
 #define RUN_STREAM(U, G) { float ms = bench([&] { hipLaunchKernelGGL((k_stream<U>), dim3(G), dim3(256), 0, 0, (const float4*)V, n / 4, out); }); \
         printf("stream unroll=%d grid=%d : %.3f ms %.1f GB/s\n", U, G, ms, gb / ms * 1e3); }
     RUN_STREAM(4, 2048) RUN_STREAM(8, 2048) RUN_STREAM(8, 4096) RUN_STREAM(16, 2048) RUN_STREAM(8, 8192) RUN_STREAM(4, 16384)
-#define RUN_FRAME(NM, PF, YZ, XZ, XY, W) { \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<NM, PF, YZ, XZ, XY, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
-        float ms = bench([&] { hipLaunchKernelGGL((k_frame<NM, PF, YZ, XZ, XY, W>), dim3(B), dim3(W * 64), lds, 0, (const float4*)V, out, out); }); \
-        printf("frame NM=%d PF=%d yz=%d xz=%d xy=%d waves=%d : %.3f ms %.1f GB/s (read only)\n", NM, PF, YZ, XZ, XY, W, ms, gb / ms * 1e3); }
+#define RUN_FRAME(NM, PF, YZ, XZ, XY, W, ...) { \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame<NM, PF, YZ, XZ, XY, W, ##__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+        float ms = bench([&] { hipLaunchKernelGGL((k_frame<NM, PF, YZ, XZ, XY, W, ##__VA_ARGS__>), dim3(B), dim3(W * 64), lds, 0, (const float4*)V, out, out); }); \
+        printf("frame NM=%d PF=%d yz=%d xz=%d xy=%d waves=%d %s: %.3f ms %.1f GB/s (read only)\n", NM, PF, YZ, XZ, XY, W, #__VA_ARGS__, ms, gb / ms * 1e3); }
     RUN_FRAME(8, 2, false, false, false, 4)
     RUN_FRAME(8, 2, true, false, false, 4)
     RUN_FRAME(8, 2, true, true, false, 4)
@@ -140,5 +172,11 @@ int main(int argc, char** argv) {
     RUN_FRAME(4, 4, true, true, true, 8)
     RUN_FRAME(4, 2, false, false, false, 8)
     RUN_FRAME(2, 4, true, true, true, 16)
+    RUN_FRAME(8, 1, true, false, true, 4, true)
+    RUN_FRAME(8, 1, true, true, false, 4, true)
+    RUN_FRAME(8, 1, true, true, true, 4, true)
+    RUN_FRAME(8, 2, true, true, true, 4, true)
+    RUN_FRAME(4, 2, true, true, true, 8, true)
+    RUN_FRAME(4, 1, true, true, true, 8, true)
     return 0;
 }
