@@ -1,0 +1,98 @@
+"""Multi-view CNN classifier of the reference's ``dnn.py`` (forward pass) on PyTorch-ROCm.
+
+Architecture (dnn.py:45-91; shapes in images/dnn_model.png): per projection branch
+Conv2D(64, 3x3, stride 2, 'same', relu) -> Conv2D(32, 3x3, stride 2, 'same', relu); concatenate the three
+branches on the channel axis (order xz, yz, xy); Flatten (NHWC order, 20*20*96 = 38 400); Dense 64 relu;
+Dropout 0.5; Dense 64 relu; Dropout 0.5; Dense n_classes softmax.  Keras semantics kept: TF 'same' padding
+(bottom/right on even sizes), NHWC flatten order, Glorot-uniform kernels / zero biases (Keras defaults).
+BASELINE config 4 runs the forward in bf16 (autocast); the dense and conv layers go to MIOpen / hipBLASLt
+through PyTorch, which the north star allows for these layers.
+"""
+import numpy as np
+
+from .nn_common import make_same_conv, to_nchw, flatten_nhwc
+
+RESCALE = (80, 80)          # dnn.py:33
+
+
+def define_classifier(xz_shape=(80, 80, 1), yz_shape=(80, 80, 1), xy_shape=(80, 80, 1), n_classes=3,
+                      device=None, dtype=None):
+    """Same signature/ordering as dnn.define_classifier (dnn.py:55): input order xz, yz, xy.
+    Returns a ``Classifier`` with Keras-like ``predict``."""
+    import torch
+    m = Classifier([xz_shape, yz_shape, xy_shape], n_classes)
+    dev = torch.device(device) if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    return m.to(dev).to(memory_format=torch.channels_last)
+
+
+def _module_base():
+    import torch.nn as nn
+    return nn.Module
+
+
+class Classifier(_module_base()):
+    def __init__(self, shapes, n_classes):
+        import torch
+        import torch.nn as nn
+        super().__init__()
+        self.shapes = [tuple(s) for s in shapes]
+        self.n_classes = n_classes
+        self.branches = nn.ModuleList()
+        feat = 0
+        for (h, w, c) in self.shapes:
+            self.branches.append(nn.ModuleList([make_same_conv(c, 64, 3, 2), make_same_conv(64, 32, 3, 2)]))
+            feat += (-(-(-(-h // 2)) // 2)) * (-(-(-(-w // 2)) // 2)) * 32
+        self.flat_features = feat
+        self.fc1 = nn.Linear(feat, 64)
+        self.fc2 = nn.Linear(64, 64)
+        self.fc3 = nn.Linear(64, n_classes)
+        self.drop = nn.Dropout(0.5)
+        # Keras defaults: glorot_uniform kernels, zero biases
+        for mod in self.modules():
+            if isinstance(mod, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_uniform_(mod.weight)
+                nn.init.zeros_(mod.bias)
+
+    def features(self, xz, yz, xy):
+        import torch
+        import torch.nn.functional as F
+        outs = []
+        for x, br in zip((xz, yz, xy), self.branches):
+            x = F.relu(br[0](x))
+            x = F.relu(br[1](x))
+            outs.append(x)
+        # all three branches share the spatial size after RESCALE; concat on channels like Keras' last axis
+        return flatten_nhwc(torch.cat(outs, dim=1))
+
+    def logits(self, xz, yz, xy):
+        import torch.nn.functional as F
+        fv = self.features(xz, yz, xy)
+        h = self.drop(F.relu(self.fc1(fv)))
+        h = self.drop(F.relu(self.fc2(h)))
+        return self.fc3(h)
+
+    def forward(self, xz, yz, xy):
+        import torch
+        return torch.softmax(self.logits(xz, yz, xy).float(), dim=-1)
+
+    def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
+        """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""
+        import torch
+        dev = next(self.parameters()).device
+        dt = getattr(torch, autocast_dtype) if autocast_dtype else None
+        was = self.training
+        self.eval()
+        outs = []
+        n = len(inputs[0])
+        with torch.no_grad():
+            for s in range(0, n, batch_size):
+                xs = [to_nchw(a[s:s + batch_size], dev) for a in inputs]
+                if dt is not None and dev.type == "cuda":
+                    with torch.autocast("cuda", dtype=dt):
+                        p = self(*xs)
+                else:
+                    p = self(*xs)
+                outs.append(p.float().cpu())
+        self.train(was)
+        return torch.cat(outs).numpy() if outs else np.zeros((0, self.n_classes), np.float32)

@@ -1,0 +1,167 @@
+"""Semi-supervised GAN discriminator / classifier of the reference's ``sgan.py`` (train step) on PyTorch-ROCm.
+
+Architecture (sgan.py:132-217; images/sgan_d_model.png, sgan_c_model.png): per projection branch
+3 x [Conv2D(128 / 64 / 32, 3x3, stride 2, 'same') + BatchNorm + LeakyReLU(0.2)] (128 -> 16); concatenate;
+Flatten (NHWC, 16*16*96 = 24 576); 2 x [Dense 64 + BatchNorm + LeakyReLU(0.2) + Dropout 0.5]; Dense n_classes.
+Two heads on the shared trunk: supervised ``c`` = softmax + sparse categorical cross-entropy; unsupervised
+``d`` = custom_activation sum(exp)/(sum(exp)+1) (sgan.py:125-129) + binary cross-entropy.  Each head has its own
+Adam(lr 2e-4, beta1 0.5) (sgan.py:206-207,214-215).  Keras semantics kept: TF 'same' padding, NHWC flatten,
+RandomNormal(0, 0.02) kernels, zero biases, BatchNorm(momentum 0.99, eps 1e-3) = torch momentum 0.01,
+Adam eps 1e-7.  BASELINE config 5: fp16 autocast + loss scaling, data parallel over the GPUs of a node with
+DistributedDataParallel (backend "nccl" = RCCL all-reduce of ~1.86 M gradient elements per step);
+BatchNorm statistics stay per replica (what Keras does per replica).
+Only the discriminator/classifier train step is in scope; the generator is not.
+"""
+import numpy as np
+
+from .nn_common import make_same_conv, to_nchw, flatten_nhwc
+
+RESCALE = (128, 128)        # sgan.py:39
+
+
+def _nn():
+    import torch.nn as nn
+    return nn
+
+
+class Discriminator(_nn().Module):
+    def __init__(self, shapes=((128, 128, 1),) * 3, n_classes=3):
+        nn = _nn()
+        super().__init__()
+        self.shapes = [tuple(s) for s in shapes]
+        self.n_classes = n_classes
+        self.branches = nn.ModuleList()
+        feat = 0
+        for (h, w, c) in self.shapes:
+            layers, ch = [], c
+            for out in (128, 64, 32):
+                layers += [make_same_conv(ch, out, 3, 2), nn.BatchNorm2d(out, eps=1e-3, momentum=0.01), nn.LeakyReLU(0.2)]
+                ch = out
+                h, w = -(-h // 2), -(-w // 2)
+            self.branches.append(nn.Sequential(*layers))
+            feat += h * w * 32
+        self.flat_features = feat
+        self.fc1 = nn.Linear(feat, 64); self.bn1 = nn.BatchNorm1d(64, eps=1e-3, momentum=0.01)
+        self.fc2 = nn.Linear(64, 64); self.bn2 = nn.BatchNorm1d(64, eps=1e-3, momentum=0.01)
+        self.fc3 = nn.Linear(64, n_classes)
+        self.act = nn.LeakyReLU(0.2)
+        self.drop = nn.Dropout(0.5)
+        for mod in self.modules():
+            if isinstance(mod, (nn.Conv2d, nn.Linear)):
+                nn.init.normal_(mod.weight, 0.0, 0.02)      # RandomNormal(stddev=0.02), sgan.py:176
+                nn.init.zeros_(mod.bias)
+
+    def forward(self, xz, yz, xy):
+        """Pre-activation class scores (N, n_classes) -- the shared ``cls`` tensor of sgan.py:199."""
+        import torch
+        outs = [br(x) for x, br in zip((xz, yz, xy), self.branches)]
+        fv = flatten_nhwc(torch.cat(outs, dim=1))
+        h = self.drop(self.act(self.bn1(self.fc1(fv))))
+        h = self.drop(self.act(self.bn2(self.fc2(h))))
+        return self.fc3(h)
+
+
+def custom_activation(logits):
+    """sgan.py:125-129: sum(exp)/(sum(exp)+1) = sigmoid(logsumexp(logits))."""
+    import torch
+    return torch.sigmoid(torch.logsumexp(logits.float(), dim=-1, keepdim=True))
+
+
+def c_loss(logits, y):
+    """sparse_categorical_crossentropy on the softmax head (sgan.py:205)."""
+    import torch.nn.functional as F
+    return F.cross_entropy(logits.float(), y)
+
+
+def d_loss(logits, y, sample_weight=None):
+    """binary_crossentropy on the custom-activation head (sgan.py:213), evaluated on the logit
+    lse = logsumexp(logits): -y log D - (1-y) log(1-D) = softplus(lse) - y*lse.  Labels may be smoothed
+    floats outside [0,1] (sgan.py:396-403)."""
+    import torch
+    import torch.nn.functional as F
+    lse = torch.logsumexp(logits.float(), dim=-1)
+    loss = F.softplus(lse) - y.float().reshape(-1) * lse
+    if sample_weight is not None:
+        loss = loss * sample_weight.float().reshape(-1)
+    return loss.mean()
+
+
+class DiscriminatorTrainer:
+    """c_model / d_model ``train_on_batch`` (sgan.py:525-532) with the reference's optimizers, fp16 autocast and,
+    when torch.distributed is initialised, DistributedDataParallel gradient all-reduce."""
+
+    def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None):
+        import torch
+        import torch.distributed as dist
+        self.model = model
+        self.device = next(model.parameters()).device
+        self.net = model
+        use_ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 if ddp is None else ddp
+        if use_ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            self.net = DDP(model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
+                           gradient_as_bucket_view=True)
+        self.opt_c = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7)
+        self.opt_d = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7)
+        self.amp_dtype = getattr(torch, amp_dtype) if (amp_dtype and self.device.type == "cuda") else None
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
+
+    def _inputs(self, x):
+        return [to_nchw(a, self.device) for a in x]
+
+    def _step(self, opt, loss_fn, x):
+        import torch
+        self.net.train()
+        opt.zero_grad(set_to_none=True)
+        xs = self._inputs(x)
+        if self.amp_dtype is not None:
+            with torch.autocast("cuda", dtype=self.amp_dtype):
+                logits = self.net(*xs)
+        else:
+            logits = self.net(*xs)
+        loss = loss_fn(logits)
+        self.scaler.scale(loss).backward()
+        self.scaler.step(opt)
+        self.scaler.update()
+        return loss.detach(), logits.detach()
+
+    def train_on_batch_c(self, x, y):
+        """c_model.train_on_batch([xz,yz,xy], y) -> (loss, accuracy)."""
+        import torch
+        yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).long().reshape(-1)
+        loss, logits = self._step(self.opt_c, lambda lg: c_loss(lg, yt), x)
+        acc = (logits.argmax(dim=-1) == yt).float().mean()
+        return float(loss), float(acc)
+
+    def train_on_batch_d(self, x, y, sample_weight=None):
+        """d_model.train_on_batch([xz,yz,xy], y[, weights]) -> loss."""
+        import torch
+        yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).float()
+        sw = None if sample_weight is None else torch.as_tensor(np.asarray(sample_weight)).to(self.device)
+        loss, _ = self._step(self.opt_d, lambda lg: d_loss(lg, yt, sw), x)
+        return float(loss)
+
+    def predict(self, x, batch_size=4096):
+        """c_model.predict: softmax class probabilities, float32 numpy."""
+        import torch
+        self.model.eval()
+        outs = []
+        with torch.no_grad():
+            for s in range(0, len(x[0]), batch_size):
+                xs = self._inputs([a[s:s + batch_size] for a in x])
+                if self.amp_dtype is not None:
+                    with torch.autocast("cuda", dtype=self.amp_dtype):
+                        lg = self.model(*xs)
+                else:
+                    lg = self.model(*xs)
+                outs.append(torch.softmax(lg.float(), dim=-1).cpu())
+        return torch.cat(outs).numpy()
+
+
+def define_discriminator(xz_shape=(128, 128, 1), yz_shape=(128, 128, 1), xy_shape=(128, 128, 1), n_classes=3, device=None):
+    """Counterpart of sgan.define_discriminator (sgan.py:160): one shared trunk; the d / c heads are the two
+    losses of :class:`DiscriminatorTrainer`."""
+    import torch
+    dev = torch.device(device) if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    return Discriminator([xz_shape, yz_shape, xy_shape], n_classes).to(dev).to(memory_format=torch.channels_last)

@@ -1,0 +1,118 @@
+"""dnn.py / sgan.py PyTorch modules: architecture, Keras semantics and losses on CPU (fp32)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def mods(rml):
+    return importlib.import_module("radar_ml_amd.dnn"), importlib.import_module("radar_ml_amd.sgan"), \
+        importlib.import_module("radar_ml_amd.nn_common")
+
+
+def test_dnn_architecture_matches_reference(mods):
+    dnn, _, _ = mods
+    m = dnn.define_classifier(device="cpu")
+    # 3 x (640 + 18 464) + 2 457 664 + 4 160 + 195 (images/dnn_model.png)
+    assert sum(p.numel() for p in m.parameters()) == 2519331
+    assert m.flat_features == 20 * 20 * 96 == 38400
+    x = [np.random.default_rng(i).uniform(-1, 1, (5, 80, 80, 1)).astype(np.float32) for i in range(3)]
+    p = m.predict(x, autocast_dtype=None)
+    assert p.shape == (5, 3) and p.dtype == np.float32
+    np.testing.assert_allclose(p.sum(1), 1.0, atol=1e-6)
+    assert m.predict([a[:0] for a in x]).shape == (0, 3)
+    # dropout inactive at inference: deterministic
+    np.testing.assert_array_equal(p, m.predict(x, autocast_dtype=None))
+
+
+def test_tf_same_padding_and_flatten_order(mods):
+    _, _, nc = mods
+    assert nc.tf_same_pad(80, 3, 2) == (0, 1) and nc.tf_same_pad(40, 3, 2) == (0, 1)      # bottom/right only
+    assert nc.tf_same_pad(81, 3, 2) == (1, 1) and nc.tf_same_pad(128, 3, 2) == (0, 1)
+    conv = nc.make_same_conv(1, 2, 3, 2)
+    x = torch.arange(36, dtype=torch.float32).reshape(1, 1, 6, 6)
+    y = conv(x)
+    assert y.shape == (1, 2, 3, 3)
+    # TF semantics: output (r,c) covers input rows 2r..2r+2 with zero beyond the bottom/right edge
+    w, b = conv.conv.weight.detach(), conv.conv.bias.detach()
+    xp = torch.zeros(1, 1, 7, 7); xp[..., :6, :6] = x
+    want = torch.stack([(xp[0, 0, 2 * r:2 * r + 3, 2 * c:2 * c + 3] * w[0, 0]).sum() + b[0] for r in range(3) for c in range(3)])
+    np.testing.assert_allclose(y[0, 0].reshape(-1).detach().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    t = torch.arange(2 * 3 * 4 * 5).reshape(2, 3, 4, 5)       # (N,C,H,W)
+    f = nc.flatten_nhwc(t)
+    assert f[0, 0] == t[0, 0, 0, 0] and f[0, 1] == t[0, 1, 0, 0] and f[0, 3] == t[0, 0, 0, 1]   # (h, w, c) order
+
+
+def test_sgan_discriminator_architecture_and_losses(mods):
+    _, sgan, _ = mods
+    d = sgan.define_discriminator(device="cpu")
+    assert abs(sum(p.numel() for p in d.parameters()) - 1.86e6) < 5e3 and d.flat_features == 16 * 16 * 96
+    lg = torch.randn(7, 3)
+    D = sgan.custom_activation(lg)
+    Z = torch.exp(lg).sum(-1, keepdim=True)
+    np.testing.assert_allclose(D.numpy(), (Z / (Z + 1)).numpy(), rtol=1e-6)                 # sgan.py:125-129
+    y = torch.tensor([0.9, 1.1, 0.7, 0.0, 0.2, 1.0, 0.3])
+    bce = -(y * torch.log(D[:, 0]) + (1 - y) * torch.log(1 - D[:, 0])).mean()
+    np.testing.assert_allclose(float(sgan.d_loss(lg, y)), float(bce), rtol=1e-5)
+    yc = torch.tensor([0, 1, 2, 1, 0, 2, 1])
+    np.testing.assert_allclose(float(sgan.c_loss(lg, yc)), float(-torch.log_softmax(lg, -1)[torch.arange(7), yc].mean()), rtol=1e-6)
+
+
+def test_sgan_train_steps_reduce_loss(mods):
+    _, sgan, _ = mods
+    torch.manual_seed(0)
+    d = sgan.Discriminator(((32, 32, 1),) * 3, 3)
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None, ddp=False)
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 3, 48)
+    x = [((rng.uniform(-1, 1, (48, 32, 32, 1)) * 0.1) + (y[:, None, None, None] - 1) * 0.5).astype(np.float32) for _ in range(3)]
+    l0, _ = tr.train_on_batch_c(x, y)
+    for _ in range(30):
+        l, acc = tr.train_on_batch_c(x, y)
+    assert l < l0 * 0.8 and acc > 0.6
+    d0 = tr.train_on_batch_d(x, np.full((48, 1), 0.9))
+    for _ in range(20):
+        dl = tr.train_on_batch_d(x, np.full((48, 1), 0.9))
+    assert dl < d0
+    p = tr.predict(x)
+    assert p.shape == (48, 3) and abs(p.sum(1) - 1).max() < 1e-5
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import radar_ml_amd  # noqa
+    sgan = importlib.import_module("radar_ml_amd.sgan")
+    torch.manual_seed(0)
+    d = sgan.Discriminator(((16, 16, 1),) * 3, 3)
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None)          # picks up DDP from the process group
+    rng = np.random.default_rng(100 + rank)                    # each rank its own shard of the batch
+    x = [rng.uniform(-1, 1, (8, 16, 16, 1)).astype(np.float32) for _ in range(3)]
+    tr.train_on_batch_c(x, rng.integers(0, 3, 8))
+    tr.train_on_batch_d(x, np.full((8, 1), 0.9))
+    flat = torch.cat([p.detach().reshape(-1) for p in d.parameters()])
+    q.put((rank, flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sgan_ddp_gloo_two_ranks_keep_replicas_in_sync():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0], res[1])      # all-reduced gradients -> identical replicas
