@@ -180,7 +180,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("project_hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            if pj.get("grid") == [X, Y, Z] and pj.get("frames_per_launch") == frames_per_launch:
+                traffic = pj.get("project_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_project_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -9,7 +9,8 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libradarml_hip.so")
+# RML_LIB overrides the library path (A/B runs of kernel variants built with radar-ml_amd/build.py --variant)
+LIB_PATH = os.environ.get("RML_LIB") or os.path.join(HERE, "libradarml_hip.so")
 
 
 class RadarMLError(RuntimeError):

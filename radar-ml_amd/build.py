@@ -36,14 +36,22 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every csrc/*.hip for gfx950 into one shared library.  Returns its path."""
+def build(force=False, verbose=False, variant=None, defines=()):
+    """Compile every csrc/*.hip for gfx950 into one shared library.  Returns its path.
+    ``variant``/``defines`` build an experimental copy libradarml_hip_<variant>.so with extra -D flags."""
+    global LIB
+    if variant:
+        lib_out = os.path.join(HERE, "libradarml_hip_%s.so" % variant)
+        return _build(lib_out, os.path.join(HERE, "build", variant), verbose, ["-D" + d for d in defines])
     if not force and not is_stale():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    return _build(LIB, os.path.join(HERE, "build"), verbose, [])
+
+
+def _build(LIB, objdir, verbose, extra):
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra)
     objs = []
     procs = []
     for src in sources():
@@ -67,4 +75,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build(variant=sys.argv[i + 1], defines=sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

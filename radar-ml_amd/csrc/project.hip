@@ -164,6 +164,18 @@ struct Emitter {
     }
 };
 
+// streaming load: every volume byte is read exactly once, so it is marked non-temporal (keeps the
+// support-vector tiles of the concurrently running SVM GEMM resident in L2 / Infinity Cache)
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#ifdef RML_NO_NT
+    return *p;
+#else
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+
 // butterfly reduction over the LPR lanes of a row (all lanes end with the result)
 template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r) {
 #pragma unroll
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
         const float4* __restrict__ Vi = Vb + (int64_t)i * plane;
         float4 cur[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) cur[m] = Vi[roff[m]];
+        for (int m = 0; m < NM; ++m) cur[m] = ld_stream(Vi + roff[m]);
         if constexpr (!FULL && MODE == RML_MODE_SUM) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) cur[m] = rv[m] ? cur[m] : id4;

@@ -44,6 +44,7 @@
 #include "rml_internal.h"
 #include <math.h>
 #include <vector>
+#include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
 #include <new>
@@ -835,7 +836,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
     if (B == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
-    const int64_t CH = std::min<int64_t>(round_up(B, kTile), 4096);
+    static const int64_t kChunk = [] { const char* e = getenv("RML_CHUNK"); int64_t v = e ? atoll(e) : 0; return v >= 128 ? round_up(v, kTile) : (int64_t)8192; }();
+    const int64_t CH = std::min<int64_t>(round_up(B, kTile), kChunk);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);

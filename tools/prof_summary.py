@@ -66,7 +66,10 @@ def pmc(fetch_db, write_db):
     proj = [v for k, v in summary.items() if k.startswith("k_project_fast") and v["fetch_kb"] > 1e5]
     if proj:
         best = max(proj, key=lambda v: v["fetch_kb"])
-        json.dump({"project_hbm_bytes_per_launch": best["hbm_bytes_corrected"], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+        best_grid = [int(k.split("grid=")[1]) for k, v in summary.items() if v is best][0]
+        grid = [int(t) for t in os.environ.get("RML_PMC_GRID", "64x64x128").split("x")]
+        fpl = best_grid // 256
+        json.dump({"project_hbm_bytes_per_launch": best["hbm_bytes_corrected"], "grid": grid, "frames_per_launch": fpl, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                    "2x FETCH correction for gfx950", "kernels": summary}, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
 
 
