@@ -313,6 +313,15 @@ def ovr_decision_function(dec, n_classes):
     return votes + soc / (3 * (np.abs(soc) + 1))
 
 
+def sklearn_decision_function(dec, n_classes):
+    """What SVC.decision_function returns (sk:svm/_base.py:546-547,780-790): binary problems flip the sign of
+    the single libsvm pair value and return shape (N,); otherwise the 'ovr' transform."""
+    dec = np.asarray(dec, dtype=np.float64)
+    if n_classes == 2:
+        return -dec[:, 0]
+    return ovr_decision_function(dec, n_classes)
+
+
 def expit(x):
     """scipy.special.expit restated: 1/(1+exp(-x)), overflow-safe."""
     x = np.asarray(x, dtype=np.float64)
@@ -333,6 +342,11 @@ def calibrated_proba(T, calib_a, calib_b):
     T = np.asarray(T, dtype=np.float64)
     a = np.asarray(calib_a, dtype=np.float64)
     b = np.asarray(calib_b, dtype=np.float64)
+    if T.ndim == 1:      # binary: one calibrator for classes_[1]; proba[:,0] = 1 - proba[:,1] (calibration.py:760-767)
+        p1 = expit(-(a[0] * T + b[0]))
+        proba = np.stack([1.0 - p1, p1], axis=1)
+        proba[(1.0 < proba) & (proba <= 1.0 + 1e-5)] = 1.0
+        return proba
     n_classes = T.shape[1]
     proba = expit(-(a[None, :] * T + b[None, :]))
     den = proba.sum(axis=1)[:, None]

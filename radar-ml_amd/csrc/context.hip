@@ -2,6 +2,7 @@
 #include "rml_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <new>
 
 namespace {
@@ -63,7 +64,20 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
     RML_REQUIRE(c != nullptr, RML_ERR_NOMEM, "rml_ctx_create: out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    // CU masks on MI355X (measured, tools/exp/exp_cumask.hip): mask bit i selects local CU i/8 of XCD i%8; an XCD
+    // left without any CU makes the runtime ignore the mask for that XCD.
+    const char* env = getenv("RML_GEMM_CUS");
+    int g = env ? atoi(env) : 0;
+    hipError_t e = hipSuccess;
+    if (g > 0 && g < 32 && prop.multiProcessorCount == 256) {
+        uint32_t mg[8] = {0}, mp[8] = {0};
+        for (int bit = 0; bit < 256; ++bit) ((bit / 8) < g ? mg : mp)[bit / 32] |= 1u << (bit % 32);
+        e = hipExtStreamCreateWithCUMask(&c->aux_stream, 8, mg);
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->proj_stream, 8, mp);
+        c->gemm_cus_per_xcd = g;
+    } else {
+        e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -91,6 +105,7 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->proj_stream) (void)hipStreamDestroy(ctx->proj_stream);
     delete ctx;
     return RML_OK;
 }

@@ -15,6 +15,10 @@ struct rml_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
+    // optional CU partition (RML_GEMM_CUS=g): aux_stream is restricted to g CUs of every XCD and proj_stream to
+    // the remaining 32-g, so the MFMA-bound GEMM and the HBM-bound projection stop fighting for wave slots/LDS
+    hipStream_t proj_stream = nullptr;
+    int gemm_cus_per_xcd = 0;
     // optional in-situ timing of the projection launches issued by rml_project_svm
     bool profiling = false;
     std::vector<hipEvent_t> prof_ev;    // start/stop pairs

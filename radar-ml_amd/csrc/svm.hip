@@ -834,7 +834,9 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
     const bool grid_ok = m->exact && ((scaled && (double)scale_div == m->code_scale) || (!scaled && m->code_scale == 1.0));
     RML_HIP(hipSetDevice(ctx->device));
     if (B == 0) return RML_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    // with a CU partition the projections run on the context's masked stream, forked from the caller's
+    hipStream_t st = ctx->proj_stream ? ctx->proj_stream : caller;
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
     static const int64_t kChunk = [] { const char* e = getenv("RML_CHUNK"); int64_t v = e ? atoll(e) : 0; return v >= 128 ? round_up(v, kTile) : (int64_t)8192; }();
     const int64_t CH = std::min<int64_t>(round_up(B, kTile), kChunk);
@@ -849,9 +851,10 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
     hipStream_t aux = ctx->aux_stream;
     hipEvent_t* ev_proj = ctx->ev_proj;
     hipEvent_t* ev_done = ctx->ev_done;
-    // aux must start after everything already queued on st
-    RML_HIP(hipEventRecord(ctx->ev_fork, st));
+    // aux (and the masked projection stream) must start after everything already queued by the caller
+    RML_HIP(hipEventRecord(ctx->ev_fork, caller));
     RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    if (st != caller) RML_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
     int64_t c = 0;
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
         const int64_t n = std::min(CH, B - r0);
@@ -905,7 +908,11 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
     }
     // join: the caller's stream continues after the last GEMMs
     RML_HIP(hipEventRecord(ctx->ev_join, aux));
-    RML_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    RML_HIP(hipStreamWaitEvent(caller, ctx->ev_join, 0));
+    if (st != caller) {
+        RML_HIP(hipEventRecord(ctx->ev_fork, st));
+        RML_HIP(hipStreamWaitEvent(caller, ctx->ev_fork, 0));
+    }
     return RML_OK;
 }
 

@@ -136,12 +136,14 @@ def svc_arrays(clf, cal):
     )
 
 
-def golden_svm(common, name, X, Y, Z, ntrain, nval, ntest, gamma, mask=(True, True, True), kernel="rbf"):
+def golden_svm(common, name, X, Y, Z, ntrain, nval, ntest, gamma, mask=(True, True, True), kernel="rbf", binary=False):
     """Fit the reference's model object (train.py:478-482,723-724 hyper-parameters from
     train-results/train_svc.log:24-31: C=10, gamma=0.01, rbf, class_weight balanced) on
     synthetic max-projection features and record sklearn's outputs."""
     n = ntrain + nval + ntest
     vol, cls = synth(SEED + 10 + X, n, X, Y, Z)
+    if binary:      # the reference's optional 'pet' aliasing (dnn.py:36-38 CLASS_ALIAS): person vs pet
+        cls = np.minimum(cls, 1).astype(np.int32)
     xz = vol.max(axis=2); yz = vol.max(axis=1); xy = vol.max(axis=3)
     samples = [(a, b, c) for a, b, c in zip(xz, yz, xy)]
     F = common.process_samples(samples, proj_mask=common.ProjMask(*mask), scale=True)
@@ -268,6 +270,7 @@ if __name__ == "__main__":
     golden_svm(common, "svm_small_linear.npz", 8, 10, 16, 400, 100, 128, gamma=0.05, kernel="linear")
     golden_svm(common, "svm_small_xy.npz", 8, 10, 16, 400, 100, 128, gamma=0.05, mask=(False, False, True))
     golden_svm(common, "svm_walabot.npz", 22, 31, 176, 420, 100, 128, gamma=0.01)
+    golden_svm(common, "svm_small_binary.npz", 8, 10, 16, 400, 100, 128, gamma=0.05, binary=True)
     golden_real_xy()
     golden_linear(common)
     golden_classifier_threshold(predict)

@@ -7,13 +7,16 @@ import oracle_np as O
 from conftest import load_golden, svm_model_arrays
 
 
-@pytest.mark.parametrize("name", ["svm_small.npz", "svm_small_linear.npz", "svm_small_xy.npz", "svm_walabot.npz"])
+@pytest.mark.parametrize("name", ["svm_small.npz", "svm_small_linear.npz", "svm_small_xy.npz", "svm_walabot.npz",
+                                  "svm_small_binary.npz"])
 def test_c_oracle_svm_matches_sklearn_golden(name):
     g = load_golden(name)
     m = svm_model_arrays(g)
     X = g["test_feat_u8"].astype(np.float32) / np.float32(255.0)
     out = OC.svm(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"],
                  m["calib_a"], m["calib_b"], threads=2)
+    if len(m["classes"]) == 2:
+        out["dec_ovo"] = -out["dec_ovo"][:, 0]          # sklearn's binary sign flip
     np.testing.assert_allclose(out["dec_ovo"], g["dec_ovo"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(out["dec_ovr"], g["dec_ovr"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(out["proba"], g["proba"], rtol=0, atol=1e-10)

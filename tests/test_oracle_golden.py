@@ -67,7 +67,7 @@ def test_process_samples_nonunit_zoom_matches_reference():
 
 
 @pytest.mark.parametrize("name", ["svm_small.npz", "svm_small_linear.npz", "svm_small_xy.npz", "svm_walabot.npz",
-                                  "real_xy_svm.npz"])
+                                  "real_xy_svm.npz", "svm_small_binary.npz"])
 def test_svm_oracle_matches_sklearn(name):
     g = load_golden(name)
     m = svm_model_arrays(g)
@@ -79,6 +79,15 @@ def test_svm_oracle_matches_sklearn(name):
     C = len(m["classes"])
     dec = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
     # float64 round-off only (BLAS dot ordering inside libsvm vs NumPy's)
+    if C == 2:       # sklearn flips the sign of the single pair value for binary problems
+        np.testing.assert_allclose(-dec[:, 0], g["dec_ovo"], rtol=0, atol=1e-10)
+        T = O.sklearn_decision_function(dec, C)
+        np.testing.assert_allclose(T, g["dec_ovr"], rtol=0, atol=1e-10)
+        np.testing.assert_array_equal(m["classes"][O.svm_vote_labels(dec, C)], g["label_vote"])
+        proba = O.calibrated_proba(T, m["calib_a"], m["calib_b"])
+        np.testing.assert_allclose(proba, g["proba"], rtol=0, atol=1e-10)
+        np.testing.assert_array_equal(m["classes"][O.calibrated_labels(proba)], g["label_calib"])
+        return
     np.testing.assert_allclose(dec, g["dec_ovo"], rtol=0, atol=1e-10)
     # W-matrix form (what the GPU epilogue uses) is the same sum
     W = O.ovo_weight_matrix(m["dual_coef"], m["n_support"])

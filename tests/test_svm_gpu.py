@@ -66,6 +66,22 @@ def test_golden_parity_with_sklearn(rml, name, path):
         assert np.abs(ovo - g["dec_ovo"]).max() <= 2e-6
 
 
+@pytest.mark.parametrize("path", ["auto", "i8", "f64"])
+def test_binary_model(rml, path):
+    """2-class problem (the reference's optional person/pet aliasing): sklearn flips the sign of the single
+    libsvm pair value and uses one calibrator."""
+    g = load_golden("svm_small_binary.npz")
+    svc, m = _model(rml, g, path=path)
+    X = _test_rows(g, "svm_small_binary.npz")
+    dec = svc.decision_function(X)
+    assert dec.shape == g["dec_ovr"].shape == (len(X),)
+    assert np.abs(dec - g["dec_ovr"]).max() <= TOL
+    np.testing.assert_array_equal(svc.predict(X), g["label_vote"])
+    cal = rml.GpuCalibratedClassifier(svc)
+    assert np.abs(cal.predict_proba(X) - g["proba"]).max() <= TOL
+    np.testing.assert_array_equal(cal.predict(X), g["label_calib"])
+
+
 def test_general_float_rows_vs_oracle(rml):
     """Non-integer features (e.g. augmented / zoomed data): auto -> f64 MFMA path vs the float64 oracle."""
     g = load_golden("svm_small.npz")
