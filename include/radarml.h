@@ -132,6 +132,15 @@ int rml_assemble_features(rml_ctx* ctx, const float* xz, const float* yz, const 
                           int64_t B, int X, int Y, int Z, float scale_div, uint32_t mask,
                           float* feat, int64_t ld_feat, void* stream);
 
+/* common.process_samples with NON-UNIT zoom (common.py:141-148 when proj_zoom != 1; predict.py:34-54,109-116):
+ * scipy.ndimage.zoom(p, zoom) with SciPy's defaults (order-3 spline, mode 'constant', prefilter) on every
+ * selected plane, then ravel + concatenate + optional "/ RADAR_MAX".  out_shape (HOST, 6 ints: xz, yz, xy as
+ * (rows, cols)) is round(in * zoom) evaluated by the caller with Python's round().  Planes as in
+ * rml_assemble_features; feat rows have D = sum of the selected output planes. */
+int rml_zoom_features(rml_ctx* ctx, const float* xz, const float* yz, const float* xy,
+                      int64_t B, int X, int Y, int Z, const int32_t* out_shape,
+                      float scale_div, uint32_t mask, float* feat, int64_t ld_feat, void* stream);
+
 /* Quantise float32 feature rows to uint8 codes + row stats, for callers that bring (N,D)
  * features instead of volumes.  A value v is on the code grid iff it is bit-identical to
  * float32(c / scale_div) for an integer c in [0,255] (scale_div = 255: the "p / 255." of

@@ -41,6 +41,8 @@ SIGNATURES = {
     "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rml_assemble_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                       c_uint32, c_void_p, c_int64, c_void_p]),
+    "rml_zoom_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_float,
+                                  c_uint32, c_void_p, c_int64, c_void_p]),
     "rml_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_svm_load": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,

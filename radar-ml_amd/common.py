@@ -199,15 +199,12 @@ def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
 
     Zoom 1.0 (the value calc_proj_zoom produces whenever the predict arena equals the train
     arena, predict.log:21) is handled as the identity: SciPy's order-3 spline round trip at
-    zoom 1 differs from it by <= 1.3e-13 absolute on 0..255 data.  Non-unit
-    zoom (order-3 spline resampling) is the next row of SURVEY.md §8(f) and raises here.
+    zoom 1 differs from it by <= 1.3e-13 absolute on 0..255 data.  Any other
+    zoom runs SciPy's algorithm (order-3 spline, mode 'constant', prefilter) in ``k_zoom``.
     """
     torch = _torch()
     lib = _lib.load()
-    for i in range(3):
-        if proj_mask[i] and any(abs(float(z) - 1.0) > 1e-12 for z in proj_zoom[i]):
-            raise NotImplementedError(
-                "proj_zoom != 1.0 (spline resampling) is not implemented on the HIP path yet")
+    unit = all((not proj_mask[i]) or all(abs(float(z) - 1.0) <= 1e-12 for z in np.ravel(proj_zoom[i])) for i in range(3))
     samples = list(samples)
     n = len(samples)
     if n == 0:
@@ -239,6 +236,21 @@ def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     ctx = _lib.context(dev)
     dplanes = [None if p is None else torch.from_numpy(p).to(dev) for p in planes]
+    if not unit:
+        import ctypes as C
+        # output shapes exactly as scipy.ndimage.zoom computes them: int(round(size * zoom)), Python round()
+        oshape = []
+        for i in range(3):
+            zf = list(np.ravel(proj_zoom[i]).astype(float)) if np.ndim(proj_zoom[i]) else [float(proj_zoom[i])] * 2
+            oshape += [int(round(expect[i][0] * zf[0])), int(round(expect[i][1] * zf[1]))]
+        D = sum(oshape[2 * i] * oshape[2 * i + 1] for i in range(3) if proj_mask[i])
+        feat = torch.empty((n, D), dtype=torch.float32, device=dev)
+        arr = (C.c_int32 * 6)(*oshape)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_zoom_features(ctx, _lib.ptr(dplanes[0]), _lib.ptr(dplanes[1]), _lib.ptr(dplanes[2]), n, X, Y, Z,
+                                             C.cast(arr, C.c_void_p), float(RADAR_MAX) if scale else 0.0, bits,
+                                             _lib.ptr(feat), D, _lib.stream_ptr(dev)), "rml_zoom_features")
+        return feat.cpu().numpy()
     feat = torch.empty((n, D), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.rml_assemble_features(ctx, _lib.ptr(dplanes[0]), _lib.ptr(dplanes[1]), _lib.ptr(dplanes[2]), n, X, Y, Z,

@@ -114,10 +114,29 @@ def test_calc_proj_zoom_and_classifier(rml):
 
 def test_process_samples_argument_errors(rml):
     a = np.zeros((2, 4), np.float32); b = np.zeros((3, 4), np.float32); c = np.zeros((2, 3), np.float32)
-    with pytest.raises(NotImplementedError):
-        rml.process_samples([(a, b, c)], proj_zoom=rml.ProjZoom([0.9, 1.0], [1.0, 1.0], [1.0, 1.0]))
     with pytest.raises(ValueError):      # ragged, like np.array() in the reference
         rml.process_samples([(a, b, c), (np.zeros((2, 5), np.float32), b, c)])
     with pytest.raises(ValueError):
         rml.process_samples([(a, b, c)], proj_mask=rml.ProjMask(False, False, False))
     assert rml.process_samples([]).shape == (0,)
+
+
+def test_dataset_pickle_roundtrip(rml, tmp_path):
+    """datasets/README.md:8-20 format: write, append (ground_truth_samples.py:561-587), read, alias, filter."""
+    import importlib
+    ds = importlib.import_module("radar_ml_amd.datasets")
+    rng = np.random.default_rng(0)
+    xz = rng.integers(0, 255, (5, 22, 176)).astype(np.float32)
+    yz = rng.integers(0, 255, (5, 31, 176)).astype(np.float32)
+    xy = rng.integers(0, 255, (5, 22, 31)).astype(np.float32)
+    p = str(tmp_path / "radar_samples.pickle")
+    assert ds.save_dataset(p, xz[:3], yz[:3], xy[:3], ["person", "polly", "rebel"]) == 3
+    assert ds.save_dataset(p, xz[3:], yz[3:], xy[3:], ["dog", "person"]) == 5
+    import pickle
+    d = pickle.load(open(p, "rb"))
+    assert set(d) == {"samples", "labels"} and len(d["samples"]) == 5 and len(d["samples"][0]) == 3
+    a, b, c, labels = ds.load_dataset(p, label_alias={"polly": "dog", "rebel": "cat"})
+    np.testing.assert_array_equal(a, xz); np.testing.assert_array_equal(b, yz); np.testing.assert_array_equal(c, xy)
+    assert labels == ["person", "dog", "cat", "dog", "person"]
+    a, b, c, labels = ds.load_dataset([p, p], desired_labels={"person"})
+    assert a.shape == (4, 22, 176) and labels == ["person"] * 4

@@ -105,6 +105,27 @@ def test_process_samples_matches_reference_golden(rml):
     np.testing.assert_array_equal(got, rml.process_samples(samples))
 
 
+def test_process_samples_nonunit_zoom_matches_reference(rml):
+    """proj_zoom != 1 (predict arena != train arena, predict.py:34-54): SciPy's order-3 spline zoom on the GPU
+    against the rows the reference itself produced (common.process_samples through scipy.ndimage.zoom)."""
+    g = load_golden("common_golden.npz")
+    zf = g["zoom_factors"]
+    zoom = rml.ProjZoom(xz=list(zf[0]), yz=list(zf[1]), xy=list(zf[2]))
+    samples = list(zip(g["zoom_in_xz"], g["zoom_in_yz"], g["zoom_in_xy"]))
+    got = rml.process_samples(samples, proj_zoom=zoom, scale=True)
+    want = g["zoom_feat"]
+    assert got.shape == want.shape == (4, 10010) and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 2e-7            # float32 round-off of values in [0,1]
+    got_xy = rml.process_samples(samples, proj_mask=rml.ProjMask(False, False, True), proj_zoom=zoom, scale=False)
+    want_xy = O.process_samples(samples, proj_mask=O.ProjMask(False, False, True), proj_zoom=O.ProjZoom(*zoom), scale=False)
+    assert got_xy.shape == want_xy.shape and np.abs(got_xy - want_xy).max() <= 5e-5   # values up to 255
+    # down-zoom and a zoom of exactly 1 on one axis
+    z2 = rml.ProjZoom(xz=[0.9, 0.8], yz=[1.0, 0.8], xy=[0.9, 1.0])
+    got2 = rml.process_samples(samples, proj_zoom=z2)
+    want2 = O.process_samples(samples, proj_zoom=O.ProjZoom(*z2))
+    assert got2.shape == want2.shape and np.abs(got2 - want2).max() <= 5e-5
+
+
 def test_slice_pipeline_equals_reference_features(rml):
     """volumes -> derive (i,j,k) on the GPU -> slice -> features == the reference's golden rows."""
     g = load_golden("common_golden.npz")
@@ -169,3 +190,17 @@ def test_full_size_properties(rml):
     assert int(cls.min()) >= 0 and int(cls.max()) <= 2
     vv = v[:64].cpu().numpy()
     assert np.array_equal(vv, np.rint(vv)) and vv.min() >= 0 and vv.max() <= 255 and 0.001 < (vv > 0).mean() < 0.2
+
+
+def test_features_from_dataset_matches_process_samples(rml, tmp_path):
+    import importlib
+    ds = importlib.import_module("radar_ml_amd.datasets")
+    g = load_golden("common_golden.npz")
+    vol = g["volumes_u8"].astype(np.float32)
+    planes = [O.project_slice(v, *ijk) for v, ijk in zip(vol, g["slice_ijk"])]
+    xz = np.array([p[0] for p in planes]); yz = np.array([p[1] for p in planes]); xy = np.array([p[2] for p in planes])
+    p = str(tmp_path / "d.pickle")
+    ds.save_dataset(p, xz, yz, xy, ["person"] * len(xz))
+    a, b, c, labels = ds.load_dataset(p)
+    feat = ds.features_from_dataset(a, b, c, scale=True).cpu().numpy()
+    assert np.abs(feat.astype(np.float64) - g["feat_m0_s1"]).max() <= 1e-15      # the reference's own rows
