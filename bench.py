@@ -133,12 +133,12 @@ def main():
     V, cls = rml.synth_volumes(B, X, Y, Z, seed=a.seed, frame0=rank * a.frames, device=dev)
     lib = _lib.load()
     ctx = _lib.context(dev)
-    gathered = torch.empty((world * B,), dtype=torch.int32, device=dev) if world > 1 else None
+    from radar_ml_amd import dist as rdist
 
     def step():
         out = svc.decide_volumes(V, mode="max", scale=True, want_proba=True)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out["label_calib"])
+            out["all_labels"] = rdist.gather_labels(out["label_calib"])      # RCCL all-gather, 4 B/frame
         return out
 
     for _ in range(a.warmup):
@@ -213,7 +213,7 @@ def main():
 
     # ---- CPU baseline: the C port of the reference path on the host cores -------------------
     cpu = None
-    if not a.no_cpu:
+    if not a.no_cpu and world == 1:      # reported on rank 0 at N=1 only
         ncpu = a.cpu_frames
         if ncpu <= 0:
             # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~15 s

@@ -171,10 +171,13 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
     const int kgrp = lane >> 4;
 
+#ifndef RML_GEMM_ABL
+#define RML_GEMM_ABL 0      // experiment builds only (radar-ml_amd/build.py --variant): 2 = no staging, 3 = no MFMA, 1 = no exp
+#endif
     stage(0, 0);
     for (int kt = 0; kt < a.KT; ++kt) {
         __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
-        if (kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 2 * kTileBytes;
         const unsigned char* sB = sA + kTileBytes;
         if constexpr (PATH == PATH_F64) {
@@ -226,7 +229,11 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if constexpr (PATH == PATH_I8) {
+#if RML_GEMM_ABL == 3
+                            acc[i][j][0] += af[kk & 1][i][0] ^ bf[kk & 1][j][1];
+#else
                             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+#endif
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
@@ -347,7 +354,11 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
         if (rbf) {
             double d2 = xt + e[0] - 2.0 * g;
             d2 = d2 > 0.0 ? d2 : 0.0;
+#if RML_GEMM_ABL == 1
+            kv = d2;
+#else
             kv = exp(-a.gs * d2);
+#endif
         } else {
             kv = (PATH == PATH_I8) ? (g + xt + e[0]) * a.gs : g;
         }

@@ -217,3 +217,43 @@ def test_from_sklearn_roundtrip(rml):
     name, p = rml.classifier(Xt[0], gpu, LE())
     pr = cal.predict_proba(Xt[:1])[0]
     assert abs(p - pr.max()) <= TOL and name == (LE.classes_[pr.argmax()] if pr.max() >= 0.7 else "Unknown")
+
+
+def test_full_size_properties_64x64x128(rml):
+    """BASELINE configs[2] shape (64x64x128, D = 20 480, M ~ 2k SVs) at > 1 chunk: size-independent properties of
+    the fused path -- determinism, permutation equivariance, independence of the chunk boundaries -- plus a slab
+    against the float64 oracle."""
+    import torch
+    import oracle_c as OC
+    B, X, Y, Z = 8192 + 1500, 64, 64, 128
+    V, _ = rml.synth_volumes(B, X, Y, Z, seed=99)
+    feat, q, isum, isq, flags = rml.process_volumes(V[:2048], mode="max", scale=True, codes=True)
+    M = 2048
+    svq = (q[:M, :20480] ^ 0x80).cpu().numpy()
+    sv = (svq.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    rng = np.random.default_rng(3)
+    ns = np.array([700, 700, 648], dtype=np.int32)
+    dc = rng.uniform(-10, 10, (2, M)); ic = np.array([0.3, -0.1, 0.2])
+    ca = np.array([-2.0, -1.5, -2.5]); cb = np.array([0.1, 0.0, -0.2])
+    svc = rml.GpuSVC(sv, dc, ic, ns, 0.01, np.arange(3), calib_a=ca, calib_b=cb)
+    assert svc.exact
+    a = svc.decide_volumes(V)
+    b = svc.decide_volumes(V)
+    for k in a:
+        assert torch.equal(a[k], b[k])                                   # deterministic
+    perm = torch.randperm(B, device=V.device, generator=torch.Generator(device=V.device).manual_seed(0))
+    c = svc.decide_volumes(V[perm].contiguous())
+    for k in a:
+        assert torch.equal(c[k], a[k][perm])                             # frames are independent
+    d1 = svc.decide_volumes(V[:5000].contiguous()); d2 = svc.decide_volumes(V[5000:].contiguous())
+    for k in a:
+        assert torch.equal(torch.cat([d1[k], d2[k]]), a[k])              # chunk boundaries do not matter
+    # supports vectors classify themselves consistently: frames 0..M-1 ARE the SVs -> K(x_m, sv_m) = 1 exactly
+    n = 96
+    vh = V[3000:3000 + n].cpu().numpy()
+    xz, yz, xy = OC.project_max(vh, threads=8)
+    ref = OC.svm(OC.features(xz, yz, xy, scale=True), sv, dc, ic, ns, 0.01, "rbf", ca, cb, threads=8)
+    assert np.abs(a["dec_ovo"][3000:3000 + n].cpu().numpy() - ref["dec_ovo"]).max() <= 1e-5
+    assert np.abs(a["proba"][3000:3000 + n].cpu().numpy() - ref["proba"]).max() <= 1e-5
+    np.testing.assert_array_equal(a["label_vote"][3000:3000 + n].cpu().numpy(), ref["label_vote"])
+    np.testing.assert_array_equal(a["label_calib"][3000:3000 + n].cpu().numpy(), ref["label_calib"])
