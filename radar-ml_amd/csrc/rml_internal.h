@@ -78,8 +78,13 @@ int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, in
 // ---- SVM (svm.hip) ------------------------------------------------------------------------
 struct rml_svm {
     int64_t M = 0, Mpad = 0, D = 0;
-    int64_t Dq = 0;               // code row bytes   = round_up(D, 128)
-    int64_t Df = 0;               // float row length = round_up(D, 32)
+    int64_t Kq = 0;               // code K extent (bytes)   = round_up(D, 128)
+    int64_t Kf = 0;               // float K extent (floats) = round_up(D, 32)
+    // Row strides: the K extent, plus one 128-byte granule when that makes the stride an ODD multiple of 128 B.
+    // With an even multiple (D = 20 480: 160 x 128 B) the same K-slice of every row of a tile maps to the same
+    // L2 channel and the LDS-DMA staging of the GEMM serialises on it.
+    int64_t Dq = 0;               // code row stride (bytes)
+    int64_t Df = 0;               // float row stride (floats)
     int C = 0, P = 0, PT = 0, kernel = 0;
     double gamma = 0, code_scale = 1;
     bool exact = false, has_calib = false;

@@ -661,7 +661,7 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
     if (run_i8) {
-        ga.sv = m->sv_q; ga.ld_sv = m->Dq; ga.x = q; ga.ld_x = ld_q; ga.KT = (int)(m->Dq / kStepBytes);
+        ga.sv = m->sv_q; ga.ld_sv = m->Dq; ga.x = q; ga.ld_x = ld_q; ga.KT = (int)(m->Kq / kStepBytes);
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
@@ -670,7 +670,7 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     }
     if (run_gen) {
         ga.sv = reinterpret_cast<const uint8_t*>(m->sv_f32); ga.ld_sv = m->Df * 4;
-        ga.x = reinterpret_cast<const uint8_t*>(f32); ga.ld_x = m->Df * 4; ga.KT = (int)(m->Df * 4 / kStepBytes);
+        ga.x = reinterpret_cast<const uint8_t*>(f32); ga.ld_x = m->Df * 4; ga.KT = (int)(m->Kf * 4 / kStepBytes);
         ga.want = 0; ga.x_nsq = nsq; ga.sv_term = m->sv_nsq; ga.gs = m->gamma;
         int rc = gen_f32 ? launch_gemm<PATH_F32>(m, ga, st) : launch_gemm<PATH_F64>(m, ga, st);
         if (rc) return rc;
@@ -708,7 +708,10 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
     m->M = M; m->D = D; m->C = n_classes; m->P = n_classes * (n_classes - 1) / 2;
     m->PT = m->P <= 1 ? 1 : (m->P <= 3 ? 3 : 6);
     m->kernel = kernel; m->gamma = gamma; m->code_scale = code_scale > 1.0 ? code_scale : 1.0;
-    m->Mpad = round_up(M, kTile); m->Dq = round_up(D, kStepBytes); m->Df = round_up(D, 32);
+    m->Mpad = round_up(M, kTile);
+    m->Kq = round_up(D, kStepBytes); m->Kf = round_up(D, 32);
+    m->Dq = ((m->Kq / 128) & 1) ? m->Kq : m->Kq + 128;
+    m->Df = ((m->Kf / 32) & 1) ? m->Kf : m->Kf + 32;
     m->has_calib = calib_a != nullptr;
 
     // per-pair SV weights: the pair loop of svm_predict_values (svm.cpp:2864-2883)
@@ -810,8 +813,8 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
         RML_REQUIRE(m->exact, RML_ERR_STATE, "rml_svm_decision: code rows given but the model is not on the code grid");
         RML_REQUIRE(path == RML_PATH_AUTO || path == RML_PATH_I8, RML_ERR_INVALID, "rml_svm_decision: the float paths need float rows");
         RML_REQUIRE(row_isum && row_isq, RML_ERR_INVALID, "rml_svm_decision: code rows need row_isum/row_isq");
-        RML_REQUIRE(ld_q >= m->Dq && ld_q % 16 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 15) == 0, RML_ERR_INVALID,
-                    "rml_svm_decision: code rows need ld_q >= %lld, ld_q %% 16 == 0 and 16-byte alignment", (long long)m->Dq);
+        RML_REQUIRE(ld_q >= m->Kq && ld_q % 16 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 15) == 0, RML_ERR_INVALID,
+                    "rml_svm_decision: code rows need ld_q >= %lld, ld_q %% 16 == 0 and 16-byte alignment", (long long)m->Kq);
     }
     RML_HIP(hipSetDevice(ctx->device));
     if (N == 0) return RML_OK;
