@@ -26,6 +26,7 @@
 // Algorithmic HBM bytes per frame (mode MAX): 4*X*Y*Z read + 4*D written (+ D code bytes).
 #include "rml_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -128,13 +129,13 @@ struct Emitter {
             }
         }
     }
-    // block reduction of the statistics; red must hold >= 16 int64 slots; all threads call it
+    // block reduction of the statistics (up to 16 waves); red must hold >= 64 int64 slots; all threads call it
     __device__ void finish(int64_t* red) {
         if (a.o.qrow) {   // zero the pad columns [qD, qstride) of the code row (i8 value 0)
-            for (int64_t c = a.o.qD + threadIdx.x; c < a.o.qstride; c += kThreads) a.o.qrow[b * a.o.qstride + c] = 0;
+            for (int64_t c = a.o.qD + threadIdx.x; c < a.o.qstride; c += blockDim.x) a.o.qrow[b * a.o.qstride + c] = 0;
         }
         if (a.o.prow) {   // zero the pad columns [pD, pstride) of the float row
-            for (int64_t c = a.o.pD + threadIdx.x; c < a.o.pstride; c += kThreads) a.o.prow[b * a.o.pstride + c] = 0.0f;
+            for (int64_t c = a.o.pD + threadIdx.x; c < a.o.pstride; c += blockDim.x) a.o.prow[b * a.o.pstride + c] = 0.0f;
         }
         if (!(a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.row_nsq)) return;
         int64_t s = isum, q = isq;
@@ -148,14 +149,14 @@ struct Emitter {
             nn += __shfl_xor(nn, off);
         }
         int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double* redd = reinterpret_cast<double*>(red + 12);
+        double* redd = reinterpret_cast<double*>(red + 48);
         __syncthreads();
         if (lane == 0) { red[wave * 3 + 0] = s; red[wave * 3 + 1] = q; red[wave * 3 + 2] = g; redd[wave] = nn; }
         __syncthreads();
         if (threadIdx.x == 0) {
             int64_t S = 0, Q = 0, G = 1;
             double NN = 0.0;
-            for (int w = 0; w < kThreads / 64; ++w) { S += red[w * 3]; Q += red[w * 3 + 1]; G &= red[w * 3 + 2]; NN += redd[w]; }
+            for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { S += red[w * 3]; Q += red[w * 3 + 1]; G &= red[w * 3 + 2]; NN += redd[w]; }
             if (a.o.row_isum) a.o.row_isum[b] = (int32_t)S;
             if (a.o.row_isq) a.o.row_isq[b] = Q;
             if (a.o.row_flags) a.o.row_flags[b] = (int32_t)G;
@@ -286,12 +287,108 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Row-group path for rows that are not a power-of-two number of float4 (Walabot arena: Z = 176, 44 float4):
+// the workgroup has T = R * ZQ threads with R rows chosen so that T is a multiple of 64 (R = 16, T = 704 =
+// 11 waves at ZQ = 44), thread t owns column quad kq = t % ZQ of the rows j = t / ZQ + R * m -- every lane
+// carries data (k_project_fast would idle 20 of 64 lanes there).  yz stays in registers (NM float4), xz is
+// combined in-lane over m and across the R row slots with LDS float atomics, xy is a segmented reduction over
+// the contiguous lanes of a row (rows straddle wave boundaries, so segment heads finish with an LDS atomic).
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NM, bool PRED>
+__global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) {
+    extern __shared__ __align__(16) float lds[];
+    if constexpr (PRED) { if (*a.o.skip_if_set) return; }
+    const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
+    float* xz_lds = lds;
+    float* xy_lds = lds + (size_t)X * Z;
+    int64_t* red = reinterpret_cast<int64_t*>(xy_lds + (((size_t)X * Y + 3) & ~(size_t)3));
+    const int T = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slot = tid / ZQ, kq = tid - slot * ZQ;
+    const int64_t b = blockIdx.x;
+    const float4* __restrict__ Vb = reinterpret_cast<const float4*>(a.V + b * (int64_t)X * Y * Z);
+    const float id = Op<MODE>::ident();
+    const float4 id4 = make_float4(id, id, id, id);
+    for (int idx = tid; idx < X * Z; idx += T) xz_lds[idx] = id;
+    for (int idx = tid; idx < X * Y; idx += T) xy_lds[idx] = id;
+    __syncthreads();
+
+    float4 yz[NM];
+    int roff[NM];
+    bool rv[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int j = slot + R * m;
+        rv[m] = j < Y;
+        roff[m] = min(j, Y - 1) * ZQ + kq;
+        yz[m] = id4;
+    }
+    // segmented reduction over the lanes of a row: lane l+d belongs to my row iff it is in this wave and its
+    // row slot equals mine; the masks depend on the lane only (the same for every m)
+    unsigned same = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = 1 << s;
+        if (lane + d < 64 && (tid + d) / ZQ == slot) same |= 1u << s;
+    }
+    const bool head = (lane == 0) || ((tid - 1) / ZQ != slot);
+    const int plane = Y * ZQ;
+
+#pragma unroll 2
+    for (int i = 0; i < X; ++i) {
+        const float4* __restrict__ Vi = Vb + (int64_t)i * plane;
+        float4 cur[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) cur[m] = ld_stream(Vi + roff[m]);
+        if constexpr (MODE == RML_MODE_SUM) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) cur[m] = rv[m] ? cur[m] : id4;
+        }
+        float4 p = id4;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            yz[m] = op4<MODE>(yz[m], cur[m]);
+            p = op4<MODE>(p, cur[m]);
+            float r = Op<MODE>::f(Op<MODE>::f(cur[m].x, cur[m].y), Op<MODE>::f(cur[m].z, cur[m].w));
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const float o = __shfl_down(r, 1 << s);
+                r = ((same >> s) & 1u) ? Op<MODE>::f(r, o) : r;
+            }
+            if (head && rv[m]) Op<MODE>::lds_atomic(xy_lds + i * Y + slot + R * m, r);
+        }
+        float* dst = xz_lds + i * Z + 4 * kq;
+        Op<MODE>::lds_atomic(dst + 0, p.x);
+        Op<MODE>::lds_atomic(dst + 1, p.y);
+        Op<MODE>::lds_atomic(dst + 2, p.z);
+        Op<MODE>::lds_atomic(dst + 3, p.w);
+    }
+
+    Emitter em(a, b);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int j = slot + R * m;
+        if (rv[m]) em.put4(1, (int64_t)j * Z + 4 * kq, yz[m]);
+    }
+    __syncthreads();
+    const int nxz4 = (X * Z) >> 2;
+    for (int idx = tid; idx < nxz4; idx += T)
+        em.put4(0, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xz_lds + idx * 4));
+    const int nxy = X * Y;
+    const int nxy4 = nxy >> 2;
+    for (int idx = tid; idx < nxy4; idx += T)
+        em.put4(2, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xy_lds + idx * 4));
+    for (int idx = nxy4 * 4 + tid; idx < nxy; idx += T) em.put1(2, idx, xy_lds[idx]);
+    em.finish(red);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic fallback: any (X,Y,Z).  Three coalesced passes over the frame (L2 resident after
 // the first), no shape restrictions.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
-    __shared__ int64_t red[16];
+    __shared__ int64_t red[64];
     if (a.o.skip_if_set && *a.o.skip_if_set) return;
     const int X = a.X, Y = a.Y, Z = a.Z;
     const int64_t b = blockIdx.x;
@@ -326,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
 // Slice mode: planes through (i,j,k) of each frame, Python negative-index wrap.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
-    __shared__ int64_t red[16];
+    __shared__ int64_t red[64];
     if (a.o.skip_if_set && *a.o.skip_if_set) return;
     const int X = a.X, Y = a.Y, Z = a.Z;
     const int64_t b = blockIdx.x;
@@ -350,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
 
 // planes -> rows (common.process_samples at zoom 1 on already separate projections)
 __global__ __launch_bounds__(kThreads) void k_assemble(const float* xz, const float* yz, const float* xy, ProjParams a) {
-    __shared__ int64_t red[16];
+    __shared__ int64_t red[64];
     const int X = a.X, Y = a.Y, Z = a.Z;
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -364,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_assemble(const float* xz, const fl
 // float rows -> codes + stats (rml_quantize_rows).  A value is on the code grid iff it is
 // bit-identical to float32(c / scale_div) (the "p / 255." of train.py:667) or to c itself.
 __global__ __launch_bounds__(kThreads) void k_quantize_rows(const float* feat, int64_t D, int64_t ld, float scale_div, ProjParams a) {
-    __shared__ int64_t red[16];
+    __shared__ int64_t red[64];
     const int64_t b = blockIdx.x;
     Emitter em(a, b);
     const bool scaled = scale_div > 1.0f;
@@ -438,13 +535,42 @@ int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t s
     return 0;
 }
 
+template <int MODE, int NM>
+void launch_rowgroup(const ProjParams& pp, int R, size_t lds_bytes, hipStream_t st) {
+    dim3 grid((unsigned)pp.B), block((unsigned)(R * pp.ZQ));
+    if (pp.o.skip_if_set) {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<MODE, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_rowgroup<MODE, NM, true>), grid, block, lds_bytes, st, pp, R);
+    } else {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<MODE, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_rowgroup<MODE, NM, false>), grid, block, lds_bytes, st, pp, R);
+    }
+}
+
+int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
 template <int MODE>
 int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
     const int X = pp.X, Y = pp.Y, Z = pp.Z;
     *used_fast = false;
     bool fast_ok = (Z % 4 == 0) && (Z / 4 <= 64) && ((reinterpret_cast<uintptr_t>(pp.V) & 15) == 0);
-    size_t lds_bytes = ((size_t)X * Z + (((size_t)X * Y + 3) & ~(size_t)3)) * 4 + 16 * 8;
+    size_t lds_bytes = ((size_t)X * Z + (((size_t)X * Y + 3) & ~(size_t)3)) * 4 + 64 * 8;
     if (lds_bytes > 150 * 1024) fast_ok = false;
+    static const bool allow_rowgroup = [] { const char* e = getenv("RML_ROWGROUP"); return !e || atoi(e) != 0; }();
+    if (fast_ok && allow_rowgroup && (Z / 4) != next_pow2(Z / 4) && (Z / 4) >= 8) {
+        // rows that are not a power-of-two number of float4: row groups with every lane busy
+        const int zq = Z / 4;
+        int R = 64 / gcd_int(zq, 64);
+        while (R * zq < 512 && 2 * R * zq <= 1024 && 2 * R <= Y) R *= 2;
+        if (R * zq <= 1024) {
+            const int nm = (Y + R - 1) / R;
+            if (nm <= 2) { launch_rowgroup<MODE, 2>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+            if (nm <= 4) { launch_rowgroup<MODE, 4>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+            if (nm <= 8) { launch_rowgroup<MODE, 8>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+        }
+    }
     if (fast_ok) {
         int zq = Z / 4;
         int lpr = next_pow2(zq); if (lpr < 16) lpr = 16;

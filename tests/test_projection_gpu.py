@@ -7,7 +7,8 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 9), (3, 70, 24), (2, 3, 260), (16, 16, 64), (9, 130, 32)]
+SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 9), (3, 70, 24), (2, 3, 260), (16, 16, 64), (9, 130, 32),
+          (7, 37, 160), (5, 33, 48), (4, 9, 48), (3, 100, 176)]      # row-group kernel shapes (Z/4 not a power of two)
 
 
 def _vol(seed, B, X, Y, Z, integer=True):
