@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--parity", type=int, default=4096, help="frames checked against the CPU oracle")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-walabot", action="store_true", help="skip the secondary Walabot-arena-grid workload")
+    ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -85,29 +87,13 @@ def sv_f64(model):
     return (model["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
 
 
-def main():
-    a = parse()
+def run_workload(a, env, grid, frames, primary):
+    """Fit the model, make the resident batch, time K steps, and (rank 0) check parity / CPU baseline.
+    Returns the result dict on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
-    import radar_ml_amd as rml
-    from radar_ml_amd import _lib
-
-    X, Y, Z = (int(t) for t in a.grid.lower().split("x"))
+    rml, _lib, dev, rank, world = env["rml"], env["lib_mod"], env["dev"], env["rank"], env["world"]
+    X, Y, Z = grid
     D = rml.feature_len(X, Y, Z)
     frame_bytes = 4 * X * Y * Z
 
@@ -129,8 +115,8 @@ def main():
     # ---- resident batch ---------------------------------------------------------------------
     free, total = torch.cuda.mem_get_info(dev)
     reserve = 6 << 30
-    B = int(min(a.frames, max(128, (free - reserve) // frame_bytes)))
-    V, cls = rml.synth_volumes(B, X, Y, Z, seed=a.seed, frame0=rank * a.frames, device=dev)
+    B = int(min(frames, max(128, (free - reserve) // frame_bytes)))
+    V, cls = rml.synth_volumes(B, X, Y, Z, seed=a.seed, frame0=rank * frames, device=dev)
     lib = _lib.load()
     ctx = _lib.context(dev)
     from radar_ml_amd import dist as rdist
@@ -165,9 +151,9 @@ def main():
     dt = float(tmax.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        del V, out, svc
+        torch.cuda.empty_cache()
+        return None
 
     # ---- roofline of the dominant kernel (projection; HBM-bound) ---------------------------
     # algorithmic bytes per frame of the fused path: the volume read + 16 B of outputs
@@ -181,11 +167,12 @@ def main():
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            if pj.get("grid") == [X, Y, Z] and pj.get("frames_per_launch") == frames_per_launch:
+            if pj.get("grid") == [X, Y, Z] and abs(pj.get("frames_per_launch", 0) - frames_per_launch) < 1:
                 traffic = pj.get("project_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_project_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    kname = "k_project_fast" if (Z // 4) & ((Z // 4) - 1) == 0 else "k_project_rowgroup"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_frame": alg_bytes_frame}
@@ -193,7 +180,7 @@ def main():
     # ---- parity gate on a slab of the very frames the GPU classified ----------------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as OC
-    npar = min(a.parity, B)
+    npar = min(a.parity if primary else min(a.parity, 1024), B)
     vh = V[:npar].cpu().numpy()
     threads = len(os.sched_getaffinity(0))
     xz, yz, xy = OC.project_max(vh, threads=threads)
@@ -211,14 +198,14 @@ def main():
                                           np.searchsorted(model["classes"], cls[:npar].cpu().numpy())).mean()),
     }
 
-    # ---- CPU baseline: the C port of the reference path on the host cores -------------------
+    # ---- CPU baseline: the C port of the reference path on the host cores (rank 0, N = 1 only) ---
     cpu = None
-    if not a.no_cpu and world == 1:      # reported on rank 0 at N=1 only
+    if not a.no_cpu and world == 1:
         ncpu = a.cpu_frames
         if ncpu <= 0:
-            # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~15 s
+            # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~20 s (10 s secondary)
             est = 3.0 * D * M / (1.2e9 * threads)
-            ncpu = int(max(threads * 4, min(npar, 20.0 / max(est, 1e-6))))
+            ncpu = int(max(threads * 4, min(npar, (20.0 if primary else 10.0) / max(est, 1e-6))))
         ncpu = min(ncpu, npar)
         t1 = time.perf_counter()
         cxz, cyz, cxy = OC.project_max(vh[:ncpu], threads=threads)
@@ -230,13 +217,9 @@ def main():
                "sample": "%d of the same synthetic frames, oracle/oracle.c (max-projection + float64 libsvm loops, "
                          "OpenMP over frames), %.1f s" % (ncpu, cdt)}
 
-    frames_total = world * B * a.steps
-    value = frames_total / dt
-    line = {
-        "metric": "radar frames/s (3D-proj->SVM)", "value": round(value, 1), "unit": "frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
+    value = world * B * a.steps / dt
+    res = {
+        "value": round(value, 1), "ms_per_step": round(dt / a.steps * 1e3, 3),
         "config": {"workload": "configs[2]: max-projection + RBF-SVM decision_function, 3-class, %d SVs, "
                                "batch %d frames/GPU of %dx%dx%d f32 resident in HBM" % (M, B, X, Y, Z),
                    "grid": [X, Y, Z], "frames_per_gpu": B, "global_frames": world * B, "n_sv": M, "D": D,
@@ -246,8 +229,57 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
-    print(json.dumps(line))
+    del V, out, svc
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import radar_ml_amd as rml
+    from radar_ml_amd import _lib
+    env = {"rml": rml, "lib_mod": _lib, "dev": dev, "rank": rank, "world": world}
+
+    grid = tuple(int(t) for t in a.grid.lower().split("x"))
+    res = run_workload(a, env, grid, a.frames, primary=True)
+    # north_star: "Throughput ... at the Walabot Arena grid shape is reported": the reference's own grid
+    # (22, 31, 176) (common.py:25-27, predict.log:13) as a second workload in the same run, same metric.
+    wal = None
+    if not a.no_walabot and grid != (22, 31, 176):
+        wal = run_workload(a, env, (22, 31, 176), a.walabot_frames, primary=False)
+
+    if rank == 0:
+        line = {
+            "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
+            "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
+            "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "parity": res["parity"],
+            "model": res["model"],
+        }
+        if wal is not None:
+            line["walabot_grid"] = wal
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
