@@ -270,6 +270,18 @@ class GpuLinearClassifier(_Base):
         lab = self._run(self._rows(X))[1]
         return self.classes_.take(lab.cpu().numpy().astype(np.intp))
 
+    def decide_volumes(self, volumes, mode="max", ijk=None, proj_mask=ProjMask(True, True, True), scale=True):
+        """Batched path for the reference's default (SGD) model: (B,X,Y,Z) volumes -> projection + feature rows
+        (one pass over the volumes) -> linear scores, labels and calibrated probabilities, all on the GPU."""
+        from .common import process_volumes
+        feat = process_volumes(volumes, mode=mode, ijk=ijk, proj_mask=proj_mask, scale=scale)
+        dec, lab, proba, labc = self._run(feat, want_proba=self.has_calibration)
+        out = {"dec": dec, "label": lab}
+        if proba is not None:
+            out["proba"] = proba
+            out["label_calib"] = labc
+        return out
+
     def _proba(self, Xd):
         _, _, proba, labc = self._run(Xd, want_proba=True)
         return proba, labc

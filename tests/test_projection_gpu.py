@@ -205,3 +205,35 @@ def test_features_from_dataset_matches_process_samples(rml, tmp_path):
     a, b, c, labels = ds.load_dataset(p)
     feat = ds.features_from_dataset(a, b, c, scale=True).cpu().numpy()
     assert np.abs(feat.astype(np.float64) - g["feat_m0_s1"]).max() <= 1e-15      # the reference's own rows
+
+
+def test_random_shapes_property(rml):
+    """Property test over random grids (every kernel family: fast / row-group / generic, all three modes):
+    the HIP projections equal NumPy's on arbitrary float data, bit for bit (max, slice) or exactly on integer
+    data (sum)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 24), st.integers(1, 40), st.integers(1, 80), st.integers(1, 3), st.integers(0, 2 ** 31 - 1),
+           st.sampled_from([1, 2, 4]))
+    def check(X, Y, Zq, B, seed, zmul):
+        Z = Zq * zmul if zmul > 1 else Zq
+        rng = np.random.default_rng(seed)
+        v = rng.integers(-50, 255, (B, X, Y, Z)).astype(np.float32)
+        got = rml.project(v, mode="max")
+        for g, w in zip(got, O.project_max(v)):
+            np.testing.assert_array_equal(g, w)
+        got = rml.project(v, mode="sum")
+        for g, w in zip(got, O.project_sum(v)):
+            np.testing.assert_array_equal(g, w)
+        ijk = np.stack([rng.integers(-X, X, B), rng.integers(-Y, Y, B), rng.integers(-Z, Z, B)], 1)
+        got = rml.project(v, mode="slice", ijk=ijk)
+        for b in range(B):
+            for g, w in zip(got, O.project_slice(v[b], *ijk[b])):
+                np.testing.assert_array_equal(g[b], w)
+        mask = rml.ProjMask(bool(seed & 1), bool(seed & 2) or not (seed & 5), bool(seed & 4))
+        f = rml.process_volumes(np.abs(v), proj_mask=mask, scale=True).cpu().numpy()
+        xz, yz, xy = O.project_max(np.abs(v))
+        np.testing.assert_array_equal(f, O.features_from_projections(xz, yz, xy, tuple(mask), True))
+
+    check()

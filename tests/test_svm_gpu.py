@@ -193,6 +193,16 @@ def test_linear_classifier_golden(rml):
     np.testing.assert_array_equal(cal.predict(X), g["label_calib"])
 
 
+def test_linear_fused_volumes(rml):
+    g = load_golden("linear_golden.npz")
+    clf = rml.GpuLinearClassifier(g["coef"], g["intercept"], g["classes"], g["calib_a"], g["calib_b"])
+    vol, _ = O.synth_volumes(1234 + 77, 700, 10, 12, 16)           # the frames the golden model was fitted on
+    out = clf.decide_volumes(vol[600:700], mode="max", scale=True)
+    assert np.abs(out["dec"].cpu().numpy() - g["dec"]).max() <= 1e-9
+    np.testing.assert_array_equal(g["classes"][out["label"].cpu().numpy()], g["label"])
+    np.testing.assert_array_equal(g["classes"][out["label_calib"].cpu().numpy()], g["label_calib"])
+
+
 def test_from_sklearn_roundtrip(rml):
     sklearn = pytest.importorskip("sklearn")
     import warnings
