@@ -185,6 +185,13 @@ int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
                      double* dec_ovo, double* dec_ovr, double* proba,
                      int32_t* label_vote, int32_t* label_calib, void* stream);
 
+/* SVC(probability=True).predict_proba (the estimator train.py:478 constructs): libsvm's Platt sigmoid on every
+ * pair value followed by pairwise coupling (sk:svm/src/libsvm/svm.cpp:2032-2104, 2918-2952).  probA/probB: HOST,
+ * P values each (SVC._probA / _probB); dec_ovo: DEVICE N*P libsvm pair values (dec_ovo of rml_svm_decision);
+ * proba: DEVICE N*C.  Synchronises the stream before returning. */
+int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, const double* probB,
+                           const double* dec_ovo, int64_t N, double* proba, void* stream);
+
 /* Fused front door: volumes -> projection (mode, mask fixed at load: D must match) ->
  * SVM outputs, features never returned to the caller.  Workspace is owned by the ctx and
  * grows on demand. */

@@ -361,6 +361,49 @@ def calibrated_labels(proba):
     return np.argmax(proba, axis=1)
 
 
+def libsvm_pairwise_proba(dec, probA, probB, n_classes):
+    """SVC.predict_proba for probability=True models (the SVC of train.py:478): libsvm's
+    svm_predict_probability, sk:svm/src/libsvm/svm.cpp:2032-2040 (sigmoid_predict), 2043-2104
+    (multiclass_probability, method 2 of Wu, Lin & Weng), 2918-2952.  ``dec`` are libsvm's pair values (N,P)."""
+    dec = np.asarray(dec, dtype=np.float64).reshape(len(dec), -1)
+    k = n_classes
+    N = dec.shape[0]
+    out = np.empty((N, k))
+    for n in range(N):
+        r = np.zeros((k, k))
+        q = 0
+        for i in range(k):
+            for j in range(i + 1, k):
+                f = dec[n, q] * probA[q] + probB[q]
+                s = np.exp(-f) / (1.0 + np.exp(-f)) if f >= 0 else 1.0 / (1.0 + np.exp(f))
+                r[i, j] = min(max(s, 1e-7), 1 - 1e-7)
+                r[j, i] = 1 - r[i, j]
+                q += 1
+        p = np.full(k, 1.0 / k)
+        Q = np.zeros((k, k))
+        for t in range(k):
+            for j in range(t):
+                Q[t, t] += r[j, t] * r[j, t]
+                Q[t, j] = Q[j, t]
+            for j in range(t + 1, k):
+                Q[t, t] += r[j, t] * r[j, t]
+                Q[t, j] = -r[j, t] * r[t, j]
+        eps = 0.005 / k
+        for it in range(max(100, k)):
+            Qp = Q @ p
+            pQp = float(p @ Qp)
+            if np.abs(Qp - pQp).max() < eps:
+                break
+            for t in range(k):
+                diff = (-Qp[t] + pQp) / Q[t, t]
+                p[t] += diff
+                pQp = (pQp + diff * (diff * Q[t, t] + 2 * Qp[t])) / (1 + diff) / (1 + diff)
+                Qp = (Qp + diff * Q[t]) / (1 + diff)
+                p = p / (1 + diff)
+        out[n] = p
+    return out
+
+
 def linear_decision(X, coef, intercept):
     """SGDClassifier.decision_function: X @ coef_.T + intercept_ (train.py:421,433 predict
     = argmax of this for >2 classes; sk:linear_model/_base.py decision_function)."""

@@ -526,6 +526,51 @@ __global__ __launch_bounds__(256) void k_svm_finish(FinishArgs a) {
     }
 }
 
+// ---- libsvm probability estimates (SVC(probability=True).predict_proba) ---------------------------------
+// sigmoid_predict + multiclass_probability (method 2 of Wu, Lin & Weng) of sk:svm/src/libsvm/svm.cpp:2032-2104,
+// 2918-2952, one thread per sample, float64, same iteration order as the C loops.
+__global__ __launch_bounds__(256) void k_pairwise_proba(const double* dec, int64_t N, int k, const double* probA, const double* probB,
+                                                        double* proba) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int P = k * (k - 1) / 2;
+    double r[kMaxC][kMaxC], Q[kMaxC][kMaxC], p[kMaxC], Qp[kMaxC];
+    int q = 0;
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j, ++q) {
+            const double f = dec[n * P + q] * probA[q] + probB[q];
+            double s = f >= 0 ? exp(-f) / (1.0 + exp(-f)) : 1.0 / (1.0 + exp(f));
+            s = fmin(fmax(s, 1e-7), 1.0 - 1e-7);
+            r[i][j] = s; r[j][i] = 1.0 - s;
+        }
+    for (int t = 0; t < k; ++t) {
+        p[t] = 1.0 / k;
+        Q[t][t] = 0.0;
+        for (int j = 0; j < t; ++j) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = Q[j][t]; }
+        for (int j = t + 1; j < k; ++j) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = -r[j][t] * r[t][j]; }
+    }
+    const double eps = 0.005 / k;
+    const int max_iter = k > 100 ? k : 100;
+    for (int iter = 0; iter < max_iter; ++iter) {
+        double pQp = 0.0;
+        for (int t = 0; t < k; ++t) {
+            Qp[t] = 0.0;
+            for (int j = 0; j < k; ++j) Qp[t] += Q[t][j] * p[j];
+            pQp += p[t] * Qp[t];
+        }
+        double max_error = 0.0;
+        for (int t = 0; t < k; ++t) max_error = fmax(max_error, fabs(Qp[t] - pQp));
+        if (max_error < eps) break;
+        for (int t = 0; t < k; ++t) {
+            const double diff = (-Qp[t] + pQp) / Q[t][t];
+            p[t] += diff;
+            pQp = (pQp + diff * (diff * Q[t][t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+            for (int j = 0; j < k; ++j) { Qp[j] = (Qp[j] + diff * Q[t][j]) / (1 + diff); p[j] /= (1 + diff); }
+        }
+    }
+    for (int t = 0; t < k; ++t) proba[n * k + t] = p[t];
+}
+
 // ---- linear classifier: one wave per row, float64 accumulation ----------------------------
 __global__ __launch_bounds__(256) void k_linear(const float* feat, int64_t ld, int64_t N, int64_t D, int C,
                                                 const double* coef, const double* intercept, const double* calib, int has_calib,
@@ -941,6 +986,27 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
         RML_HIP(hipEventRecord(ctx->ev_fork, st));
         RML_HIP(hipStreamWaitEvent(caller, ctx->ev_fork, 0));
     }
+    return RML_OK;
+}
+
+extern "C" int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, const double* probB,
+                                      const double* dec_ovo, int64_t N, double* proba, void* stream) {
+    RML_REQUIRE(ctx && m && probA && probB && N >= 0, RML_ERR_INVALID, "rml_svm_pairwise_proba: bad arguments");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(dec_ovo && proba, RML_ERR_INVALID, "rml_svm_pairwise_proba: NULL array");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the 2 x P Platt coefficients travel through the workspace (host pointers in, like rml_svm_load)
+    void* ws = nullptr;
+    int rc = rml_ws_reserve(ctx, 2 * kMaxP * sizeof(double) + 256, &ws);
+    if (rc) return rc;
+    double* dA = static_cast<double*>(ws);
+    double* dB = dA + kMaxP;
+    RML_HIP(hipMemcpyAsync(dA, probA, m->P * sizeof(double), hipMemcpyHostToDevice, st));
+    RML_HIP(hipMemcpyAsync(dB, probB, m->P * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pairwise_proba, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dec_ovo, N, m->C, dA, dB, proba);
+    RML_HIP(hipGetLastError());
+    RML_HIP(hipStreamSynchronize(st));      // probA/probB are caller-owned host memory
     return RML_OK;
 }
 

@@ -57,7 +57,8 @@ class GpuSVC(_Base):
     """GPU twin of a fitted ``sklearn.svm.SVC`` (C-SVC, one-vs-one, RBF or linear kernel)."""
 
     def __init__(self, support_vectors, dual_coef, intercept, n_support, gamma, classes, kernel="rbf",
-                 calib_a=None, calib_b=None, decision_function_shape="ovr", device=None, path="auto"):
+                 calib_a=None, calib_b=None, decision_function_shape="ovr", device=None, path="auto",
+                 probA=None, probB=None):
         torch = _torch()
         lib = _lib.load()
         sv = _f64(support_vectors)
@@ -87,6 +88,9 @@ class GpuSVC(_Base):
                 "rml_svm_load")
         self._h = h
         self.has_calibration = ca is not None
+        # libsvm's own Platt coefficients (SVC(probability=True)): used by predict_proba of the bare SVC
+        self._probA = None if probA is None or len(np.ravel(probA)) == 0 else _f64(np.ravel(probA))
+        self._probB = None if probB is None or len(np.ravel(probB)) == 0 else _f64(np.ravel(probB))
         self.exact = bool(lib.rml_svm_is_exact(h)) and self.code_scale > 0
         self.n_sv = sv.shape[0]
 
@@ -101,7 +105,7 @@ class GpuSVC(_Base):
         if calib is not None:
             a, b = calib
         return cls(clf.support_vectors_, clf._dual_coef_, clf._intercept_, clf._n_support, clf._gamma, clf.classes_,
-                   kernel=kernel, calib_a=a, calib_b=b,
+                   kernel=kernel, calib_a=a, calib_b=b, probA=getattr(clf, "_probA", None), probB=getattr(clf, "_probB", None),
                    decision_function_shape=getattr(clf, "decision_function_shape", "ovr"), **kw)
 
     def __del__(self):
@@ -177,6 +181,24 @@ class GpuSVC(_Base):
         if len(self.classes_) > 2 and self.decision_function_shape == "ovo":
             return ovo.cpu().numpy()
         return ovr.cpu().numpy()
+
+    def predict_proba(self, X):
+        """SVC.predict_proba of a probability=True model: libsvm's Platt sigmoids + pairwise coupling
+        (sk:svm/src/libsvm/svm.cpp:2918-2952).  (The reference itself calls predict_proba on the calibrated
+        wrapper -- GpuCalibratedClassifier -- not on the bare SVC.)"""
+        if self._probA is None:
+            raise AttributeError("predict_proba is not available when probability=False")
+        torch = _torch()
+        lib = _lib.load()
+        Xd = self._rows(X)
+        ovo = self._decide(Xd)[0]
+        N, C_ = Xd.shape[0], len(self.classes_)
+        proba = torch.empty((N, C_), dtype=torch.float64, device=Xd.device)
+        with torch.cuda.device(Xd.device):
+            _lib.check(lib.rml_svm_pairwise_proba(self._ctx, self._h, self._probA.ctypes.data, self._probB.ctypes.data,
+                                                  _lib.ptr(ovo), N, _lib.ptr(proba), _lib.stream_ptr(Xd.device)),
+                       "rml_svm_pairwise_proba")
+        return proba.cpu().numpy()
 
     def predict(self, X):
         """SVC.predict: libsvm one-vs-one vote (sk:svm/src/libsvm/svm.cpp:2884-2894)."""

@@ -175,6 +175,31 @@ def golden_svm(common, name, X, Y, Z, ntrain, nval, ntest, gamma, mask=(True, Tr
                                                            arr["n_support"]))
 
 
+def golden_platt(common):
+    """SVC(probability=True) as the reference constructs it (train.py:478): libsvm's own Platt scaling +
+    pairwise coupling (SVC.predict_proba), recorded next to the pair decision values it is computed from."""
+    from sklearn import svm
+    X, Y, Z = 8, 10, 16
+    vol, cls = synth(SEED + 31, 700, X, Y, Z)
+    F = np.concatenate([vol.max(axis=2).reshape(700, -1), vol.max(axis=1).reshape(700, -1),
+                        vol.max(axis=3).reshape(700, -1)], axis=1)
+    Fq = F.astype(np.uint8); Fx = Fq.astype(np.float32) / np.float32(255.0)
+    out = {}
+    for tag, y in (("c3", cls), ("c2", np.minimum(cls, 1))):
+        clf = svm.SVC(kernel="rbf", C=10.0, gamma=0.05, probability=True, class_weight="balanced", random_state=SEED)
+        clf.fit(Fx[:500], y[:500])
+        te = slice(500, 700)
+        clf.decision_function_shape = "ovo"
+        out.update({tag + "_sv_u8": np.rint(clf.support_vectors_ * 255).astype(np.uint8), tag + "_dual_coef": clf._dual_coef_,
+                    tag + "_intercept": clf._intercept_, tag + "_n_support": clf._n_support.astype(np.int32),
+                    tag + "_classes": clf.classes_, tag + "_probA": clf._probA, tag + "_probB": clf._probB,
+                    tag + "_dec": clf.decision_function(Fx[te]), tag + "_proba": clf.predict_proba(Fx[te]),
+                    tag + "_label_vote": clf.predict(Fx[te])})
+    out["test_feat_u8"] = Fq[500:700]; out["gamma"] = np.float64(0.05)
+    np.savez_compressed(os.path.join(HERE, "svm_platt.npz"), **out)
+    print("svm_platt: M3=%d M2=%d" % (out["c3_sv_u8"].shape[0], out["c2_sv_u8"].shape[0]))
+
+
 def golden_real_xy():
     """The only real radar data in the reference tree: the DEBUG data dump in
     ground_truth_samples.log (XY projections printed in full; XZ/YZ elided)."""
@@ -271,6 +296,7 @@ if __name__ == "__main__":
     golden_svm(common, "svm_small_xy.npz", 8, 10, 16, 400, 100, 128, gamma=0.05, mask=(False, False, True))
     golden_svm(common, "svm_walabot.npz", 22, 31, 176, 420, 100, 128, gamma=0.01)
     golden_svm(common, "svm_small_binary.npz", 8, 10, 16, 400, 100, 128, gamma=0.05, binary=True)
+    golden_platt(common)
     golden_real_xy()
     golden_linear(common)
     golden_classifier_threshold(predict)

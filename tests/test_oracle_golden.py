@@ -140,3 +140,13 @@ def test_projection_identities():
     np.testing.assert_array_equal(st, sx[0].sum(axis=1))
     np.testing.assert_array_equal(sp, sy[0].sum(axis=1))
     np.testing.assert_array_equal(sr, sy[0].sum(axis=0))
+
+
+def test_libsvm_pairwise_proba_matches_sklearn():
+    g = load_golden("svm_platt.npz")
+    for tag, C in (("c3", 3), ("c2", 2)):
+        dec = g[tag + "_dec"]
+        if C == 2:
+            dec = -dec               # sklearn flips the sign of the binary pair value; libsvm couples its own
+        p = O.libsvm_pairwise_proba(dec, g[tag + "_probA"], g[tag + "_probB"], C)
+        np.testing.assert_allclose(p, g[tag + "_proba"], rtol=0, atol=1e-12)

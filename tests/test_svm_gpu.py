@@ -267,3 +267,19 @@ def test_full_size_properties_64x64x128(rml):
     assert np.abs(a["proba"][3000:3000 + n].cpu().numpy() - ref["proba"]).max() <= 1e-5
     np.testing.assert_array_equal(a["label_vote"][3000:3000 + n].cpu().numpy(), ref["label_vote"])
     np.testing.assert_array_equal(a["label_calib"][3000:3000 + n].cpu().numpy(), ref["label_calib"])
+
+
+@pytest.mark.parametrize("tag,C", [("c3", 3), ("c2", 2)])
+def test_svc_predict_proba_platt(rml, tag, C):
+    """SVC(probability=True).predict_proba: libsvm Platt scaling + pairwise coupling on the GPU vs sklearn."""
+    g = load_golden("svm_platt.npz")
+    sv = (g[tag + "_sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    svc = rml.GpuSVC(sv, g[tag + "_dual_coef"], g[tag + "_intercept"], g[tag + "_n_support"], float(g["gamma"]),
+                     g[tag + "_classes"], probA=g[tag + "_probA"], probB=g[tag + "_probB"], decision_function_shape="ovo")
+    X = g["test_feat_u8"].astype(np.float32) / np.float32(255.0)
+    assert np.abs(svc.decision_function(X) - g[tag + "_dec"]).max() <= TOL
+    assert np.abs(svc.predict_proba(X) - g[tag + "_proba"]).max() <= TOL
+    np.testing.assert_array_equal(svc.predict(X), g[tag + "_label_vote"])
+    bare = rml.GpuSVC(sv, g[tag + "_dual_coef"], g[tag + "_intercept"], g[tag + "_n_support"], float(g["gamma"]), g[tag + "_classes"])
+    with pytest.raises(AttributeError):
+        bare.predict_proba(X)
