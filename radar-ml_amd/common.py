@@ -163,7 +163,8 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
     ijk_t = None
     if m == _lib.MODE_SLICE:
         if ijk is None:
-            raise ValueError("mode='slice' needs ijk")
+            # no SDK targets: derive the strongest return per frame on the GPU (common.py:49-80), then slice there
+            ijk = derive_targets(v, 1)[:, 0, :]
         ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
             device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
     feat = out if out is not None else torch.empty((B, D), dtype=torch.float32, device=dev)

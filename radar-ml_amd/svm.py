@@ -154,6 +154,9 @@ class GpuSVC(_Base):
         if want_proba is None:
             want_proba = self.has_calibration
         ijk_t = None
+        if mode == "slice" and ijk is None:
+            from .common import derive_targets
+            ijk = derive_targets(v, 1)[:, 0, :]          # DerivedTarget.get_derived_targets on the GPU (common.py:49-80)
         if ijk is not None:
             ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
                 device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()

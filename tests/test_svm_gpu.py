@@ -283,3 +283,21 @@ def test_svc_predict_proba_platt(rml, tag, C):
     bare = rml.GpuSVC(sv, g[tag + "_dual_coef"], g[tag + "_intercept"], g[tag + "_n_support"], float(g["gamma"]), g[tag + "_classes"])
     with pytest.raises(AttributeError):
         bare.predict_proba(X)
+
+
+def test_slice_mode_fused_with_derived_targets(rml):
+    """Reference-faithful pipeline without the Walabot SDK: derive (i,j,k) on the GPU (common.py:49-80), slice the
+    planes there (predict.py:102-107), scale, classify -- all in one call, against the CPU oracle."""
+    import oracle_c as OC
+    g = load_golden("svm_walabot.npz")
+    svc, m = _model(rml, g)
+    vol = g["test_vol_u8"].astype(np.float32)
+    out = svc.decide_volumes(vol, mode="slice", scale=True)
+    ijk = np.array([[t.i, t.j, t.k] for v in vol for t in O.get_derived_targets(v, 22, 31, 176)])
+    xz, yz, xy = OC.project_slice(vol, ijk)
+    ref = OC.svm(OC.features(xz, yz, xy, scale=True), m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"],
+                 "rbf", m["calib_a"], m["calib_b"], threads=2)
+    assert np.abs(out["dec_ovo"].cpu().numpy() - ref["dec_ovo"]).max() <= TOL
+    np.testing.assert_array_equal(out["label_calib"].cpu().numpy(), ref["label_calib"])
+    feat = rml.process_volumes(vol, mode="slice", scale=True).cpu().numpy()
+    np.testing.assert_array_equal(feat, OC.features(xz, yz, xy, scale=True))
