@@ -208,6 +208,15 @@ int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, in
                         double* dec /* N*C */, double* proba /* N*C or NULL */, int32_t* label /* argmax dec */,
                         int32_t* label_calib, void* stream);
 
+/* ---- dnn.py convolutional trunk (dnn.py:45-52,68-76), fused ----------------------------------------------
+ * Per branch Conv2D(1->64,3x3,s2,'same',relu) -> Conv2D(64->32,3x3,s2,'same',relu); the three branches concatenated
+ * on channels and flattened NHWC: feat[b][(h*(W/4)+w)*96 + branch*32 + n], bf16.  Inputs (B,H,W) float32 already
+ * scaled to [-1,1] and resized (dnn.py:200-254); H, W multiples of 4.  Weights (DEVICE): w1 [3][64][9] float32
+ * (tap = ky*3+kx), b1 [3][64], w2t [3][32][576] bf16 with k = (ky*3+kx)*64 + cin, b2 [3][32]. */
+int rml_dnn_trunk(rml_ctx* ctx, const float* xz, const float* yz, const float* xy, int64_t B, int H, int W,
+                  const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                  uint16_t* feat, void* stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------- */
 int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
                       int n_classes, float* V, int32_t* cls /* B or NULL */, void* stream);

@@ -1,0 +1,317 @@
+// Fused convolutional trunk of the reference's multi-view CNN (dnn.py:45-52, 68-76) for gfx950:
+// per projection branch  Conv2D(1->64, 3x3, stride 2, 'same', relu) -> Conv2D(64->32, 3x3, stride 2, 'same', relu),
+// the three branches concatenated on the channel axis and flattened in NHWC order (dnn.py:74-76) -- i.e. the
+// 38 400-long feature vector that feeds the dense layers.
+//
+// PyTorch/MIOpen spends ~60 % of this forward in separate pad / bias / relu / cast passes over the 40x40x64
+// intermediate (614 KB per sample in bf16).  Here the intermediate never leaves the CU: one workgroup handles one
+// (sample, branch), two workgroups share a CU; the conv2 output is produced in strips of SR rows:
+//   1. (once per workgroup) the whole input plane is staged in LDS as bf16 (rows >= H and columns >= W are
+//      TensorFlow's bottom/right 'same' zeros) and each wave loads its weight fragments into registers,
+//   2. conv1 + bias + relu on the matrix cores, transposed: M = 64 channels (the weights = A), N = 16 strip pixels
+//      per tile (B = the pixels' 3x3 windows, five LDS reads per lane: the K order is chosen so that row pairs of the
+//      window are single aligned 32-bit reads, and K slots with zero weights may hold anything finite), K = 9 padded
+//      to 32.  The bias rides in as the C operand, relu is one v_pk_max_i16 on the packed bf16 pair, and a lane holds
+//      4 consecutive channels of one pixel: one 8-byte LDS store into the conv1 image [rows][cols+1][64],
+//   3. conv2 is an implicit GEMM (v_mfma_f32_16x16x32_bf16): M = 32 output channels (weights, in registers),
+//      N = strip pixels, K = 9 taps x 64 channels; the pixel fragments are read straight from the conv1 image (16
+//      contiguous bytes = 8 input channels of one tap); the K range is split over two wave pairs and reduced
+//      through LDS,
+//   4. relu, bf16, and a coalesced store at ((h*OW2 + w)*96 + branch*32 + n).
+// The conv1 image uses a padded pixel stride (144 B) so that the ds_read_b128 fragment reads are bank-conflict
+// free; the reduction and output staging buffers alias it (it is dead between conv2 and the next strip).
+// Numerics: bf16 operands, float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
+#include "rml_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int C1 = 64, C2 = 32, KTAPS = 9;
+constexpr int K2 = KTAPS * C1;            // 576
+constexpr int PIX_STRIDE = C1 * 2 + 16;    // 144 B per conv1 pixel in LDS
+constexpr int MT_MAX = 5;                  // conv2 pixel tiles per strip
+
+struct TrunkArgs {
+    const float* in[3];     // (B, H, W) float32 per branch
+    int64_t B;
+    int H, W;
+    const float* w1;        // [3][64][9]
+    const float* b1;        // [3][64]
+    const uint16_t* w2t;    // [3][32][576] bf16, k = (ky*3+kx)*64 + cin
+    const float* b2;        // [3][32]
+    uint16_t* feat;         // [B][OH2*OW2*96] bf16
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32 (round to nearest even)
+    bf16x2 b = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+    return *reinterpret_cast<uint32_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pk_relu(uint32_t v) {             // bf16 is sign-magnitude: max as int16 with 0
+    s16x2 s = *reinterpret_cast<s16x2*>(&v);
+    s = __builtin_elementwise_max(s, s16x2{0, 0});
+    return *reinterpret_cast<uint32_t*>(&s);
+}
+
+struct TrunkLayout {        // LDS carve-up, shared by the kernel and the launcher
+    int RS, ntp;
+    size_t off_c1, off_tab, total;
+    __host__ __device__ TrunkLayout(int H, int W, int SR) {
+        const int R1 = 2 * SR + 1, OW1 = W / 2;
+        RS = W + 2;
+        ntp = (R1 * OW1 + 15) & ~15;
+        off_c1 = ((size_t)(H + 5) * RS * 2 + 15) & ~(size_t)15;
+        const size_t image = ((size_t)R1 * (OW1 + 1) + 1) * PIX_STRIDE;
+        const size_t stage = (size_t)2 * MT_MAX * 64 * 16 + (size_t)SR * (W / 4) * C2 * 2;     // red_s + o_s
+        off_tab = off_c1 + (image > stage ? image : stage);
+        total = off_tab + (size_t)2 * ntp * 4;
+    }
+};
+
+template <int SR>
+__global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = a.H, W = a.W;
+    const int OH1 = H / 2, OW1 = W / 2, OH2 = H / 4, OW2 = W / 4;
+    constexpr int R1 = 2 * SR + 1;        // conv1 rows per strip
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int br = blockIdx.y;
+    const TrunkLayout L(H, W, SR);
+    const int RS = L.RS;
+
+    uint16_t* in_s = reinterpret_cast<uint16_t*>(smem);          // [H+5][W+2] bf16: plane + zero pad
+    unsigned char* c1_s = smem + L.off_c1;                       // [R1][OW1+1] pixels x 144 B (+ 1 dummy pixel)
+    int* tab_in = reinterpret_cast<int*>(smem + L.off_tab);      // [ntp]
+    int* tab_out = tab_in + L.ntp;                               // [ntp]
+    float* red_s = reinterpret_cast<float*>(c1_s);               // [2 nt][MT_MAX][64 lanes][4]   (aliases the image)
+    uint16_t* o_s = reinterpret_cast<uint16_t*>(c1_s + 2 * MT_MAX * 64 * 16);   // [SR*OW2][32] bf16  (ditto)
+    const int dummy_off = R1 * (OW1 + 1) * PIX_STRIDE;
+
+    const float* __restrict__ src = a.in[br] + b * (int64_t)H * W;
+    const float* __restrict__ w1 = a.w1 + br * C1 * KTAPS;
+    const float* __restrict__ b1 = a.b1 + br * C1;
+    const float* __restrict__ b2 = a.b2 + br * C2;
+
+    // everything the window reads may touch -> 0, then the plane as bf16; conv1 image -> 0 (its pad column is never
+    // written again)
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < (int)(L.off_c1 >> 4); i += 256) *reinterpret_cast<uint4*>(smem + i * 16) = z;
+        for (int i = tid; i < (int)((L.off_tab - L.off_c1) >> 4); i += 256) *reinterpret_cast<uint4*>(c1_s + i * 16) = z;
+    }
+    __syncthreads();
+    {
+        const int W4 = W >> 2;
+        for (int i = tid; i < H * W4; i += 256) {
+            const int rr = i / W4, c4 = i - rr * W4;
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)rr * W + c4 * 4);
+            *reinterpret_cast<uint2*>(in_s + rr * RS + c4 * 4) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+        }
+    }
+    // conv2 weights: a wave only ever needs the fragments of its (K half, channel tile): 9 x 16 B per lane, in
+    // registers for the whole workgroup lifetime (36 VGPRs instead of a 37 KB LDS image)
+    const int nt = wave & 1, kh = wave >> 1, kg = lane >> 4;
+    bf16x8 bfrag[9];
+    {
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(a.w2t + (size_t)br * C2 * K2) +
+                                 (size_t)(nt * 16 + (lane & 15)) * (K2 * 2) + kg * 16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bfrag[t] = *reinterpret_cast<const bf16x8*>(g + (kh * 9 + t) * 64);
+    }
+    // conv1 weights as four A fragments (channel = ct*16 + lane&15).  K slots of k-group 0: the window's
+    // (r0c0 r0c1)(r1c0 r1c1)(r2c0 r2c1)(r0c2 r1c2), k-group 1: r2c2 then zeros, k-groups 2 and 3: zeros.
+    bf16x8 w1frag[4];
+    f32x4 b1r[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float* wr_ = w1 + (ct * 16 + (lane & 15)) * KTAPS;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (kg == 0) u = make_uint4(pk_bf16(wr_[0], wr_[1]), pk_bf16(wr_[3], wr_[4]), pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[2], wr_[5]));
+        else if (kg == 1) u.x = pk_bf16(wr_[8], 0.0f);
+        w1frag[ct] = *reinterpret_cast<bf16x8*>(&u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1r[ct][r] = b1[ct * 16 + kg * 4 + r];
+    }
+    f32x4 b2r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b2r[r] = kh == 0 ? b2[nt * 16 + kg * 4 + r] : 0.0f;
+    // pixel -> offset tables of a strip (the same for every strip): window base in the input plane (bf16 units) and
+    // byte offset in the conv1 image (+ the conv1 row in the top byte; pixels past the strip -> the dummy pixel)
+    for (int q = tid; q < L.ntp; q += 256) {
+        const int qq = q < R1 * OW1 ? q : R1 * OW1 - 1;
+        const int cr = qq / OW1, cc = qq - cr * OW1;
+        tab_in[q] = (2 * cr) * RS + 2 * cc;
+        tab_out[q] = ((q < R1 * OW1) ? (cr * (OW1 + 1) + cc) * PIX_STRIDE : dummy_off) | (cr << 24);
+    }
+
+    const int P = SR * OW2;                 // output pixels per strip
+    const int MT = (P + 15) / 16;           // pixel tiles (<= MT_MAX)
+    int poff[MT_MAX];                       // conv2: byte offset of the lane's pixel window in the conv1 image
+#pragma unroll
+    for (int m = 0; m < MT_MAX; ++m) {
+        int q = m * 16 + (lane & 15);
+        q = q < P ? q : P - 1;
+        const int pr = q / OW2, pc = q - pr * OW2;
+        poff[m] = ((2 * pr) * (OW1 + 1) + 2 * pc) * PIX_STRIDE + kg * 16;
+    }
+    const int NT1 = L.ntp >> 4;             // pixel tiles of the strip's conv1 image
+    const int kgoff = kg == 1 ? 2 * RS + 2 : 0;
+
+#ifdef RML_DNN_TIMING
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0_, t1_, t2_, t3_, t4_;
+    const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
+    for (int r0 = 0; r0 < OH2; r0 += SR) {
+        __syncthreads();                    // previous strip stored (and the initial fills are done)
+#ifdef RML_DNN_TIMING
+        t0_ = __builtin_readcyclecounter();
+#endif
+        // 2. conv1 + bias + relu -> bf16 image.  conv1 rows past the bottom edge are 'same' zeros: their pixels go to
+        //    the dummy slot and the rows are cleared here (only ever in the last strip).
+        const int live = OH1 - 2 * r0;      // conv1 rows of this strip that exist
+        if (live < R1) {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            const int lo = (live < 0 ? 0 : live) * (OW1 + 1) * (PIX_STRIDE / 16);
+            for (int i = lo + tid; i < R1 * (OW1 + 1) * (PIX_STRIDE / 16); i += 256) *reinterpret_cast<uint4*>(c1_s + i * 16) = z;
+        }
+        if (tid < R1 * (PIX_STRIDE / 16)) {   // the pad column again: the staging buffers of the last strip lay over it
+            const int cr = tid / (PIX_STRIDE / 16), part = tid - cr * (PIX_STRIDE / 16);
+            *reinterpret_cast<uint4*>(c1_s + (cr * (OW1 + 1) + OW1) * PIX_STRIDE + part * 16) = make_uint4(0, 0, 0, 0);
+        }
+        const uint16_t* plane0 = in_s + (4 * r0) * RS + kgoff;
+#pragma unroll 2
+        for (int mt = wave; mt < NT1; mt += 4) {
+            const uint16_t* xin = plane0 + tab_in[mt * 16 + (lane & 15)];
+            int to = tab_out[mt * 16 + (lane & 15)];
+            uint4 u;
+            u.x = *reinterpret_cast<const uint32_t*>(xin);
+            u.y = *reinterpret_cast<const uint32_t*>(xin + RS);
+            u.z = *reinterpret_cast<const uint32_t*>(xin + 2 * RS);
+            u.w = (uint32_t)xin[2] | ((uint32_t)xin[RS + 2] << 16);
+            const bf16x8 xfrag = *reinterpret_cast<bf16x8*>(&u);
+            to = (to >> 24) < live ? (to & 0xFFFFFF) : dummy_off;
+            unsigned char* dstp = c1_s + to + kg * 8;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                // C/D map: rows (channels) ct*16 + (lane>>4)*4 + r, column (pixel) lane&15
+                const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1frag[ct], xfrag, b1r[ct], 0, 0, 0);
+                *reinterpret_cast<uint2*>(dstp + ct * 32) = make_uint2(pk_relu(pk_bf16(c[0], c[1])), pk_relu(pk_bf16(c[2], c[3])));
+            }
+        }
+#ifdef RML_DNN_TIMING
+        t1_ = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#ifdef RML_DNN_TIMING
+        t2_ = __builtin_readcyclecounter();
+#endif
+        // 3. conv2 as implicit GEMM: wave = (K half kh, channel tile nt), all MT_MAX pixel tiles (tiles past the strip
+        //    recompute its last pixel and are dropped in the epilogue: no divergent loads in the MFMA loop)
+        f32x4 acc[MT_MAX];
+#pragma unroll
+        for (int m = 0; m < MT_MAX; ++m) acc[m] = b2r;
+#pragma unroll
+        for (int t0 = 0; t0 < 9; t0 += 3) {         // three K-steps at a time: fragment reads in flight, then the MFMAs
+            bf16x8 afrag[3][MT_MAX];
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int ks = kh * 9 + t0 + tt;
+                const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3;
+                const int aoff = (ky * (OW1 + 1) + kx) * PIX_STRIDE + (ks & 1) * 64;
+#pragma unroll
+                for (int m = 0; m < MT_MAX; ++m) afrag[tt][m] = *reinterpret_cast<const bf16x8*>(c1_s + poff[m] + aoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int m = 0; m < MT_MAX; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[t0 + tt], afrag[tt][m], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef RML_DNN_TIMING
+        t3_ = __builtin_readcyclecounter();
+#endif
+        __syncthreads();                    // every wave is done reading the conv1 image: its space is reused below
+        if (kh == 1) {
+#pragma unroll
+            for (int m = 0; m < MT_MAX; ++m)
+                if (m < MT) *reinterpret_cast<f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4) = acc[m];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            // C/D map: rows (channels) nt*16 + (lane>>4)*4 + r, column (pixel) lane&15: 4 channels = one 8-byte store
+#pragma unroll
+            for (int m = 0; m < MT_MAX; ++m) {
+                const int q = m * 16 + (lane & 15);
+                if (m < MT && q < P) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4);
+                    const f32x4 s4 = acc[m] + o;
+                    *reinterpret_cast<uint2*>(o_s + q * C2 + nt * 16 + kg * 4) =
+                        make_uint2(pk_relu(pk_bf16(s4[0], s4[1])), pk_relu(pk_bf16(s4[2], s4[3])));
+                }
+            }
+        }
+        __syncthreads();
+        // 4. coalesced store: 64 B (32 channels) per pixel at ((h*OW2 + w)*96 + br*32); the strip's pixels are
+        //    consecutive in the output
+        const int rows = (OH2 - r0) < SR ? (OH2 - r0) : SR;
+        uint16_t* dst0 = a.feat + b * (int64_t)OH2 * OW2 * 96 + (int64_t)r0 * OW2 * 96 + br * 32;
+        for (int i = tid; i < rows * OW2 * 4; i += 256) {
+            const int q = i >> 2, part = i & 3;
+            *reinterpret_cast<uint4*>(dst0 + q * 96 + part * 8) = *reinterpret_cast<const uint4*>(o_s + q * C2 + part * 8);
+        }
+#ifdef RML_DNN_TIMING
+        t4_ = __builtin_readcyclecounter();
+        tA += t1_ - t0_; tB += t2_ - t1_; tC += t3_ - t2_; tD += t4_ - t3_;
+#endif
+    }
+#ifdef RML_DNN_TIMING
+    if (b == 100 && br == 0 && lane == 0)
+        printf("[dnn timing] wave %d: conv1 %llu  barrier %llu  conv2 %llu  epilogue %llu  total %llu\n", wave,
+               tA, tB, tC, tD, (unsigned long long)(__builtin_readcyclecounter() - tstart));
+#endif
+}
+
+template <int SR>
+int launch_trunk(const TrunkArgs& a, hipStream_t stream) {
+    const TrunkLayout L(a.H, a.W, SR);
+    if (SR * (a.W / 4) > 16 * MT_MAX || L.total > 150 * 1024) return RML_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    hipLaunchKernelGGL((k_dnn_trunk<SR>), dim3((unsigned)a.B, 3), dim3(256), L.total, stream, a);
+    return RML_OK;
+}
+
+}  // namespace
+
+extern "C" int rml_dnn_trunk(rml_ctx* ctx, const float* xz, const float* yz, const float* xy, int64_t B, int H, int W,
+                             const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                             uint16_t* feat, void* stream) {
+    RML_REQUIRE(ctx && B >= 0 && H > 0 && W > 0, RML_ERR_INVALID, "rml_dnn_trunk: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(xz && yz && xy && w1 && b1 && w2t && b2 && feat, RML_ERR_INVALID, "rml_dnn_trunk: NULL argument");
+    RML_REQUIRE(H % 4 == 0 && W % 4 == 0, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: H and W must be multiples of 4 (got %dx%d)", H, W);
+    RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: B too large");
+    RML_REQUIRE((reinterpret_cast<uintptr_t>(w2t) & 15) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(xz) & 15) == 0 && (reinterpret_cast<uintptr_t>(yz) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(xy) & 15) == 0, RML_ERR_INVALID,
+                "rml_dnn_trunk: planes, w2t and feat must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    TrunkArgs a{};
+    a.in[0] = xz; a.in[1] = yz; a.in[2] = xy; a.B = B; a.H = H; a.W = W;
+    a.w1 = w1; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.feat = feat;
+    // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
+    int rc = RML_ERR_UNSUPPORTED;
+    if (4 * (W / 4) <= 16 * MT_MAX && TrunkLayout(H, W, 4).total <= 80 * 1024) rc = launch_trunk<4>(a, static_cast<hipStream_t>(stream));
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<2>(a, static_cast<hipStream_t>(stream));
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<1>(a, static_cast<hipStream_t>(stream));
+    RML_REQUIRE(rc != RML_ERR_UNSUPPORTED, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: plane %dx%d does not fit the LDS-resident trunk", H, W);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

@@ -76,6 +76,49 @@ class Classifier(_module_base()):
         import torch
         return torch.softmax(self.logits(xz, yz, xy).float(), dim=-1)
 
+    # ---- fused HIP trunk -------------------------------------------------------------------------------
+    def _packed_trunk_weights(self):
+        """conv weights in the layout of rml_dnn_trunk (cached; invalidate by deleting ``_trunk_pack``)."""
+        import torch
+        pk = getattr(self, "_trunk_pack", None)
+        if pk is None:
+            w1 = torch.stack([br[0].conv.weight.detach().float().reshape(64, 9) for br in self.branches]).contiguous()
+            b1 = torch.stack([br[0].conv.bias.detach().float() for br in self.branches]).contiguous()
+            # (32, 64, 3, 3) -> (32, ky, kx, cin) -> (32, 576): k = (ky*3+kx)*64 + cin
+            w2t = torch.stack([br[1].conv.weight.detach().float().permute(0, 2, 3, 1).reshape(32, 576)
+                               for br in self.branches]).to(torch.bfloat16).contiguous()
+            b2 = torch.stack([br[1].conv.bias.detach().float() for br in self.branches]).contiguous()
+            pk = self._trunk_pack = (w1, b1, w2t, b2)
+        return pk
+
+    def features_fused(self, xz, yz, xy):
+        """The 38 400-long NHWC feature rows (bf16) of the three conv branches from the fused HIP kernel
+        (csrc/dnn.hip); inputs (N,H,W) or (N,1,H,W) float32 CUDA tensors."""
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        xs = [x.reshape(x.shape[0], x.shape[-2], x.shape[-1]).float().contiguous() for x in (xz, yz, xy)]
+        n, H, W = xs[0].shape
+        dev = xs[0].device
+        w1, b1, w2t, b2 = self._packed_trunk_weights()
+        feat = torch.empty((n, (H // 4) * (W // 4) * 96), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_dnn_trunk(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), n, H, W,
+                                         _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(feat),
+                                         _lib.stream_ptr(dev)), "rml_dnn_trunk")
+        return feat
+
+    def forward_fused(self, xz, yz, xy):
+        """Class probabilities with the fused HIP trunk + bf16 dense tail (hipBLASLt through PyTorch)."""
+        import torch
+        import torch.nn.functional as F
+        fv = self.features_fused(xz, yz, xy)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = F.relu(self.fc1(fv))
+            h = F.relu(self.fc2(h))
+            lg = self.fc3(h)
+        return torch.softmax(lg.float(), dim=-1)
+
     def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""
         import torch

@@ -55,3 +55,38 @@ def test_sgan_step_fp16_tracks_fp32(rml):
     assert abs(lc - lg) < 2e-2
     dc = tc.train_on_batch_d(x, np.full((32, 1), 0.9)); dg = tg.train_on_batch_d(x, np.full((32, 1), 0.9))
     assert abs(dc - dg) < 3e-2
+
+
+def test_dnn_fused_trunk_vs_fp32_cpu(rml):
+    """Hand-written fused conv trunk (csrc/dnn.hip: both convolutions as bf16 MFMA implicit GEMMs) vs the fp32 CPU
+    restatement of dnn.py:45-52,68-76 with shared weights."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    torch.manual_seed(7)
+    cpu = dnn.define_classifier(device="cpu").eval()
+    for mod in cpu.modules():                                  # non-zero biases so that they are exercised
+        if isinstance(mod, torch.nn.Conv2d):
+            torch.nn.init.normal_(mod.bias, 0.0, 0.1)
+    gpu = copy.deepcopy(cpu).to("cuda").to(memory_format=torch.channels_last).eval()
+    rng = np.random.default_rng(8)
+    x = [rng.uniform(-1, 1, (37, 80, 80)).astype(np.float32) for _ in range(3)]
+    with torch.no_grad():
+        want = cpu.features(*[torch.from_numpy(a).unsqueeze(1) for a in x]).numpy()
+        got = gpu.features_fused(*[torch.from_numpy(a).cuda() for a in x]).float().cpu().numpy()
+        assert got.shape == want.shape == (37, 38400)
+        err = np.abs(got - want)
+        assert err.max() <= 2e-2 + 1e-2 * np.abs(want).max() and err.mean() <= 2e-3      # bf16 storage of activations
+        p_want = cpu.predict([a[..., None] for a in x], autocast_dtype=None)
+        p_got = gpu.forward_fused(*[torch.from_numpy(a).cuda() for a in x]).cpu().numpy()
+    assert np.abs(p_got - p_want).max() < 3e-2
+    # other sizes: strips of 4 / 2 conv2 rows, a partial last strip (24 rows -> 6 conv2 rows), sgan's 128x128
+    for (h_, w_) in ((48, 64), (24, 16), (128, 128), (44, 36), (4, 4)):
+        small = dnn.Classifier([(h_, w_, 1)] * 3, 3).eval()
+        for mod in small.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                torch.nn.init.normal_(mod.bias, 0.0, 0.1)
+        sg = copy.deepcopy(small).to("cuda").eval()
+        xs = [rng.uniform(-1, 1, (5, h_, w_)).astype(np.float32) for _ in range(3)]
+        with torch.no_grad():
+            w = small.features(*[torch.from_numpy(a).unsqueeze(1) for a in xs]).numpy()
+            g = sg.features_fused(*[torch.from_numpy(a).cuda() for a in xs]).float().cpu().numpy()
+        assert g.shape == w.shape and np.abs(g - w).max() <= 2e-2 + 1e-2 * np.abs(w).max(), (h_, w_)

@@ -77,6 +77,26 @@ def main():
                 model(*xs)
             torch.cuda.synchronize()
         fwd = (time.perf_counter() - t0) / 10
+        with torch.no_grad():
+            for _ in range(3):
+                model.forward_fused(*xs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                model.forward_fused(*xs)
+            torch.cuda.synchronize()
+            fused = (time.perf_counter() - t0) / 10
+            for _ in range(3):
+                model.features_fused(*xs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                model.features_fused(*xs)
+            torch.cuda.synchronize()
+            trunk = (time.perf_counter() - t0) / 10
+        print(json.dumps({"what": "fused HIP trunk (csrc/dnn.hip) + bf16 dense tail", "batch": bs,
+                          "forward_frames_per_s": round(bs / fused), "forward_TFLOPs": round(bs * DNN_FLOP_PER_SAMPLE / fused / 1e12, 1),
+                          "trunk_only_frames_per_s": round(bs / trunk), "trunk_ms": round(trunk * 1e3, 3)}))
         print(json.dumps({"what": "configs[3]: projection + dnn forward", "dtype": str(dt), "frames": B, "batch": bs,
                           "frames_per_s_end_to_end": round(B / dtm), "ms_total": round(dtm * 1e3, 2),
                           "cnn_forward_frames_per_s": round(bs / fwd), "cnn_forward_TFLOPs": round(bs * DNN_FLOP_PER_SAMPLE / fwd / 1e12, 1),
