@@ -208,12 +208,23 @@ int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, in
                         double* dec /* N*C */, double* proba /* N*C or NULL */, int32_t* label /* argmax dec */,
                         int32_t* label_calib, void* stream);
 
+/* ---- PIL bicubic resize in front of the dnn / sgan classifiers ----------------------------------------------
+ * Image.fromarray(p).resize((out_w, out_h), resample=Image.BICUBIC) of float32 planes (dnn.py:240-245,
+ * sgan.py:676-681; Pillow's Resample.c: antialiased, double-precision taps, float32 intermediate), bit-identical
+ * to Pillow.  When div != 0 the reference's [-1,1] scaling (dnn.py:202-205) is applied first: v = (p - sub) / div
+ * (sub = div = RADAR_MAX/2 = 127.5).  in: B planes of H x W float32, in_stride floats from one sample to the next
+ * (a plane inside a feature row [xz|yz|xy] is addressed directly); out: B x out_h x out_w contiguous, float32
+ * (out_bf16 = 0) or bf16 (out_bf16 = 1, the operand type of rml_dnn_trunk). */
+int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stride, int64_t B, int H, int W, int out_h, int out_w,
+                       float sub, float div, void* out, int out_bf16, void* stream);
+
 /* ---- dnn.py convolutional trunk (dnn.py:45-52,68-76), fused ----------------------------------------------
  * Per branch Conv2D(1->64,3x3,s2,'same',relu) -> Conv2D(64->32,3x3,s2,'same',relu); the three branches concatenated
- * on channels and flattened NHWC: feat[b][(h*(W/4)+w)*96 + branch*32 + n], bf16.  Inputs (B,H,W) float32 already
- * scaled to [-1,1] and resized (dnn.py:200-254); H, W multiples of 4.  Weights (DEVICE): w1 [3][64][9] float32
+ * on channels and flattened NHWC: feat[b][(h*(W/4)+w)*96 + branch*32 + n], bf16.  Inputs (B,H,W) already scaled to
+ * [-1,1] and resized (dnn.py:200-254; rml_resize_bicubic), float32 (in_bf16 = 0; H, W multiples of 4; rounded to
+ * bf16 on load) or bf16 (in_bf16 = 1; W a multiple of 8): the results are identical.  Weights (DEVICE): w1 [3][64][9] float32
  * (tap = ky*3+kx), b1 [3][64], w2t [3][32][576] bf16 with k = (ky*3+kx)*64 + cin, b2 [3][32]. */
-int rml_dnn_trunk(rml_ctx* ctx, const float* xz, const float* yz, const float* xy, int64_t B, int H, int W,
+int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H, int W,
                   const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
                   uint16_t* feat, void* stream);
 

@@ -459,3 +459,86 @@ def synth_volumes(seed, nframes, X, Y, Z, n_classes=3, dtype=np.float32):
     np.minimum(vol, np.float32(255.0), out=vol)
     vol[vol < np.float32(13.0)] = 0.0
     return vol.astype(dtype), cls
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# PIL bicubic resize of float32 ('F' mode) images -- the resize in front of the dnn / sgan classifiers
+# (dnn.py:240-245, sgan.py:676-681: Image.fromarray(p).resize(RESCALE, resample=Image.BICUBIC)).
+# The algorithm lives in Pillow (requirements.txt:41 pins Pillow 8.2.0; absent from /root/reference), file
+# src/libImaging/Resample.c: precompute_coeffs() + ImagingResampleHorizontal_32bpc / ImagingResampleVertical_32bpc.
+# Restated here; pinned against Pillow itself by tests/golden/pil_resize.npz (tests/golden/make_golden.py).
+# ----------------------------------------------------------------------------------------------------------------
+def _pil_bicubic_filter(x):
+    a = -0.5
+    x = -x if x < 0.0 else x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size, out_size):
+    """precompute_coeffs() of Resample.c for the full box and the bicubic filter (support 2): per output index the
+    first input index, the tap count and the normalised double weights.  Returns (bounds (out,2) int32, kk (out,ksize) f64)."""
+    scale = float(in_size) / float(out_size)
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.float64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)         # C truncation of a value >= -support + 0.5 ...
+        if center - support + 0.5 < 0:
+            xmin = 0                               # ... and the clamp at 0 (truncation towards zero never goes below)
+        xmin = max(xmin, 0)
+        xmax = int(center + support + 0.5)
+        xmax = min(xmax, in_size) - xmin
+        ww = 0.0
+        for x in range(xmax):
+            w = _pil_bicubic_filter((x + xmin - center + 0.5) * ss)
+            kk[xx, x] = w
+            ww += w
+        if ww != 0.0:
+            for x in range(xmax):
+                kk[xx, x] /= ww
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_resize_bicubic(img, out_hw):
+    """Image.fromarray(img).resize((out_w, out_h), Image.BICUBIC) for a 2-D float array: horizontal pass into a
+    float32 intermediate, then the vertical pass; every output is a double-precision sum in tap order, rounded to
+    float32 (no fused multiply-add).  A pass whose size does not change is skipped, as in ImagingResample()."""
+    src = np.asarray(img, dtype=np.float32)
+    H, W = src.shape
+    OH, OW = out_hw
+    cur = src
+    if OW != W:
+        bounds, kk = pil_resample_coeffs(W, OW)
+        tmp = np.empty((H, OW), np.float32)
+        for xx in range(OW):
+            x0, n = bounds[xx]
+            ss = np.zeros(H, np.float64)
+            for t in range(n):
+                ss = ss + cur[:, x0 + t].astype(np.float64) * kk[xx, t]
+            tmp[:, xx] = ss.astype(np.float32)
+        cur = tmp
+    if OH != H:
+        bounds, kk = pil_resample_coeffs(H, OH)
+        out = np.empty((OH, cur.shape[1]), np.float32)
+        for yy in range(OH):
+            y0, n = bounds[yy]
+            ss = np.zeros(cur.shape[1], np.float64)
+            for t in range(n):
+                ss = ss + cur[y0 + t, :].astype(np.float64) * kk[yy, t]
+            out[yy, :] = ss.astype(np.float32)
+        cur = out
+    return np.array(cur, dtype=np.float32, copy=True)
+
+
+def scale_unit_range(p, radar_max=255.0):
+    """dnn.py:202-205 / sgan.py:638-641: (p - RADAR_MAX/2) / (RADAR_MAX/2), stored as float32 by Image.fromarray."""
+    return ((np.asarray(p, dtype=np.float64) - radar_max / 2.0) / (radar_max / 2.0)).astype(np.float32)

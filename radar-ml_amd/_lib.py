@@ -60,7 +60,9 @@ SIGNATURES = {
     "rml_linear_free": (c_int, [c_void_p, c_void_p]),
     "rml_linear_decision": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
-    "rml_dnn_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+    "rml_resize_bicubic": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_float,
+                                   c_void_p, c_int, c_void_p]),
+    "rml_dnn_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),

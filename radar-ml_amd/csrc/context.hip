@@ -104,6 +104,7 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (const rml_resize_tab& t : ctx->resize_tabs) (void)hipFree(const_cast<double*>(t.kk));
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->proj_stream) (void)hipStreamDestroy(ctx->proj_stream);
     delete ctx;

@@ -43,7 +43,7 @@ constexpr int TPW = 6;                     // conv1 pixel tiles per wave and str
 constexpr int PLD = 7;                     // 16-byte loads of the input plane per thread that are prefetched
 
 struct TrunkArgs {
-    const float* in[3];     // (B, H, W) float32 per branch
+    const void* in[3];      // (B, H, W) per branch: float32, or bf16 (template INBF)
     int64_t B;
     int H, W;
     const float* w1;        // [3][64][9]
@@ -81,7 +81,7 @@ struct TrunkLayout {        // LDS carve-up, shared by the kernel and the launch
     }
 };
 
-template <int SR>
+template <int SR, bool INBF>
 __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = a.H, W = a.W;
@@ -113,21 +113,34 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     lds_barrier();
     // the workgroup is persistent: it walks samples blockIdx.x, +gridDim.x, ... of its branch, and while one sample
     // is being convolved the next plane is already in flight into registers (PLD float4 per thread)
-    const int W4 = W >> 2, nquad = H * W4;
-    const bool prefetch = nquad <= 256 * PLD;
-    int lofs[PLD];                          // LDS destination (bf16 units) of the thread's quads, -1 past the plane
+    // (a 16-byte quad = 4 float32 or 8 bf16 values of one row)
+    constexpr int QE = INBF ? 8 : 4;        // elements per quad
+    constexpr int NLD = INBF ? (PLD + 1) / 2 : PLD;
+    const int WQ = W / QE, nquad = H * WQ;
+    const bool prefetch = nquad <= 256 * NLD;
+    int lofs[NLD];                          // LDS destination (bf16 units) of the thread's quads, -1 past the plane
 #pragma unroll
-    for (int u = 0; u < PLD; ++u) {
-        const int i = u * 256 + tid, rr = i / W4;
-        lofs[u] = i < nquad ? rr * RS + (i - rr * W4) * 4 : -1;
+    for (int u = 0; u < NLD; ++u) {
+        const int i = u * 256 + tid, rr = i / WQ;
+        lofs[u] = i < nquad ? rr * RS + (i - rr * WQ) * QE : -1;
     }
-    float4 pv[PLD];
+    uint4 pv[NLD];
     auto issue = [&](int64_t bb) {
-        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(a.in[br] + bb * (int64_t)H * W);
+        const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(
+            static_cast<const unsigned char*>(a.in[br]) + bb * (int64_t)H * W * (INBF ? 2 : 4));
 #pragma unroll
-        for (int u = 0; u < PLD; ++u) {
+        for (int u = 0; u < NLD; ++u) {
             const int i = u * 256 + tid;
             pv[u] = src4[i < nquad ? i : nquad - 1];
+        }
+    };
+    auto put = [&](int lo, const uint4& v) {        // one quad into the bf16 plane (rows are only 4-byte aligned)
+        uint32_t* d = reinterpret_cast<uint32_t*>(in_s + lo);
+        if (INBF) {
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            d[0] = pk_bf16(__uint_as_float(v.x), __uint_as_float(v.y));
+            d[1] = pk_bf16(__uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
     if (prefetch) issue(blockIdx.x);
@@ -189,17 +202,16 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     // 1. the plane as bf16 into LDS (every wave is past the conv1 of the previous sample: barriers in between)
     if (prefetch) {
 #pragma unroll
-        for (int u = 0; u < PLD; ++u)
-            if (lofs[u] >= 0)
-                *reinterpret_cast<uint2*>(in_s + lofs[u]) = make_uint2(pk_bf16(pv[u].x, pv[u].y), pk_bf16(pv[u].z, pv[u].w));
+        for (int u = 0; u < NLD; ++u)
+            if (lofs[u] >= 0) put(lofs[u], pv[u]);
         const int64_t nb = b + gridDim.x;
         issue(nb < a.B ? nb : b);           // (the last round reloads its own plane and drops it)
     } else {
-        const float* __restrict__ src = a.in[br] + b * (int64_t)H * W;
+        const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(
+            static_cast<const unsigned char*>(a.in[br]) + b * (int64_t)H * W * (INBF ? 2 : 4));
         for (int i = tid; i < nquad; i += 256) {
-            const int rr = i / W4, c4 = i - rr * W4;
-            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)i * 4);
-            *reinterpret_cast<uint2*>(in_s + rr * RS + c4 * 4) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+            const int rr = i / WQ;
+            put(rr * RS + (i - rr * WQ) * QE, src4[i]);
         }
     }
     for (int r0 = 0; r0 < OH2; r0 += SR) {
@@ -329,27 +341,40 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #endif
 }
 
-template <int SR>
+template <int SR, bool INBF>
 int launch_trunk(const TrunkArgs& a, int num_cu, hipStream_t stream) {
     const TrunkLayout L(a.H, a.W, SR);
     if (SR * (a.W / 4) > 16 * MT_MAX || L.nt1 > 4 * TPW || L.total > 150 * 1024) return RML_ERR_UNSUPPORTED;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR, INBF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     const int64_t slots = L.total <= 80 * 1024 ? 2 * (int64_t)num_cu : num_cu;      // workgroups resident at once
     const int64_t gx = slots / 3 > 0 ? slots / 3 : 1;
-    hipLaunchKernelGGL((k_dnn_trunk<SR>), dim3((unsigned)(a.B < gx ? a.B : gx), 3), dim3(256), L.total, stream, a);
+    hipLaunchKernelGGL((k_dnn_trunk<SR, INBF>), dim3((unsigned)(a.B < gx ? a.B : gx), 3), dim3(256), L.total, stream, a);
     return RML_OK;
 }
 
 }  // namespace
 
-extern "C" int rml_dnn_trunk(rml_ctx* ctx, const float* xz, const float* yz, const float* xy, int64_t B, int H, int W,
-                             const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+namespace {
+template <bool INBF>
+int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
+    // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
+    int rc = RML_ERR_UNSUPPORTED;
+    if (4 * (a.W / 4) <= 16 * MT_MAX && TrunkLayout(a.H, a.W, 4).total <= 80 * 1024) rc = launch_trunk<4, INBF>(a, num_cu, st);
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<2, INBF>(a, num_cu, st);
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<1, INBF>(a, num_cu, st);
+    return rc;
+}
+}  // namespace
+
+extern "C" int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H,
+                             int W, const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
                              uint16_t* feat, void* stream) {
     RML_REQUIRE(ctx && B >= 0 && H > 0 && W > 0, RML_ERR_INVALID, "rml_dnn_trunk: bad arguments");
     if (B == 0) return RML_OK;
     RML_REQUIRE(xz && yz && xy && w1 && b1 && w2t && b2 && feat, RML_ERR_INVALID, "rml_dnn_trunk: NULL argument");
-    RML_REQUIRE(H % 4 == 0 && W % 4 == 0, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: H and W must be multiples of 4 (got %dx%d)", H, W);
+    RML_REQUIRE(H % 4 == 0 && W % (in_bf16 ? 8 : 4) == 0, RML_ERR_UNSUPPORTED,
+                "rml_dnn_trunk: H must be a multiple of 4 and W of %d (got %dx%d)", in_bf16 ? 8 : 4, H, W);
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: B too large");
     RML_REQUIRE((reinterpret_cast<uintptr_t>(w2t) & 15) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(xz) & 15) == 0 && (reinterpret_cast<uintptr_t>(yz) & 15) == 0 &&
@@ -359,11 +384,8 @@ extern "C" int rml_dnn_trunk(rml_ctx* ctx, const float* xz, const float* yz, con
     TrunkArgs a{};
     a.in[0] = xz; a.in[1] = yz; a.in[2] = xy; a.B = B; a.H = H; a.W = W;
     a.w1 = w1; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.feat = feat;
-    // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
-    int rc = RML_ERR_UNSUPPORTED;
-    if (4 * (W / 4) <= 16 * MT_MAX && TrunkLayout(H, W, 4).total <= 80 * 1024) rc = launch_trunk<4>(a, ctx->num_cu, static_cast<hipStream_t>(stream));
-    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<2>(a, ctx->num_cu, static_cast<hipStream_t>(stream));
-    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<1>(a, ctx->num_cu, static_cast<hipStream_t>(stream));
+    const int rc = in_bf16 ? dispatch_trunk<true>(a, ctx->num_cu, static_cast<hipStream_t>(stream))
+                           : dispatch_trunk<false>(a, ctx->num_cu, static_cast<hipStream_t>(stream));
     RML_REQUIRE(rc != RML_ERR_UNSUPPORTED, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: plane %dx%d does not fit the LDS-resident trunk", H, W);
     RML_HIP(hipGetLastError());
     return RML_OK;

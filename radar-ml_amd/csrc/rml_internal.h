@@ -6,6 +6,13 @@
 #include <vector>
 #include "../../include/radarml.h"
 
+// device copy of Pillow's precompute_coeffs() table for one (in, out) size pair (resize.hip)
+struct rml_resize_tab {
+    int in, out, ksize;
+    const int* bounds;      // [out][2] (points into the allocation that starts at kk)
+    const double* kk;       // [out][ksize]
+};
+
 struct rml_ctx {
     int device = 0;
     int num_cu = 256;
@@ -24,6 +31,7 @@ struct rml_ctx {
     std::vector<hipEvent_t> prof_ev;    // start/stop pairs
     size_t prof_used = 0;
     int64_t prof_frames = 0;
+    std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
 };
 
 // records an event on st when profiling is on (no-op otherwise)

@@ -93,18 +93,20 @@ class Classifier(_module_base()):
 
     def features_fused(self, xz, yz, xy):
         """The 38 400-long NHWC feature rows (bf16) of the three conv branches from the fused HIP kernel
-        (csrc/dnn.hip); inputs (N,H,W) or (N,1,H,W) float32 CUDA tensors."""
+        (csrc/dnn.hip); inputs (N,H,W) or (N,1,H,W) CUDA tensors, float32 or bfloat16 (same results)."""
         import torch
         from . import _lib
         lib = _lib.load()
-        xs = [x.reshape(x.shape[0], x.shape[-2], x.shape[-1]).float().contiguous() for x in (xz, yz, xy)]
+        bf = all(x.dtype == torch.bfloat16 for x in (xz, yz, xy))
+        xs = [x.reshape(x.shape[0], x.shape[-2], x.shape[-1]) for x in (xz, yz, xy)]
+        xs = [(x if bf else x.float()).contiguous() for x in xs]
         n, H, W = xs[0].shape
         dev = xs[0].device
         w1, b1, w2t, b2 = self._packed_trunk_weights()
         feat = torch.empty((n, (H // 4) * (W // 4) * 96), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.rml_dnn_trunk(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), n, H, W,
-                                         _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(feat),
+            _lib.check(lib.rml_dnn_trunk(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), 1 if bf else 0,
+                                         n, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(feat),
                                          _lib.stream_ptr(dev)), "rml_dnn_trunk")
         return feat
 
@@ -118,6 +120,21 @@ class Classifier(_module_base()):
             h = F.relu(self.fc2(h))
             lg = self.fc3(h)
         return torch.softmax(lg.float(), dim=-1)
+
+    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192):
+        """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes -> projections (csrc/project.hip)
+        -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused conv trunk (csrc/dnn.hip) ->
+        dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor."""
+        import torch
+        from . import common, nn_common
+        outs = []
+        X, Y, Z = (int(v) for v in volumes.shape[1:])
+        with torch.no_grad():
+            for s0 in range(0, volumes.shape[0], batch_size):
+                feat = common.process_volumes(volumes[s0:s0 + batch_size], mode=mode, scale=False)
+                xz, yz, xy = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
+                outs.append(self.forward_fused(xz, yz, xy))
+        return torch.cat(outs) if outs else torch.zeros((0, self.n_classes), device=volumes.device)
 
     def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""

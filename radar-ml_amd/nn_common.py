@@ -57,17 +57,64 @@ def flatten_nhwc(x):
     return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
 
 
-def preprocess_projections(samples, rescale, device=None):
-    """dnn.py:200-254 / sgan.py:636-690 on the GPU: scale [0,255] -> [-1,1] ((p-127.5)/127.5), resize every
-    projection to ``rescale`` with antialiased bicubic interpolation (the PIL ``Image.BICUBIC`` resize of the
-    reference), return three (N,1,H,W) tensors in (xz, yz, xy) order."""
+def resize_bicubic(planes, out_hw, shape=None, scale=True, out_dtype="float32"):
+    """``Image.fromarray(p).resize((out_w, out_h), Image.BICUBIC)`` for a batch of float32 planes on the GPU
+    (csrc/resize.hip, bit-identical to Pillow), preceded by the reference's [-1,1] scaling ``(p-127.5)/127.5``
+    (dnn.py:202-205) when ``scale``.  ``planes``: (N,H,W) CUDA float32, or an (N, H*W) view into wider rows (e.g.
+    one projection inside feature rows [xz|yz|xy]) together with ``shape=(H, W)``.  Returns (N, out_h, out_w) in
+    float32 or bfloat16 (the conv trunk's operand type)."""
     torch = _torch()
-    import torch.nn.functional as F
+    from . import _lib
+    lib = _lib.load()
+    if planes.dtype != torch.float32 or not planes.is_cuda:
+        raise ValueError("resize_bicubic: CUDA float32 planes expected")
+    if shape is None:
+        if planes.ndim != 3:
+            raise ValueError("resize_bicubic: (N,H,W) planes expected (or pass shape=(H, W))")
+        H, W = int(planes.shape[1]), int(planes.shape[2])
+        flat = planes.reshape(planes.shape[0], H * W) if planes.is_contiguous() else planes.contiguous().reshape(planes.shape[0], H * W)
+    else:
+        H, W = int(shape[0]), int(shape[1])
+        flat = planes
+        if flat.ndim != 2 or flat.shape[1] != H * W:
+            raise ValueError("resize_bicubic: an (N, %d) view expected for shape %s" % (H * W, (H, W)))
+    if flat.shape[0] > 1 and flat.stride(1) != 1:
+        flat = flat.contiguous()
+    n = int(flat.shape[0])
+    stride = int(flat.stride(0)) if n > 1 else H * W
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    dt = getattr(torch, out_dtype) if isinstance(out_dtype, str) else out_dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise ValueError("resize_bicubic: out_dtype must be float32 or bfloat16")
+    out = torch.empty((n, oh, ow), dtype=dt, device=flat.device)
+    with torch.cuda.device(flat.device):
+        _lib.check(lib.rml_resize_bicubic(_lib.context(flat.device), _lib.ptr(flat), stride, n, H, W, oh, ow,
+                                          127.5 if scale else 0.0, 127.5 if scale else 0.0, _lib.ptr(out),
+                                          1 if dt == torch.bfloat16 else 0, _lib.stream_ptr(flat.device)),
+                   "rml_resize_bicubic")
+    return out
+
+
+def preprocess_projections(samples, rescale, device=None, out_dtype="float32"):
+    """dnn.py:200-254 / sgan.py:636-690 on the GPU: scale [0,255] -> [-1,1] ((p-127.5)/127.5), resize every
+    projection to ``rescale`` (PIL's (width, height) order, square in the reference) with Pillow's bicubic resize,
+    return three (N,1,H,W) tensors in (xz, yz, xy) order."""
+    torch = _torch()
     dev = device or torch.device("cuda", torch.cuda.current_device())
     outs = []
     for i in range(3):
         p = torch.from_numpy(np.stack([np.asarray(s[i], dtype=np.float32) for s in samples])).to(dev)
-        p = (p - 127.5) / 127.5
-        p = F.interpolate(p.unsqueeze(1), size=tuple(rescale), mode="bicubic", align_corners=False, antialias=True)
-        outs.append(p.contiguous(memory_format=torch.channels_last))
+        outs.append(resize_bicubic(p, (rescale[1], rescale[0]), out_dtype=out_dtype).unsqueeze(1))
+    return outs
+
+
+def preprocess_features(feat, grid, rescale, out_dtype="bfloat16"):
+    """The same preprocessing straight from unscaled feature rows [xz | yz | xy] of ``process_volumes`` (one kernel
+    per projection, no copies): returns (xz, yz, xy) as (N, H, W) tensors."""
+    X, Y, Z = grid
+    shapes = ((X, Z), (Y, Z), (X, Y))
+    outs, off = [], 0
+    for (h, w) in shapes:
+        outs.append(resize_bicubic(feat[:, off:off + h * w], (rescale[1], rescale[0]), shape=(h, w), out_dtype=out_dtype))
+        off += h * w
     return outs

@@ -287,7 +287,44 @@ def golden_classifier_threshold(predict):
     print("classifier_threshold:", sum(n == "Unknown" for n in names), "Unknown of", len(names))
 
 
+def golden_pil_resize():
+    """The resize in front of the dnn / sgan classifiers exactly as the reference calls it (dnn.py:202-205, 240-245;
+    sgan.py:638-641, 676-681): scale to [-1,1], Image.fromarray(p).resize(RESCALE, resample=Image.BICUBIC).  Inputs
+    are uint8-valued projections of the Walabot arena grid (22, 31, 176); outputs come from Pillow itself."""
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(77)
+    out = {"pillow_version": np.array(PIL.__version__)}
+    X, Y, Z = 22, 31, 176
+    shapes = {"xz": (X, Z), "yz": (Y, Z), "xy": (X, Y)}
+    for name, (h, w) in shapes.items():
+        p = rng.integers(0, 256, size=(2, h, w)).astype(np.uint8)
+        p[0] = (np.add.outer(np.arange(h), np.arange(w)) * 255 // (h + w - 2)).astype(np.uint8)     # a smooth ramp
+        out["in_" + name] = p
+        for tag, rescale in (("80", (80, 80)), ("128", (128, 128))):         # dnn.py:33 / sgan.py RESCALE
+            if tag == "128" and name != "xz":
+                continue
+            res = []
+            for q in p:
+                d = (q - 255.0 / 2.) / (255.0 / 2.)
+                res.append(np.asarray(Image.fromarray(d).resize(rescale, resample=Image.BICUBIC)))
+            out["out%s_%s" % (tag, name)] = np.array(res)
+            assert out["out%s_%s" % (tag, name)].dtype == np.float32
+    # other geometries: pure downscale, pure upscale, one axis unchanged, non-square target (width, height)
+    extra = {"a": ((100, 37), (48, 64)), "b": ((5, 300), (80, 80)), "c": ((80, 31), (80, 80)), "d": ((9, 9), (64, 96))}
+    for k, ((h, w), (oh, ow)) in extra.items():
+        q = rng.uniform(-1, 1, size=(h, w)).astype(np.float32)
+        out["xin_" + k] = q
+        out["xout_" + k] = np.asarray(Image.fromarray(q).resize((ow, oh), resample=Image.BICUBIC))
+        assert out["xout_" + k].shape == (oh, ow)
+    np.savez_compressed(os.path.join(HERE, "pil_resize.npz"), **out)
+    print("pil_resize:", {k: v.shape for k, v in out.items() if k.startswith("out")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pil":      # Pillow-only fixture: does not need /root/reference
+        golden_pil_resize()
+        sys.exit(0)
     common, predict = import_reference()
     golden_index_kats(common)
     golden_common(common, predict)
@@ -300,3 +337,4 @@ if __name__ == "__main__":
     golden_real_xy()
     golden_linear(common)
     golden_classifier_threshold(predict)
+    golden_pil_resize()

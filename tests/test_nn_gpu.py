@@ -26,18 +26,74 @@ def test_dnn_forward_bf16_vs_fp32_cpu(rml):
     assert (got16.argmax(1) == want.argmax(1)).mean() > 0.97
 
 
-def test_preprocess_matches_pil_bicubic(rml):
-    from PIL import Image
+def test_resize_bit_exact_vs_pillow_golden(rml):
+    """csrc/resize.hip against outputs of Pillow itself (tests/golden/pil_resize.npz, the reference's call
+    dnn.py:202-205 + 240-245) and against the oracle on other geometries: bit-exact float32."""
+    from conftest import load_golden
     nc = importlib.import_module("radar_ml_amd.nn_common")
     import oracle_np as O
-    vol, _ = O.synth_volumes(5, 6, 22, 31, 176)
+    g = load_golden("pil_resize.npz")
+    for name in ("xz", "yz", "xy"):
+        p = torch.from_numpy(g["in_" + name].astype(np.float32)).cuda()
+        got = nc.resize_bicubic(p, (80, 80), scale=True)
+        assert got.dtype == torch.float32
+        np.testing.assert_array_equal(got.cpu().numpy(), g["out80_" + name])
+    got = nc.resize_bicubic(torch.from_numpy(g["in_xz"].astype(np.float32)).cuda(), (128, 128), scale=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), g["out128_xz"])
+    for k in "abcd":
+        want = g["xout_" + k]
+        got = nc.resize_bicubic(torch.from_numpy(g["xin_" + k][None]).cuda(), want.shape, scale=False)
+        np.testing.assert_array_equal(got[0].cpu().numpy(), want)
+    # seeded batch vs the oracle, through the strided feature-row front door, float32 and bf16 outputs
+    vol, _ = O.synth_volumes(5, 9, 22, 31, 176)
+    feat = rml.process_volumes(torch.from_numpy(vol).cuda(), mode="max", scale=False)
+    outs = nc.preprocess_features(feat, (22, 31, 176), (80, 80), out_dtype="float32")
+    outs16 = nc.preprocess_features(feat, (22, 31, 176), (80, 80), out_dtype="bfloat16")
+    for b, v in enumerate(vol):
+        for i, pr in enumerate(O.project_max(v)):
+            want = O.pil_resize_bicubic(O.scale_unit_range(pr), (80, 80))
+            np.testing.assert_array_equal(outs[i][b].cpu().numpy(), want)
+            np.testing.assert_array_equal(outs16[i][b].float().cpu().numpy(),
+                                          torch.from_numpy(want).to(torch.bfloat16).float().numpy())
+    # identity size: a copy (ImagingResample skips both passes); empty batch; bad arguments
+    same = nc.resize_bicubic(torch.from_numpy(g["xin_c"][None]).cuda(), (80, 31), scale=False)
+    np.testing.assert_array_equal(same[0].cpu().numpy(), g["xin_c"])
+    assert nc.resize_bicubic(torch.zeros((0, 22, 31), device="cuda"), (80, 80)).shape == (0, 80, 80)
+    with pytest.raises(ValueError):
+        nc.resize_bicubic(torch.zeros((2, 22, 31), device="cuda", dtype=torch.float64), (80, 80))
+
+
+def test_preprocess_projections_reference_layout(rml):
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    import oracle_np as O
+    vol, _ = O.synth_volumes(6, 4, 22, 31, 176)
     samples = [O.project_max(v) for v in vol]
     xz, yz, xy = nc.preprocess_projections(samples, (80, 80))
     for got, idx in ((xz, 0), (yz, 1), (xy, 2)):
+        assert got.shape == (4, 1, 80, 80)
         for b in range(len(samples)):
-            p = (samples[b][idx] - 127.5) / 127.5                 # dnn.py:202-205
-            want = np.asarray(Image.fromarray(p.astype(np.float32)).resize((80, 80), resample=Image.BICUBIC))
-            assert np.abs(got[b, 0].cpu().numpy() - want).max() < 2e-2
+            want = O.pil_resize_bicubic(O.scale_unit_range(samples[b][idx]), (80, 80))      # dnn.py:202-205, 240-245
+            np.testing.assert_array_equal(got[b, 0].cpu().numpy(), want)
+
+
+def test_dnn_predict_volumes_end_to_end(rml):
+    """BASELINE configs[3] as one GPU pipeline (projection -> Pillow resize -> fused trunk -> dense tail) against the
+    CPU chain oracle projection -> oracle resize -> fp32 PyTorch model with the same weights."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    import oracle_np as O
+    torch.manual_seed(11)
+    cpu = dnn.define_classifier(device="cpu").eval()
+    gpu = copy.deepcopy(cpu).to("cuda").eval()
+    vol, _ = O.synth_volumes(9, 24, 22, 31, 176)
+    planes = [[], [], []]
+    for v in vol:
+        for i, pr in enumerate(O.project_max(v)):
+            planes[i].append(O.pil_resize_bicubic(O.scale_unit_range(pr), (80, 80)))
+    want = cpu.predict([np.stack(p)[..., None] for p in planes], autocast_dtype=None)
+    got = gpu.predict_volumes(torch.from_numpy(vol).cuda(), batch_size=16).cpu().numpy()
+    assert got.shape == want.shape == (24, 3)
+    assert np.abs(got - want).max() < 3e-2
+    assert np.allclose(got.sum(1), 1.0, atol=1e-3)
 
 
 def test_sgan_step_fp16_tracks_fp32(rml):
@@ -75,6 +131,8 @@ def test_dnn_fused_trunk_vs_fp32_cpu(rml):
         assert got.shape == want.shape == (37, 38400)
         err = np.abs(got - want)
         assert err.max() <= 2e-2 + 1e-2 * np.abs(want).max() and err.mean() <= 2e-3      # bf16 storage of activations
+        got16 = gpu.features_fused(*[torch.from_numpy(a).cuda().to(torch.bfloat16) for a in x]).float().cpu().numpy()
+        np.testing.assert_array_equal(got16, got)                 # bf16 planes in == float32 planes rounded on load
         p_want = cpu.predict([a[..., None] for a in x], autocast_dtype=None)
         p_got = gpu.forward_fused(*[torch.from_numpy(a).cuda() for a in x]).cpu().numpy()
     assert np.abs(p_got - p_want).max() < 3e-2

@@ -150,3 +150,22 @@ def test_libsvm_pairwise_proba_matches_sklearn():
             dec = -dec               # sklearn flips the sign of the binary pair value; libsvm couples its own
         p = O.libsvm_pairwise_proba(dec, g[tag + "_probA"], g[tag + "_probB"], C)
         np.testing.assert_allclose(p, g[tag + "_proba"], rtol=0, atol=1e-12)
+
+
+def test_pil_bicubic_resize_matches_pillow():
+    """oracle_np.pil_resize_bicubic (restating Pillow's Resample.c) against outputs of Pillow itself for the
+    reference's call (dnn.py:202-205, 240-245; sgan.py): bit-exact float32."""
+    g = load_golden("pil_resize.npz")
+    for name in ("xz", "yz", "xy"):
+        for q, want in zip(g["in_" + name], g["out80_" + name]):
+            got = O.pil_resize_bicubic(O.scale_unit_range(q), (80, 80))
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got, want)
+    for q, want in zip(g["in_xz"], g["out128_xz"]):
+        np.testing.assert_array_equal(O.pil_resize_bicubic(O.scale_unit_range(q), (128, 128)), want)
+    for k in "abcd":
+        want = g["xout_" + k]
+        np.testing.assert_array_equal(O.pil_resize_bicubic(g["xin_" + k], want.shape), want)
+    # coefficient rows are normalised and the windows stay inside the image
+    b, kk = O.pil_resample_coeffs(176, 80)
+    assert kk.shape == (80, 11) and np.allclose(kk.sum(1), 1.0) and (b[:, 0] >= 0).all() and (b.sum(1) <= 176).all()

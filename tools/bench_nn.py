@@ -94,6 +94,35 @@ def main():
                 model.features_fused(*xs)
             torch.cuda.synchronize()
             trunk = (time.perf_counter() - t0) / 10
+        # the all-HIP pipeline: projection -> Pillow-exact resize (bf16 out) -> fused trunk -> dense tail
+        nc = importlib.import_module("radar_ml_amd.nn_common")
+
+        def run_hip():
+            return model.predict_volumes(V, batch_size=bs).argmax(dim=-1)
+
+        def timeit(fn, n=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        with torch.no_grad():
+            t_hip = timeit(run_hip, a.steps // 4 or 1)
+            lab_hip = run_hip()
+            feat = rml.process_volumes(V[:bs], mode="max", scale=False)
+            t_proj = timeit(lambda: rml.process_volumes(V[:bs], mode="max", scale=False))
+            t_res = timeit(lambda: nc.preprocess_features(feat, (X, Y, Z), (80, 80), out_dtype="bfloat16"))
+            x16 = nc.preprocess_features(feat, (X, Y, Z), (80, 80), out_dtype="bfloat16")
+            t_fwd16 = timeit(lambda: model.forward_fused(*x16))
+        print(json.dumps({"what": "configs[3] all-HIP: projection + resize + fused trunk + dense tail", "frames": B, "batch": bs,
+                          "frames_per_s_end_to_end": round(B / t_hip), "ms_total": round(t_hip * 1e3, 2),
+                          "projection_ms": round(t_proj * 1e3, 3), "resize_ms": round(t_res * 1e3, 3),
+                          "forward_ms": round(t_fwd16 * 1e3, 3), "per_batch": bs,
+                          "label_agreement_with_torch_path": round(float((lab_hip == lab).float().mean()), 4)}))
         print(json.dumps({"what": "fused HIP trunk (csrc/dnn.hip) + bf16 dense tail", "batch": bs,
                           "forward_frames_per_s": round(bs / fused), "forward_TFLOPs": round(bs * DNN_FLOP_PER_SAMPLE / fused / 1e12, 1),
                           "trunk_only_frames_per_s": round(bs / trunk), "trunk_ms": round(trunk * 1e3, 3)}))
