@@ -9,8 +9,9 @@
 // weights are computed on the host exactly as Pillow does; the passes run with fp contraction off (separate
 // multiply and add, no fma), so the result is bit-identical to Pillow's (tests/golden/pil_resize.npz).
 //
-// One workgroup per plane: the (scaled) plane, the intermediate and both weight tables live in LDS; input and output
-// are touched once.  Bytes per plane: 4*H*W in, 4 (or 2, bf16 for the conv trunk)*OH*OW out.
+// Persistent workgroups: the weight tables are staged in LDS once, then the workgroup walks its planes; the
+// (scaled) plane and the intermediate live in LDS, the next plane is prefetched into registers meanwhile, input and
+// output are touched once.  In the horizontal pass a thread owns an output column and keeps its weights in registers.  Bytes per plane: 4*H*W in, 4 (or 2, bf16 for the conv trunk)*OH*OW out.
 #include "rml_internal.h"
 #include <math.h>
 #include <vector>
@@ -80,20 +81,32 @@ __device__ __forceinline__ uint16_t f2bf_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
-// one pass of Resample.c over LDS: dst[o][j] (vertical) or dst[j][o] (horizontal) = (float) sum_t src[..] * k[o][t]
-template <bool HORIZ>
-__device__ __forceinline__ float resample_at(const float* src, int src_stride, int line, int o, const int* bnd,
-                                             const double* kk, int ksize) {
-#pragma clang fp contract(off)      // HIP contracts a*b+c into an fma by default, and __dmul_rn/__dadd_rn are plain * and +
-    const int first = bnd[2 * o], n = bnd[2 * o + 1];
-    const double* k = kk + o * ksize;
-    const float* s = HORIZ ? src + line * src_stride + first : src + first * src_stride + line;
-    double ss = 0.0;
-    for (int t = 0; t < n; ++t) ss = ss + (double)s[HORIZ ? t : t * src_stride] * k[t];
-    return (float)ss;
+constexpr int KPAD = 16;        // zeroed floats behind the plane: a register-resident window may overrun its row
+constexpr int PF = 24;          // floats of the next plane a thread prefetches (planes up to 6144 pixels)
+
+// LDS-only barrier: __syncthreads() would also wait for the prefetch of the next plane (vmcnt)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Horizontal pass with the window in registers: a thread owns output column xx (its KS weights never change) and
+// walks the rows; taps past the window have weight 0 and read finite values, which leaves the double sum bit-identical.
+template <int KS>
+__device__ __forceinline__ void horizontal_fixed(const float* in_s, int H, int W, int OW, int first, const double (&k)[KS],
+                                                 int g, int G, int xx, float* tmp_s) {
+#pragma clang fp contract(off)
+    if (g >= G) return;
+    for (int y = g; y < H; y += G) {
+        const float* s = in_s + y * W + first;
+        double ss = 0.0;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) ss = ss + (double)s[t] * k[t];
+        tmp_s[y * OW + xx] = (float)ss;                 // Pillow's float32 intermediate image
+    }
 }
 
+// KS = 0: weights from LDS (any window size)
+template <int KS>
 __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
+#pragma clang fp contract(off)      // HIP contracts a*b+c into an fma by default; Pillow multiplies, then adds
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = a.H, W = a.W, OH = a.OH, OW = a.OW;
     const int tid = threadIdx.x;
@@ -103,9 +116,11 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
     double* kv_s = kh_s + (horiz ? OW * a.ksh : 0);
     int* bh_s = reinterpret_cast<int*>(kv_s + (vert ? OH * a.ksv : 0));
     int* bv_s = bh_s + (horiz ? 2 * OW : 0);
-    float* in_s = reinterpret_cast<float*>(bv_s + (vert ? 2 * OH : 0));
-    float* tmp_s = in_s + H * W;                    // [H][OW] (only when both passes run)
+    float* in_s = reinterpret_cast<float*>(bv_s + (vert ? 2 * OH : 0));      // [H*W + KPAD]
+    float* tmp_s = in_s + H * W + KPAD;                                      // [H][OW] (only when both passes run)
 
+    // persistent workgroup: the tables are staged once, planes blockIdx.x, +gridDim.x, ... follow, and while one
+    // plane is resampled the next one is already in flight into registers
     if (horiz) {
         for (int i = tid; i < OW * a.ksh; i += 256) kh_s[i] = a.kh[i];
         for (int i = tid; i < 2 * OW; i += 256) bh_s[i] = a.bh[i];
@@ -114,44 +129,140 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
         for (int i = tid; i < OH * a.ksv; i += 256) kv_s[i] = a.kv[i];
         for (int i = tid; i < 2 * OH; i += 256) bv_s[i] = a.bv[i];
     }
-    const int64_t b = blockIdx.x;
-    const float* __restrict__ src = a.in + b * a.in_stride;
-    const bool scaled = a.div != 0.0f;
-    for (int i = tid; i < H * W; i += 256) {
-        const float v = src[i];
-        in_s[i] = scaled ? __fdiv_rn(v - a.sub, a.div) : v;
-    }
+    if (tid < KPAD) in_s[H * W + tid] = 0.0f;
     __syncthreads();
-    const float* cur = in_s;
-    int cur_w = W;
-    const float inv_ow = 1.0f / (float)OW;
-    if (horiz) {
-        float* dst = tmp_s;
-        for (int i = tid; i < H * OW; i += 256) {
-            int y = (int)(((float)i + 0.5f) * inv_ow);
-            y = y * OW > i ? y - 1 : ((y + 1) * OW <= i ? y + 1 : y);
-            const int xx = i - y * OW;
-            dst[i] = resample_at<true>(in_s, W, y, xx, bh_s, kh_s, a.ksh);
-        }
-        __syncthreads();
-        cur = dst;
-        cur_w = OW;
+    // the thread's column of the horizontal pass
+    const int G = OW <= 256 ? 256 / OW : 0;
+    const int hg = G ? tid / OW : 0, hx = tid - hg * OW;
+    constexpr int KR = KS > 0 ? KS : 1;
+    double kreg[KR];
+    int hfirst = 0;
+    if (KS > 0 && horiz && hg < G) {
+        hfirst = bh_s[2 * hx];
+#pragma unroll
+        for (int t = 0; t < KR; ++t) kreg[t] = t < a.ksh ? kh_s[hx * a.ksh + t] : 0.0;
     }
-    float* outf = reinterpret_cast<float*>(a.out) + b * (int64_t)OH * OW;
-    uint16_t* outh = reinterpret_cast<uint16_t*>(a.out) + b * (int64_t)OH * OW;
-    for (int i = tid; i < OH * OW; i += 256) {
-        float v;
-        if (vert) {
-            int yy = (int)(((float)i + 0.5f) * inv_ow);
-            yy = yy * OW > i ? yy - 1 : ((yy + 1) * OW <= i ? yy + 1 : yy);
-            const int xx = i - yy * OW;
-            v = resample_at<false>(cur, cur_w, xx, yy, bv_s, kv_s, a.ksv);
+    const int npix = H * W;
+    const bool prefetch = npix <= 256 * PF;
+    const bool scaled = a.div != 0.0f;
+    float pv[PF];
+    auto issue = [&](int64_t bb) {
+        const float* __restrict__ src = a.in + bb * a.in_stride;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = u * 256 + tid;
+            pv[u] = src[i < npix ? i : npix - 1];
+        }
+    };
+    if (prefetch) issue(blockIdx.x);
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (prefetch) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int i = u * 256 + tid;
+                if (i < npix) in_s[i] = scaled ? __fdiv_rn(pv[u] - a.sub, a.div) : pv[u];
+            }
+            const int64_t nb = b + gridDim.x;
+            issue(nb < a.B ? nb : b);
         } else {
-            v = cur[i];
+            const float* __restrict__ src = a.in + b * a.in_stride;
+            for (int i0 = 0; i0 < npix; i0 += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256 + tid;
+                    v[u] = src[i < npix ? i : npix - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256 + tid;
+                    if (i < npix) in_s[i] = scaled ? __fdiv_rn(v[u] - a.sub, a.div) : v[u];
+                }
+            }
         }
-        if (a.out_bf16) outh[i] = f2bf_rne(v);
-        else outf[i] = v;
+        lds_barrier();
+
+        float* outf = reinterpret_cast<float*>(a.out) + b * (int64_t)OH * OW;
+        uint16_t* outh = reinterpret_cast<uint16_t*>(a.out) + b * (int64_t)OH * OW;
+        auto emit = [&](int i, float v) {
+            if (a.out_bf16) outh[i] = f2bf_rne(v);
+            else outf[i] = v;
+        };
+        const float* cur = in_s;
+        if (horiz) {
+            if (KS > 0 && vert) {
+                horizontal_fixed<KR>(in_s, H, W, OW, hfirst, kreg, hg, G, hx, tmp_s);
+            } else {
+                const int dq = 256 / OW, dr = 256 - dq * OW;
+                int y = tid / OW, xx = tid - y * OW;
+                for (int i = tid; i < H * OW; i += 256) {
+                    const int first = bh_s[2 * xx], n = bh_s[2 * xx + 1];
+                    const float* s = in_s + y * W + first;
+                    const double* k = kh_s + xx * a.ksh;
+                    double ss = 0.0;
+                    for (int t = 0; t < n; ++t) ss = ss + (double)s[t] * k[t];
+                    if (vert) tmp_s[i] = (float)ss;
+                    else emit(i, (float)ss);            // width only: straight to the output
+                    y += dq; xx += dr;
+                    if (xx >= OW) { xx -= OW; ++y; }
+                }
+            }
+            if (vert) lds_barrier();
+            cur = tmp_s;
+        }
+        if (!vert) {
+            if (!horiz)             // no pass at all: Image.resize returns a copy
+                for (int i = tid; i < OH * OW; i += 256) emit(i, cur[i]);
+        } else if ((OW & 1) == 0) {
+            // vertical pass: a thread produces (yy, xx) and (yy, xx + OW/2) from one read of the row's weights
+            const int HW2 = OW >> 1;
+            const int dq = 256 / HW2, dr = 256 - dq * HW2;
+            int yy = tid / HW2, xx = tid - yy * HW2;
+            for (int i = tid; i < OH * HW2; i += 256) {
+                const int first = bv_s[2 * yy], n = bv_s[2 * yy + 1];
+                const float* s = cur + first * OW + xx;
+                const double* k = kv_s + yy * a.ksv;
+                double s0 = 0.0, s1 = 0.0;
+                for (int t = 0; t < n; ++t) {
+                    const double kt = k[t];
+                    s0 = s0 + (double)s[t * OW] * kt;
+                    s1 = s1 + (double)s[t * OW + HW2] * kt;
+                }
+                emit(yy * OW + xx, (float)s0);
+                emit(yy * OW + xx + HW2, (float)s1);
+                yy += dq; xx += dr;
+                if (xx >= HW2) { xx -= HW2; ++yy; }
+            }
+        } else {
+            const int dq = 256 / OW, dr = 256 - dq * OW;
+            int yy = tid / OW, xx = tid - yy * OW;
+            for (int i = tid; i < OH * OW; i += 256) {
+                const int first = bv_s[2 * yy], n = bv_s[2 * yy + 1];
+                const float* s = cur + first * OW + xx;
+                const double* k = kv_s + yy * a.ksv;
+                double ss = 0.0;
+                for (int t = 0; t < n; ++t) ss = ss + (double)s[t * OW] * k[t];
+                emit(i, (float)ss);
+                yy += dq; xx += dr;
+                if (xx >= OW) { xx -= OW; ++yy; }
+            }
+        }
+        lds_barrier();          // the plane and the intermediate are free for the next sample
     }
+}
+
+template <int KS>
+void launch_resize(const ResizeArgs& a, size_t lds, int num_cu, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resize<KS>, 256, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int64_t slots = (int64_t)per_cu * num_cu;
+    hipLaunchKernelGGL(k_resize<KS>, dim3((unsigned)(a.B < slots ? a.B : slots)), dim3(256), lds, st, a);
 }
 
 // device copy of an axis table, cached in the context (a handful of (in, out) pairs per process)
@@ -188,21 +299,25 @@ extern "C" int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stri
     ResizeArgs a{};
     a.in = in; a.in_stride = in_stride; a.B = B; a.H = H; a.W = W; a.OH = out_h; a.OW = out_w;
     a.sub = sub; a.div = div; a.out = out; a.out_bf16 = out_bf16 ? 1 : 0;
-    size_t lds = (size_t)H * W * 4;
+    size_t lds = ((size_t)H * W + KPAD) * 4;
     if (out_w != W) {
         int rc = axis_table(ctx, W, out_w, &a.bh, &a.kh, &a.ksh);
         if (rc != RML_OK) return rc;
-        lds += (size_t)out_w * a.ksh * 8 + (size_t)out_w * 8 + (size_t)H * out_w * 4;
+        lds += (size_t)out_w * a.ksh * 8 + (size_t)out_w * 8;
     }
     if (out_h != H) {
         int rc = axis_table(ctx, H, out_h, &a.bv, &a.kv, &a.ksv);
         if (rc != RML_OK) return rc;
         lds += (size_t)out_h * a.ksv * 8 + (size_t)out_h * 8;
     }
+    if (out_w != W && out_h != H) lds += (size_t)H * out_w * 4;
     RML_REQUIRE(lds <= 150 * 1024, RML_ERR_UNSUPPORTED, "rml_resize_bicubic: %dx%d -> %dx%d does not fit the LDS-resident resize", H, W, out_h, out_w);
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
-    hipLaunchKernelGGL(k_resize, dim3((unsigned)B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool fixed = out_w != W && out_h != H && out_w <= 256;
+    if (fixed && a.ksh <= 6) launch_resize<6>(a, lds, ctx->num_cu, st);
+    else if (fixed && a.ksh <= 12) launch_resize<12>(a, lds, ctx->num_cu, st);
+    else if (fixed && a.ksh <= KPAD) launch_resize<KPAD>(a, lds, ctx->num_cu, st);
+    else launch_resize<0>(a, lds, ctx->num_cu, st);
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
