@@ -17,8 +17,10 @@
  *     documented "host".  The library never frees caller memory.
  *   - launches are asynchronous on the caller's hipStream_t (passed as void*; NULL =
  *     the default stream).  A context is bound to one device.
- *   - layouts: volumes V[b][i][j][k] float32, C-contiguous, (x=theta index i,
- *     y=phi index j, z=range index k).  Feature rows are [xz | yz | xy] (the tuple
+ *   - layouts: volumes V[b][i][j][k], C-contiguous, (x=theta index i, y=phi index j,
+ *     z=range index k); element type float32 (vdtype RML_VOL_F32) or uint8 (RML_VOL_U8: the
+ *     radar's native 0..255 magnitudes as stored by the data sets -- a quarter of the HBM
+ *     bytes; results are identical to the float32 path on the same values).  Feature rows are [xz | yz | xy] (the tuple
  *     order of common.py:40), each plane C-order, i.e. exactly
  *     np.concatenate((xz, yz, xy), axis=None) of common.py:146.
  */
@@ -49,6 +51,10 @@ typedef struct rml_linear rml_linear;
 #define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V        */
 #define RML_MODE_SLICE 1   /* reference-faithful plane slices through (i,j,k): predict.py:102-107       */
 #define RML_MODE_SUM   2   /* sum-projection (the reductions of common.py:51-53), float32 accumulation  */
+
+/* element type of the volumes */
+#define RML_VOL_F32    0
+#define RML_VOL_U8     1
 
 /* projection mask bits, positional order of common.ProjMask (common.py:40) */
 #define RML_MASK_XZ 1u
@@ -104,7 +110,7 @@ int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask);
  *   row_flags            B int32 or NULL: 1 iff every selected value of the row is an
  *            integer in [0,255] (the exact-integer SVM path may then be used)
  */
-int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+int rml_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                 const int32_t* ijk, float scale_div, uint32_t mask,
                 float* feat, int64_t ld_feat,
                 uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
@@ -112,7 +118,7 @@ int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, in
 
 /* The three planes as separate arrays (B,X,Z) (B,Y,Z) (B,X,Y); any may be NULL.
  * Same modes; no scaling.  (The tuple a reference caller packs at predict.py:113.) */
-int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+int rml_project_planes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, float* xz, float* yz, float* xy, void* stream);
 
 /* DerivedTarget.get_derived_targets, common.py:49-80, batched: the three energy
@@ -122,7 +128,7 @@ int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, in
  *                                     zipped as common.py:80)
  *   profiles B*(X+Y+Z) float32 or NULL: [s_theta | s_phi | s_r] per frame
  */
-int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z,
+int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                        int num_targets, int32_t* ijk, float* profiles, void* stream);
 
 /* Assemble feature rows from already separate projection planes (the list-of-tuples
@@ -195,7 +201,7 @@ int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, 
 /* Fused front door: volumes -> projection (mode, mask fixed at load: D must match) ->
  * SVM outputs, features never returned to the caller.  Workspace is owned by the ctx and
  * grows on demand. */
-int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, int64_t B, int X, int Y, int Z,
+int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                     int mode, const int32_t* ijk, float scale_div, uint32_t mask,
                     double* dec_ovo, double* dec_ovr, double* proba,
                     int32_t* label_vote, int32_t* label_calib, void* stream);

@@ -34,11 +34,11 @@ SIGNATURES = {
     "rml_profile_enable": (c_int, [c_void_p, c_int]),
     "rml_profile_read": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_int64)]),
     "rml_feature_len": (c_int64, [c_int, c_int, c_int, c_uint32]),
-    "rml_project": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
+    "rml_project": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rml_project_planes": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+    "rml_project_planes": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rml_assemble_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                       c_uint32, c_void_p, c_int64, c_void_p]),
     "rml_zoom_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_float,
@@ -54,7 +54,7 @@ SIGNATURES = {
     "rml_svm_decision": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_svm_pairwise_proba": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
+    "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                 c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_linear_load": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, C.POINTER(c_void_p)]),
     "rml_linear_free": (c_int, [c_void_p, c_void_p]),
@@ -69,6 +69,7 @@ SIGNATURES = {
 }
 
 MODE_MAX, MODE_SLICE, MODE_SUM = 0, 1, 2
+VOL_F32, VOL_U8 = 0, 1
 MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM}
 KERNEL_RBF, KERNEL_LINEAR = 0, 1
 PATH_AUTO, PATH_F32, PATH_I8, PATH_F64 = 0, 1, 2, 3

@@ -93,6 +93,21 @@ def _as_device_f32(a, device=None):
     return t.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
 
 
+def _as_device_volumes(a, device=None):
+    """Volumes for the projection entry points: uint8 stays uint8 (the radar's native magnitudes, a quarter of the
+    HBM bytes, same results), everything else becomes float32.  Returns (contiguous CUDA tensor, RML_VOL_* code)."""
+    torch = _torch()
+    is_u8 = (a.dtype == torch.uint8) if isinstance(a, torch.Tensor) else (np.asarray(a).dtype == np.uint8)
+    if not is_u8:
+        return _as_device_f32(a, device), _lib.VOL_F32
+    if not torch.cuda.is_available():
+        raise _lib.RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    if device is None:
+        device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return t.to(device=device, non_blocking=True).contiguous(), _lib.VOL_U8
+
+
 def project(volumes, mode="max", ijk=None, return_numpy=None):
     """Batched 3-D -> 2-D projections: returns the reference's tuple ``(xz, yz, xy)``.
 
@@ -108,7 +123,7 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
     if return_numpy is None:
         return_numpy = is_np
     single = (volumes.ndim == 3)
-    v = _as_device_f32(volumes)
+    v, vdt = _as_device_volumes(volumes)
     if single:
         v = v.unsqueeze(0)
     if v.ndim != 4:
@@ -133,7 +148,7 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
     yz = torch.empty((B, Y, Z), dtype=torch.float32, device=dev)
     xy = torch.empty((B, X, Y), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.rml_project_planes(ctx, _lib.ptr(v), B, X, Y, Z, m, _lib.ptr(ijk_t), _lib.ptr(xz), _lib.ptr(yz),
+        _lib.check(lib.rml_project_planes(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), _lib.ptr(xz), _lib.ptr(yz),
                                           _lib.ptr(xy), _lib.stream_ptr(dev)), "rml_project_planes")
     out = (xz, yz, xy)
     if single:
@@ -151,7 +166,7 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
     """
     torch = _torch()
     lib = _lib.load()
-    v = _as_device_f32(volumes)
+    v, vdt = _as_device_volumes(volumes)
     if v.ndim == 3:
         v = v.unsqueeze(0)
     B, X, Y, Z = v.shape
@@ -177,7 +192,7 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
         isq = torch.empty((B,), dtype=torch.int64, device=dev)
         flags = torch.empty((B,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.rml_project(ctx, _lib.ptr(v), B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
+        _lib.check(lib.rml_project(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
                                    bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                    _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
     if codes:
@@ -265,7 +280,7 @@ def derive_targets(volumes, num_targets=1, return_profiles=False):
     (i,j,k) triples, ascending by energy; optionally the three energy profiles."""
     torch = _torch()
     lib = _lib.load()
-    v = _as_device_f32(volumes)
+    v, vdt = _as_device_volumes(volumes)
     if v.ndim == 3:
         v = v.unsqueeze(0)
     B, X, Y, Z = v.shape
@@ -274,7 +289,7 @@ def derive_targets(volumes, num_targets=1, return_profiles=False):
     ijk = torch.empty((B, num_targets, 3), dtype=torch.int32, device=dev)
     prof = torch.empty((B, X + Y + Z), dtype=torch.float32, device=dev) if return_profiles else None
     with torch.cuda.device(dev):
-        _lib.check(lib.rml_derive_targets(ctx, _lib.ptr(v), B, X, Y, Z, int(num_targets), _lib.ptr(ijk), _lib.ptr(prof),
+        _lib.check(lib.rml_derive_targets(ctx, _lib.ptr(v), vdt, B, X, Y, Z, int(num_targets), _lib.ptr(ijk), _lib.ptr(prof),
                                           _lib.stream_ptr(dev)), "rml_derive_targets")
     if return_profiles:
         return ijk, prof

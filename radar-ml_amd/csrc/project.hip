@@ -33,7 +33,7 @@ namespace {
 constexpr int kThreads = 256;
 
 struct ProjParams {
-    const float* V;
+    const void* V;      // float32 or uint8 voxels (template VT of the kernels)
     int64_t B;
     int X, Y, Z, ZQ;
     const int32_t* ijk;
@@ -177,6 +177,20 @@ __device__ __forceinline__ float4 ld_stream(const float4* p) {
 #endif
 }
 
+// uint8 volumes (the radar's native 0..255 magnitudes, 4x fewer HBM bytes): a lane's quad is one dword,
+// widened with v_cvt_f32_ubyte0..3; everything downstream is the float path, so the results are identical
+__device__ __forceinline__ float4 ld_stream(const uint32_t* p) {
+#ifdef RML_NO_NT
+    const uint32_t w = *p;
+#else
+    const uint32_t w = __builtin_nontemporal_load(p);
+#endif
+    return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
+}
+template <typename VT> struct Quad;
+template <> struct Quad<float> { typedef float4 T; };
+template <> struct Quad<uint8_t> { typedef uint32_t T; };
+
 // butterfly reduction over the LPR lanes of a row (all lanes end with the result)
 template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r) {
 #pragma unroll
@@ -193,7 +207,7 @@ template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r
 // Loads are ALWAYS unconditional: padded rows / lanes re-read a valid neighbour (clamped offset) and
 // are neutralised afterwards (a duplicate is harmless for max; sum selects 0) -- a conditional load
 // makes hipcc branch around every load and drain vmcnt per element, which de-pipelines the stream.
-template <int MODE, int LPR, int NM, bool FULL, bool PRED>
+template <typename VT, int MODE, int LPR, int NM, bool FULL, bool PRED>
 __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     extern __shared__ __align__(16) float lds[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     const int kq = lane % LPR;
     const bool act = FULL || (kq < ZQ);
     const int64_t b = blockIdx.x;
-    const float4* __restrict__ Vb = reinterpret_cast<const float4*>(a.V + b * (int64_t)X * Y * Z);
+    typedef typename Quad<VT>::T QT;
+    const QT* __restrict__ Vb = reinterpret_cast<const QT*>(static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z);
 
     const float id = Op<MODE>::ident();
     const float4 id4 = make_float4(id, id, id, id);
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
 
 #pragma unroll 2
     for (int i = 0; i < X; ++i) {
-        const float4* __restrict__ Vi = Vb + (int64_t)i * plane;
+        const QT* __restrict__ Vi = Vb + (int64_t)i * plane;
         float4 cur[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) cur[m] = ld_stream(Vi + roff[m]);
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
 // combined in-lane over m and across the R row slots with LDS float atomics, xy is a segmented reduction over
 // the contiguous lanes of a row (rows straddle wave boundaries, so segment heads finish with an LDS atomic).
 // ------------------------------------------------------------------------------------------
-template <int MODE, int NM, bool PRED>
+template <typename VT, int MODE, int NM, bool PRED>
 __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) {
     extern __shared__ __align__(16) float lds[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
@@ -306,7 +321,8 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int slot = tid / ZQ, kq = tid - slot * ZQ;
     const int64_t b = blockIdx.x;
-    const float4* __restrict__ Vb = reinterpret_cast<const float4*>(a.V + b * (int64_t)X * Y * Z);
+    typedef typename Quad<VT>::T QT;
+    const QT* __restrict__ Vb = reinterpret_cast<const QT*>(static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z);
     const float id = Op<MODE>::ident();
     const float4 id4 = make_float4(id, id, id, id);
     for (int idx = tid; idx < X * Z; idx += T) xz_lds[idx] = id;
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
 
 #pragma unroll 2
     for (int i = 0; i < X; ++i) {
-        const float4* __restrict__ Vi = Vb + (int64_t)i * plane;
+        const QT* __restrict__ Vi = Vb + (int64_t)i * plane;
         float4 cur[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) cur[m] = ld_stream(Vi + roff[m]);
@@ -386,13 +402,13 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
 // Generic fallback: any (X,Y,Z).  Three coalesced passes over the frame (L2 resident after
 // the first), no shape restrictions.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <typename VT, int MODE>
 __global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
     __shared__ int64_t red[64];
     if (a.o.skip_if_set && *a.o.skip_if_set) return;
     const int X = a.X, Y = a.Y, Z = a.Z;
     const int64_t b = blockIdx.x;
-    const float* __restrict__ Vb = a.V + b * (int64_t)X * Y * Z;
+    const VT* __restrict__ Vb = static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Emitter em(a, b);
     const float id = Op<MODE>::ident();
@@ -400,19 +416,19 @@ __global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
     for (int idx = tid; idx < X * Z; idx += kThreads) {
         int i = idx / Z, k = idx - i * Z;
         float r = id;
-        for (int j = 0; j < Y; ++j) r = Op<MODE>::f(r, Vb[((int64_t)i * Y + j) * Z + k]);
+        for (int j = 0; j < Y; ++j) r = Op<MODE>::f(r, (float)Vb[((int64_t)i * Y + j) * Z + k]);
         em.put1(0, idx, r);
     }
     // yz[j,k] = op_i V[i,j,k]
     for (int idx = tid; idx < Y * Z; idx += kThreads) {
         float r = id;
-        for (int i = 0; i < X; ++i) r = Op<MODE>::f(r, Vb[(int64_t)i * Y * Z + idx]);
+        for (int i = 0; i < X; ++i) r = Op<MODE>::f(r, (float)Vb[(int64_t)i * Y * Z + idx]);
         em.put1(1, idx, r);
     }
     // xy[i,j] = op_k V[i,j,k]: one wave per row
     for (int row = wave; row < X * Y; row += kThreads / 64) {
         float r = id;
-        for (int k = lane; k < Z; k += 64) r = Op<MODE>::f(r, Vb[(int64_t)row * Z + k]);
+        for (int k = lane; k < Z; k += 64) r = Op<MODE>::f(r, (float)Vb[(int64_t)row * Z + k]);
         r = row_reduce<MODE, 64>(r);
         if (lane == 0) em.put1(2, row, r);
     }
@@ -422,12 +438,13 @@ __global__ __launch_bounds__(kThreads) void k_project_generic(ProjParams a) {
 // ------------------------------------------------------------------------------------------
 // Slice mode: planes through (i,j,k) of each frame, Python negative-index wrap.
 // ------------------------------------------------------------------------------------------
+template <typename VT>
 __global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
     __shared__ int64_t red[64];
     if (a.o.skip_if_set && *a.o.skip_if_set) return;
     const int X = a.X, Y = a.Y, Z = a.Z;
     const int64_t b = blockIdx.x;
-    const float* __restrict__ Vb = a.V + b * (int64_t)X * Y * Z;
+    const VT* __restrict__ Vb = static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z;
     int i = a.ijk[b * 3 + 0], j = a.ijk[b * 3 + 1], k = a.ijk[b * 3 + 2];
     i = i < 0 ? i + X : i; j = j < 0 ? j + Y : j; k = k < 0 ? k + Z : k;
     // out-of-range after wrapping would raise IndexError in the reference; clamp defensively
@@ -436,12 +453,12 @@ __global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
     Emitter em(a, b);
     for (int idx = tid; idx < X * Z; idx += kThreads) {          // xz = V[:, j, :]
         int ii = idx / Z, kk = idx - ii * Z;
-        em.put1(0, idx, Vb[((int64_t)ii * Y + j) * Z + kk]);
+        em.put1(0, idx, (float)Vb[((int64_t)ii * Y + j) * Z + kk]);
     }
     for (int idx = tid; idx < Y * Z; idx += kThreads)            // yz = V[i, :, :]
-        em.put1(1, idx, Vb[(int64_t)i * Y * Z + idx]);
+        em.put1(1, idx, (float)Vb[(int64_t)i * Y * Z + idx]);
     for (int idx = tid; idx < X * Y; idx += kThreads)            // xy = V[:, :, k]
-        em.put1(2, idx, Vb[(int64_t)idx * Z + k]);
+        em.put1(2, idx, (float)Vb[(int64_t)idx * Z + k]);
     em.finish(red);
 }
 
@@ -509,53 +526,53 @@ __global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const fl
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-template <int MODE, int LPR, int NM, bool FULL>
+template <typename VT, int MODE, int LPR, int NM, bool FULL>
 void launch_fast_pred(const ProjParams& pp, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block(kThreads);
     // > 64 KB of dynamic LDS needs the attribute (gfx950 has 160 KB per CU); harmless otherwise
     if (pp.o.skip_if_set) {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, FULL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, FULL, true>), grid, block, lds_bytes, st, pp);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<VT, MODE, LPR, NM, FULL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<VT, MODE, LPR, NM, FULL, true>), grid, block, lds_bytes, st, pp);
     } else {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<MODE, LPR, NM, FULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_fast<MODE, LPR, NM, FULL, false>), grid, block, lds_bytes, st, pp);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<VT, MODE, LPR, NM, FULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_fast<VT, MODE, LPR, NM, FULL, false>), grid, block, lds_bytes, st, pp);
     }
 }
 
-template <int MODE, int LPR>
+template <typename VT, int MODE, int LPR>
 int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t st) {
     constexpr int NSLOT = 4 * (64 / LPR);
     if (nm > 8) return 1;
     const int NMr = nm <= 4 ? 4 : 8;
     const bool full = (pp.ZQ == LPR) && (pp.Y == NMr * NSLOT);
-    if (NMr == 4) { if (full) launch_fast_pred<MODE, LPR, 4, true>(pp, lds_bytes, st); else launch_fast_pred<MODE, LPR, 4, false>(pp, lds_bytes, st); }
-    else          { if (full) launch_fast_pred<MODE, LPR, 8, true>(pp, lds_bytes, st); else launch_fast_pred<MODE, LPR, 8, false>(pp, lds_bytes, st); }
+    if (NMr == 4) { if (full) launch_fast_pred<VT, MODE, LPR, 4, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 4, false>(pp, lds_bytes, st); }
+    else          { if (full) launch_fast_pred<VT, MODE, LPR, 8, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 8, false>(pp, lds_bytes, st); }
     return 0;
 }
 
-template <int MODE, int NM>
+template <typename VT, int MODE, int NM>
 void launch_rowgroup(const ProjParams& pp, int R, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block((unsigned)(R * pp.ZQ));
     if (pp.o.skip_if_set) {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<MODE, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_rowgroup<MODE, NM, true>), grid, block, lds_bytes, st, pp, R);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<VT, MODE, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_rowgroup<VT, MODE, NM, true>), grid, block, lds_bytes, st, pp, R);
     } else {
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<MODE, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-        hipLaunchKernelGGL((k_project_rowgroup<MODE, NM, false>), grid, block, lds_bytes, st, pp, R);
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<VT, MODE, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_rowgroup<VT, MODE, NM, false>), grid, block, lds_bytes, st, pp, R);
     }
 }
 
 int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
-template <int MODE>
+template <typename VT, int MODE>
 int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
     const int X = pp.X, Y = pp.Y, Z = pp.Z;
     *used_fast = false;
-    bool fast_ok = (Z % 4 == 0) && (Z / 4 <= 64) && ((reinterpret_cast<uintptr_t>(pp.V) & 15) == 0);
+    bool fast_ok = (Z % 4 == 0) && (Z / 4 <= 64) && ((reinterpret_cast<uintptr_t>(pp.V) & (4 * sizeof(VT) - 1)) == 0);
     size_t lds_bytes = ((size_t)X * Z + (((size_t)X * Y + 3) & ~(size_t)3)) * 4 + 64 * 8;
     if (lds_bytes > 150 * 1024) fast_ok = false;
     static const bool allow_rowgroup = [] { const char* e = getenv("RML_ROWGROUP"); return !e || atoi(e) != 0; }();
@@ -566,9 +583,9 @@ int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
         while (R * zq < 512 && 2 * R * zq <= 1024 && 2 * R <= Y) R *= 2;
         if (R * zq <= 1024) {
             const int nm = (Y + R - 1) / R;
-            if (nm <= 2) { launch_rowgroup<MODE, 2>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
-            if (nm <= 4) { launch_rowgroup<MODE, 4>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
-            if (nm <= 8) { launch_rowgroup<MODE, 8>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+            if (nm <= 2) { launch_rowgroup<VT, MODE, 2>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+            if (nm <= 4) { launch_rowgroup<VT, MODE, 4>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
+            if (nm <= 8) { launch_rowgroup<VT, MODE, 8>(pp, R, lds_bytes, st); *used_fast = true; return 0; }
         }
     }
     if (fast_ok) {
@@ -577,16 +594,16 @@ int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
         int nslot = 4 * (64 / lpr);
         int nm = (Y + nslot - 1) / nslot;
         int rc = 1;
-        if (lpr == 16) rc = launch_fast_nm<MODE, 16>(pp, nm, lds_bytes, st);
-        else if (lpr == 32) rc = launch_fast_nm<MODE, 32>(pp, nm, lds_bytes, st);
-        else rc = launch_fast_nm<MODE, 64>(pp, nm, lds_bytes, st);
+        if (lpr == 16) rc = launch_fast_nm<VT, MODE, 16>(pp, nm, lds_bytes, st);
+        else if (lpr == 32) rc = launch_fast_nm<VT, MODE, 32>(pp, nm, lds_bytes, st);
+        else rc = launch_fast_nm<VT, MODE, 64>(pp, nm, lds_bytes, st);
         if (rc == 0) { *used_fast = true; return 0; }
     }
-    hipLaunchKernelGGL((k_project_generic<MODE>), dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
+    hipLaunchKernelGGL((k_project_generic<VT, MODE>), dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
     return 0;
 }
 
-void fill_params(ProjParams& pp, const float* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
+void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
     pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.o = o;
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
@@ -594,21 +611,31 @@ void fill_params(ProjParams& pp, const float* V, int64_t B, int X, int Y, int Z,
 
 }  // namespace
 
-int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
-                       const int32_t* ijk, const ProjOut& o, hipStream_t st) {
-    (void)ctx;
-    if (B == 0) return RML_OK;
-    ProjParams pp;
-    fill_params(pp, V, B, X, Y, Z, ijk, o);
+namespace {
+template <typename VT>
+int launch_project_t(const ProjParams& pp, int mode, hipStream_t st) {
     bool fast = false;
-    if (mode == RML_MODE_MAX) launch_mode<RML_MODE_MAX>(pp, st, &fast);
-    else if (mode == RML_MODE_SUM) launch_mode<RML_MODE_SUM>(pp, st, &fast);
+    if (mode == RML_MODE_MAX) launch_mode<VT, RML_MODE_MAX>(pp, st, &fast);
+    else if (mode == RML_MODE_SUM) launch_mode<VT, RML_MODE_SUM>(pp, st, &fast);
     else if (mode == RML_MODE_SLICE) {
-        RML_REQUIRE(ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
-        hipLaunchKernelGGL(k_project_slice, dim3((unsigned)B), dim3(kThreads), 0, st, pp);
+        RML_REQUIRE(pp.ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
+        hipLaunchKernelGGL(k_project_slice<VT>, dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
     } else {
         RML_REQUIRE(false, RML_ERR_INVALID, "rml_project: unknown mode %d", mode);
     }
+    return RML_OK;
+}
+}  // namespace
+
+int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
+                       const int32_t* ijk, const ProjOut& o, hipStream_t st) {
+    (void)ctx;
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project: unknown volume dtype %d", vdtype);
+    ProjParams pp;
+    fill_params(pp, V, B, X, Y, Z, ijk, o);
+    const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, st) : launch_project_t<float>(pp, mode, st);
+    if (rc) return rc;
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
@@ -622,7 +649,7 @@ extern "C" int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask) {
     return d;
 }
 
-extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+extern "C" int rml_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                            const int32_t* ijk, float scale_div, uint32_t mask,
                            float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
                            int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
@@ -651,10 +678,10 @@ extern "C" int rml_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y
     o.qrow = feat_q; o.qD = D;
     o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
     o.scale_div = scale_div;
-    return rml_launch_project(ctx, V, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
+    return rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+extern "C" int rml_project_planes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                                   const int32_t* ijk, float* xz, float* yz, float* xy, void* stream) {
     RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project_planes: bad arguments");
     if (B == 0) return RML_OK;
@@ -667,10 +694,10 @@ extern "C" int rml_project_planes(rml_ctx* ctx, const float* V, int64_t B, int X
     o.p[2] = xy; o.stride[2] = (int64_t)X * Y;
     o.sel = (xz ? 1u : 0u) | (yz ? 2u : 0u) | (xy ? 4u : 0u);
     o.scale_div = 0.0f;
-    return rml_launch_project(ctx, V, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
+    return rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z,
+extern "C" int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                                   int num_targets, int32_t* ijk, float* profiles, void* stream) {
     RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_derive_targets: bad arguments");
     if (B == 0) return RML_OK;
@@ -692,7 +719,7 @@ extern "C" int rml_derive_targets(rml_ctx* ctx, const float* V, int64_t B, int X
     o.p[1] = yzs; o.stride[1] = (int64_t)Y * Z;
     o.sel = 3u;
     o.scale_div = 0.0f;
-    rc = rml_launch_project(ctx, V, B, X, Y, Z, RML_MODE_SUM, nullptr, o, st);
+    rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, RML_MODE_SUM, nullptr, o, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_profiles_topk, dim3((unsigned)B), dim3(64), (size_t)(X + Y + Z) * sizeof(float), st,
                        xzs, yzs, X, Y, Z, num_targets, ijk, profiles);

@@ -80,7 +80,7 @@ struct ProjOut {
     const int32_t* skip_if_set;
 };
 
-int rml_launch_project(rml_ctx* ctx, const float* V, int64_t B, int X, int Y, int Z, int mode,
+int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st);
 
 // ---- SVM (svm.hip) ------------------------------------------------------------------------

@@ -891,13 +891,14 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
 }
 
 // ---- fused front door: volumes -> projection -> SVM ---------------------------------------
-extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, int64_t B, int X, int Y, int Z,
+extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                                int mode, const int32_t* ijk, float scale_div, uint32_t mask,
                                double* dec_ovo, double* dec_ovr, double* proba,
                                int32_t* label_vote, int32_t* label_calib, void* stream) {
     RML_REQUIRE(ctx && m && B >= 0, RML_ERR_INVALID, "rml_project_svm: bad arguments");
     if (B == 0) return RML_OK;
     RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project_svm: V is NULL");
+    RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project_svm: unknown volume dtype %d", vdtype);
     RML_REQUIRE(rml_feature_len(X, Y, Z, mask) == m->D, RML_ERR_INVALID, "rml_project_svm: grid/mask give D=%lld, model has D=%lld",
                 (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
@@ -944,12 +945,12 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
-        const float* Vc = V + r0 * frame_elems;
+        const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
             rml_prof_mark(ctx, st);
-            rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, o, st);
+            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, st);
             rml_prof_mark(ctx, st);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
@@ -969,7 +970,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const float* V, i
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
         if (!grid_ok) rml_prof_mark(ctx, st);
-        rc = rml_launch_project(ctx, Vc, n, X, Y, Z, mode, ijkc, of, st);
+        rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, of, st);
         if (!grid_ok) { rml_prof_mark(ctx, st); if (ctx->profiling) ctx->prof_frames += n; }
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));

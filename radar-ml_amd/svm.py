@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .common import ProjMask, RADAR_MAX, _as_device_f32, _mask_bits
+from .common import ProjMask, RADAR_MAX, _as_device_f32, _as_device_volumes, _mask_bits
 
 
 def _torch():
@@ -144,7 +144,7 @@ class GpuSVC(_Base):
         Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib])."""
         torch = _torch()
         lib = _lib.load()
-        v = _as_device_f32(volumes)
+        v, vdt = _as_device_volumes(volumes)
         if v.ndim == 3:
             v = v.unsqueeze(0)
         B, X, Y, Z = v.shape
@@ -170,7 +170,7 @@ class GpuSVC(_Base):
             out["label_calib"] = torch.empty((B,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.rml_project_svm(
-                self._ctx, self._h, _lib.ptr(v), B, X, Y, Z, _lib.MODES[mode], _lib.ptr(ijk_t),
+                self._ctx, self._h, _lib.ptr(v), vdt, B, X, Y, Z, _lib.MODES[mode], _lib.ptr(ijk_t),
                 float(RADAR_MAX) if scale else 0.0, _mask_bits(proj_mask),
                 _lib.ptr(out["dec_ovo"]), _lib.ptr(out["dec_ovr"]), _lib.ptr(out.get("proba")),
                 _lib.ptr(out["label_vote"]), _lib.ptr(out.get("label_calib")), _lib.stream_ptr(dev)), "rml_project_svm")

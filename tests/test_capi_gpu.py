@@ -16,15 +16,17 @@ def test_error_codes_and_messages(rml):
     feat = torch.empty((2, 4 * 8 + 4 * 8 + 16), device="cuda")
     st = _lib.stream_ptr()
     # empty mask, NULL volume, ld too small, slice without ijk, unknown mode
-    assert lib.rml_project(ctx, _lib.ptr(v), 2, 4, 4, 8, 0, None, 0.0, 0, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 0, None, 0.0, 0, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
     assert b"mask" in lib.rml_last_error()
-    assert lib.rml_project(ctx, None, 2, 4, 4, 8, 0, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
-    assert lib.rml_project(ctx, _lib.ptr(v), 2, 4, 4, 8, 0, None, 0.0, 7, _lib.ptr(feat), 5, None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, None, 0, 2, 4, 4, 8, 0, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 0, None, 0.0, 7, _lib.ptr(feat), 5, None, 0, None, None, None, st) == -1
     assert b"ld_feat" in lib.rml_last_error()
-    assert lib.rml_project(ctx, _lib.ptr(v), 2, 4, 4, 8, 1, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
-    assert lib.rml_project(ctx, _lib.ptr(v), 2, 4, 4, 8, 9, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 1, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 9, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert lib.rml_project(ctx, _lib.ptr(v), 5, 2, 4, 4, 8, 0, None, 0.0, 7, _lib.ptr(feat), feat.stride(0), None, 0, None, None, None, st) == -1
+    assert b"dtype" in lib.rml_last_error()
     # B == 0 is a no-op even with NULL pointers
-    assert lib.rml_project(ctx, None, 0, 4, 4, 8, 0, None, 0.0, 7, None, 0, None, 0, None, None, None, st) == 0
+    assert lib.rml_project(ctx, None, 0, 0, 4, 4, 8, 0, None, 0.0, 7, None, 0, None, 0, None, None, None, st) == 0
     # model load validation
     sv = np.zeros((4, 8)); dc = np.zeros((2, 4)); ic = np.zeros(3); h = C.c_void_p()
     ns_bad = np.array([1, 1, 1], dtype=np.int32)
@@ -40,7 +42,7 @@ def test_error_codes_and_messages(rml):
     pr = torch.empty((3, 3), dtype=torch.float64, device="cuda")
     # proba without calibrators -> state error; wrong D for the fused door -> invalid
     assert lib.rml_svm_decision(ctx, h, 0, _lib.ptr(x), 8, None, 0, None, None, None, 3, _lib.ptr(dec), None, _lib.ptr(pr), None, None, st) == -5
-    assert lib.rml_project_svm(ctx, h, _lib.ptr(v), 2, 4, 4, 8, 0, None, 255.0, 7, _lib.ptr(dec), None, None, None, None, st) == -1
+    assert lib.rml_project_svm(ctx, h, _lib.ptr(v), 0, 2, 4, 4, 8, 0, None, 255.0, 7, _lib.ptr(dec), None, None, None, None, st) == -1
     assert b"D=" in lib.rml_last_error()
     assert lib.rml_svm_decision(ctx, h, 0, _lib.ptr(x), 8, None, 0, None, None, None, 3, _lib.ptr(dec), None, None, None, None, st) == 0
     torch.cuda.synchronize()

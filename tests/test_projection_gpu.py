@@ -237,3 +237,30 @@ def test_random_shapes_property(rml):
         np.testing.assert_array_equal(f, O.features_from_projections(xz, yz, xy, tuple(mask), True))
 
     check()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_uint8_volumes_give_identical_results(rml, shape):
+    """uint8 ingest (the radar's native 0..255 magnitudes, datasets/README.md:8-20): every projection mode, the
+    fused feature rows with codes and statistics, and the derived targets are bit-identical to the float32 path
+    on the same values, and equal to the oracle."""
+    import torch
+    X, Y, Z = shape
+    vf = _vol(21, 6, X, Y, Z)                      # integer-valued float32
+    v8 = vf.astype(np.uint8)
+    assert np.array_equal(v8.astype(np.float32), vf)
+    for mode in ("max", "sum"):
+        for g, w in zip(rml.project(v8, mode=mode), rml.project(vf, mode=mode)):
+            np.testing.assert_array_equal(g, w)
+    for g, w in zip(rml.project(v8, mode="max"), O.project_max(vf)):
+        np.testing.assert_array_equal(g, w)
+    ijk = np.array([[0, 0, 0], [X - 1, Y - 1, Z - 1], [-1, -1, -1], [1 % X, 2 % Y, 3 % Z], [0, Y - 1, 0], [X - 1, 0, Z - 1]])
+    for g, w in zip(rml.project(v8, mode="slice", ijk=ijk), rml.project(vf, mode="slice", ijk=ijk)):
+        np.testing.assert_array_equal(g, w)
+    a = rml.process_volumes(torch.from_numpy(v8).cuda(), mode="max", scale=True, codes=True)
+    b = rml.process_volumes(torch.from_numpy(vf).cuda(), mode="max", scale=True, codes=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[4].min()) == 1                   # every row is on the code grid
+    if min(X, Y, Z) >= 2:
+        assert torch.equal(rml.derive_targets(v8, 2), rml.derive_targets(vf, 2))

@@ -3,6 +3,7 @@
 Bar (BASELINE.json north_star): class labels bit-exact, decision-function scores within 1e-5."""
 import numpy as np
 import pytest
+import torch
 
 import oracle_np as O
 from conftest import load_golden, svm_model_arrays
@@ -152,6 +153,10 @@ def test_fused_volumes_to_labels(rml, name, shape):
     assert np.abs(out["proba"].cpu().numpy() - g["proba"]).max() <= TOL
     np.testing.assert_array_equal(m["classes"][out["label_vote"].cpu().numpy()], g["label_vote"])
     np.testing.assert_array_equal(m["classes"][out["label_calib"].cpu().numpy()], g["label_calib"])
+    # the fixture's volumes as they are stored (uint8): the same bits as the float32 ingest
+    out8 = svc.decide_volumes(g["test_vol_u8"], mode="max", proj_mask=mask, scale=True)
+    for k in ("dec_ovo", "dec_ovr", "proba", "label_vote", "label_calib"):
+        assert torch.equal(out8[k], out[k]), k
     # a frame with a non-integer return drops its tile to the f32 path; results stay within tolerance
     vol2 = vol.copy()
     vol2[3, 0, 0, 0] = 0.5

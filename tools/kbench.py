@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--svs", type=int, default=2048)
     ap.add_argument("--path", default="i8")
     ap.add_argument("--mode", default="max")
+    ap.add_argument("--u8", action="store_true", help="uint8 volumes (1 byte per voxel)")
     a = ap.parse_args()
     import torch
     import radar_ml_amd as rml
@@ -55,13 +56,19 @@ def main():
         print(json.dumps({"what": "torch amax (read only)", "bytes": 4 * n, "ms": med, "GBs": 4 * n / med / 1e6}))
         return
     V, cls = rml.synth_volumes(B, X, Y, Z, seed=1)
+    esz = 4
+    if a.u8:
+        V = V.to(torch.uint8)
+        esz = 1
     if a.what == "proj":
         feat = torch.empty((B, D), dtype=torch.float32, device=dev)
         res = []
+        qb = (D + 127) // 128 * 128
+        q = torch.empty((B, qb), dtype=torch.uint8, device=dev)
         for label, kw, outbytes in [("f32 rows", dict(out=feat), 4 * D), ("f32 rows /255", dict(out=feat, scale=True), 4 * D),
                                     ("f32 rows + codes", dict(out=feat, codes=True), 4 * D + (D + 127) // 128 * 128)]:
             med, mn, mean = timeit(torch, lambda: rml.process_volumes(V, mode=a.mode, **kw), a.iters)
-            alg = B * (4 * X * Y * Z + outbytes)
+            alg = B * (esz * X * Y * Z + outbytes)
             res.append({"what": "project %s %s" % (a.mode, label), "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4),
                         "ms_min": round(mn, 4), "frames_per_s": round(B / med * 1e3), "alg_GBs": round(alg / med / 1e6, 1),
                         "frac_of_8TBs": round(alg / med / 1e6 / 8000, 4)})
