@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-walabot", action="store_true", help="skip the secondary Walabot-arena-grid workload")
+    ap.add_argument("--no-u8", action="store_true", help="skip the uint8-ingest row (the same frames as 1-byte voxels)")
     ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -150,6 +151,56 @@ def run_workload(a, env, grid, frames, primary):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- the same frames as uint8 volumes (the radar's native magnitudes): a separate
+    #      roofline row, 1 byte per voxel.  Same model, same step, labels must be identical. -----------------
+    u8 = None
+    if not a.no_u8:
+        V8 = V.to(torch.uint8)
+
+        def step8():
+            o = svc.decide_volumes(V8, mode="max", scale=True, want_proba=True)
+            if world > 1:
+                o["all_labels"] = rdist.gather_labels(o["label_calib"])
+            return o
+
+        out8 = step8()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        lib.rml_profile_enable(ctx, 1)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out8 = step8()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt8 = time.perf_counter() - t0
+        nl8, ms8, nf8 = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+        lib.rml_profile_read(ctx, ctypes.byref(nl8), ctypes.byref(ms8), ctypes.byref(nf8))
+        lib.rml_profile_enable(ctx, 0)
+        t8 = torch.tensor([dt8], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+        dt8 = float(t8.item())
+        same = bool(torch.equal(out8["label_calib"], out["label_calib"]) and torch.equal(out8["label_vote"], out["label_vote"])
+                    and torch.equal(out8["dec_ovo"], out["dec_ovo"]))
+        l8 = max(1, nl8.value)
+        a8 = ms8.value / l8
+        ach8 = (X * Y * Z + 16) * (nf8.value / l8) / (a8 * 1e-3) / 1e9 if a8 > 0 else 0.0
+        u8 = {"value": round(world * B * a.steps / dt8, 1), "unit": "frames/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3),
+              "workload": "the same %d frames/GPU as uint8 volumes (1 byte per voxel)" % B,
+              "identical_to_f32_ingest": same,
+              "hbm_frac_end_to_end": round(B * a.steps / dt8 * (X * Y * Z + 16) / 1e9 / HBM_PEAK_GBS, 4),
+              "roofline": {"bound": "hbm", "kernel": "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>",
+                           "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach8 / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(l8),
+                           "avg_launch_ms": round(a8, 4), "frames_per_launch": nf8.value / l8,
+                           "algorithmic_bytes_per_frame": X * Y * Z + 16}}
+        del V8, out8
+        torch.cuda.empty_cache()
+
     if rank != 0:
         del V, out, svc
         torch.cuda.empty_cache()
@@ -226,7 +277,7 @@ def run_workload(a, env, grid, frames, primary):
                    "gamma": a.gamma, "parallelism": "frames sharded x%d, labels all-gathered (RCCL)" % world
                    if world > 1 else "single GPU"},
         "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "uint8_ingest": u8,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
     del V, out, svc
@@ -273,7 +324,7 @@ def main():
             "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
             "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
             "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "parity": res["parity"],
-            "model": res["model"],
+            "uint8_ingest": res["uint8_ingest"], "model": res["model"],
         }
         if wal is not None:
             line["walabot_grid"] = wal
