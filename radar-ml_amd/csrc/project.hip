@@ -568,9 +568,16 @@ bool try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
     const int nm = (Y + S - 1) / S;
     const size_t lds_bytes = (size_t)X * Z + (((size_t)X * Y + 15) & ~(size_t)15) + (size_t)4 * Y * Z + 64 * 8 + 64;
     if (nm > 8 || lds_bytes > 150 * 1024) return false;
-    if (nm <= 2) launch_u8_max<2>(pp, CPR, S, lds_bytes, st);
-    else if (nm <= 4) launch_u8_max<4>(pp, CPR, S, lds_bytes, st);
-    else launch_u8_max<8>(pp, CPR, S, lds_bytes, st);
+    switch (nm) {       // rows per lane and plane: exact, so that no lane re-reads rows it does not need
+        case 1: launch_u8_max<1>(pp, CPR, S, lds_bytes, st); break;
+        case 2: launch_u8_max<2>(pp, CPR, S, lds_bytes, st); break;
+        case 3: launch_u8_max<3>(pp, CPR, S, lds_bytes, st); break;
+        case 4: launch_u8_max<4>(pp, CPR, S, lds_bytes, st); break;
+        case 5: launch_u8_max<5>(pp, CPR, S, lds_bytes, st); break;
+        case 6: launch_u8_max<6>(pp, CPR, S, lds_bytes, st); break;
+        case 7: launch_u8_max<7>(pp, CPR, S, lds_bytes, st); break;
+        default: launch_u8_max<8>(pp, CPR, S, lds_bytes, st); break;
+    }
     return true;
 }
 
