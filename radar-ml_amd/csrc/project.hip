@@ -430,11 +430,13 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane / CPR, c = lane - s * CPR;
     const int64_t b = blockIdx.x;
-    // LDS: xz [X][Z], xy [X*Y] (dense), yz [4 waves][Y][Z], reduction scratch
-    unsigned char* xz_s = lds8;
+    // LDS: yz [4 waves][Y][Z], xz [X][Z], xy [X*Y] (dense).  The reduction scratch of Emitter::finish lies over yz
+    // (finish synchronises before it writes): two of these workgroups and one k_svm_gemm workgroup (72.7 KB) then
+    // fit a CU together at 64x64x128, which is what lets the fused pipeline overlap them.
+    unsigned char* yz_s = lds8;
+    unsigned char* xz_s = yz_s + (size_t)4 * Y * Z;
     unsigned char* xy_s = xz_s + (size_t)X * Z;
-    unsigned char* yz_s = xy_s + (((size_t)X * Y + 15) & ~(size_t)15);
-    int64_t* red = reinterpret_cast<int64_t*>(yz_s + (size_t)4 * Y * Z);
+    int64_t* red = reinterpret_cast<int64_t*>(lds8);
     const uint4* __restrict__ Vb = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(a.V) + b * (int64_t)X * Y * Z);
     const int plane = Y * CPR;          // uint4 per x-plane
 
@@ -566,7 +568,8 @@ bool try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
     if (!allow || Z % 16 != 0 || Z / 16 > 64 || (reinterpret_cast<uintptr_t>(pp.V) & 15) != 0) return false;
     const int CPR = Z / 16, S = 64 / CPR;
     const int nm = (Y + S - 1) / S;
-    const size_t lds_bytes = (size_t)X * Z + (((size_t)X * Y + 15) & ~(size_t)15) + (size_t)4 * Y * Z + 64 * 8 + 64;
+    size_t lds_bytes = (size_t)X * Z + (((size_t)X * Y + 15) & ~(size_t)15) + (size_t)4 * Y * Z;
+    if (lds_bytes < 64 * 8 + 64) lds_bytes = 64 * 8 + 64;      // Emitter::finish scratch
     if (nm > 8 || lds_bytes > 150 * 1024) return false;
     switch (nm) {       // rows per lane and plane: exact, so that no lane re-reads rows it does not need
         case 1: launch_u8_max<1>(pp, CPR, S, lds_bytes, st); break;

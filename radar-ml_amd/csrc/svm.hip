@@ -627,7 +627,10 @@ template <typename T> int dev_upload(T** dst, const std::vector<T>& h) {
 
 template <int PATH>
 int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
-    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + 2 * m->PT) * sizeof(double);
+    // RML_GEMM_LDS_EXTRA pads the request (experiment knob: > 8 KB leaves one GEMM workgroup per CU, so that the
+    // HBM-bound projection of the next chunk keeps its wave slots while the two overlap)
+    static const size_t lds_extra = [] { const char* e = getenv("RML_GEMM_LDS_EXTRA"); long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 * 1024 ? v : 0); }();
+    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + 2 * m->PT) * sizeof(double) + lds_extra;
     const int FT8 = (int)round_up(ga.FT, 8);
     dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
 #define RML_GEMM_CASE(PTV)                                                                                         \
@@ -635,7 +638,7 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
         static bool attr_done = false;                                                                             \
         if (!attr_done) {                                                                                          \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm<PATH, PTV>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);                     \
             attr_done = true;                                                                                      \
         }                                                                                                          \
         hipLaunchKernelGGL((k_svm_gemm<PATH, PTV>), grid, block, lds, st, ga);                                     \
