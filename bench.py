@@ -189,13 +189,20 @@ def run_workload(a, env, grid, frames, primary):
         l8 = max(1, nl8.value)
         a8 = ms8.value / l8
         ach8 = (X * Y * Z + 16) * (nf8.value / l8) / (a8 * 1e-3) / 1e9 if a8 > 0 else 0.0
+        tr8 = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pj.get("grid") == [X, Y, Z] and abs(pj.get("u8_project_frames_per_launch", 0) - nf8.value / l8) < 1:
+                tr8 = pj.get("u8_project_hbm_bytes_per_launch")
+        except Exception:
+            tr8 = None
         u8 = {"value": round(world * B * a.steps / dt8, 1), "unit": "frames/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3),
               "workload": "the same %d frames/GPU as uint8 volumes (1 byte per voxel)" % B,
               "identical_to_f32_ingest": same,
               "hbm_frac_end_to_end": round(B * a.steps / dt8 * (X * Y * Z + 16) / 1e9 / HBM_PEAK_GBS, 4),
               "roofline": {"bound": "hbm", "kernel": "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>",
                            "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach8 / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(l8),
+                           "frac": round(ach8 / HBM_PEAK_GBS, 4), "traffic": tr8, "launches": int(l8),
                            "avg_launch_ms": round(a8, 4), "frames_per_launch": nf8.value / l8,
                            "algorithmic_bytes_per_frame": X * Y * Z + 16}}
         del V8, out8

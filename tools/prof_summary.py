@@ -63,14 +63,17 @@ def pmc(fetch_db, write_db):
         hbm = 2.0 * fk * 1024 + wk * 1024
         print("%-70s %10d %6d %16.1f %16.1f %12.1f %16.0f" % (k[0][:70], k[1], len(f or w), fk, wk, du, hbm))
         summary["%s|grid=%d" % k] = {"fetch_kb": fk, "write_kb": wk, "avg_us": du, "hbm_bytes_corrected": hbm}
-    proj = [v for k, v in summary.items() if k.startswith("k_project_fast") and v["fetch_kb"] > 1e5]
-    if proj:
-        best = max(proj, key=lambda v: v["fetch_kb"])
-        best_grid = [int(k.split("grid=")[1]) for k, v in summary.items() if v is best][0]
-        grid = [int(t) for t in os.environ.get("RML_PMC_GRID", "64x64x128").split("x")]
-        fpl = best_grid // 256
-        json.dump({"project_hbm_bytes_per_launch": best["hbm_bytes_corrected"], "grid": grid, "frames_per_launch": fpl, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                   "2x FETCH correction for gfx950", "kernels": summary}, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    grid = [int(t) for t in os.environ.get("RML_PMC_GRID", "64x64x128").split("x")]
+    doc = {"grid": grid, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction for gfx950", "kernels": summary}
+    for prefix, key in (("k_project_fast", "project_hbm_bytes_per_launch"), ("k_project_u8_max", "u8_project_hbm_bytes_per_launch")):
+        proj = {k: v for k, v in summary.items() if k.startswith(prefix) and v["fetch_kb"] > 1e5}
+        if proj:
+            bk = max(proj, key=lambda k: proj[k]["fetch_kb"])
+            doc[key] = proj[bk]["hbm_bytes_corrected"]
+            doc[key.replace("hbm_bytes_per_launch", "frames_per_launch")] = int(bk.split("grid=")[1]) // 256
+    if "project_frames_per_launch" in doc:
+        doc["frames_per_launch"] = doc["project_frames_per_launch"]
+    json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
