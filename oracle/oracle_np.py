@@ -542,3 +542,55 @@ def pil_resize_bicubic(img, out_hw):
 def scale_unit_range(p, radar_max=255.0):
     """dnn.py:202-205 / sgan.py:638-641: (p - RADAR_MAX/2) / (RADAR_MAX/2), stored as float32 by Image.fromarray."""
     return ((np.asarray(p, dtype=np.float64) - radar_max / 2.0) / (radar_max / 2.0)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Multi-view CNN forward (dnn.py:45-91), Keras semantics restated in NumPy float64.  "Parity unpinned": the
+# reference ships no weights and TensorFlow is not installable here, so this pins the layer semantics (TF 'same'
+# padding, NHWC flatten order, branch order) for the PyTorch module and the HIP trunk, not trained outputs.
+# Weights in Keras layout: conv kernels (kh, kw, cin, cout), dense kernels (in, out).
+# ----------------------------------------------------------------------------------------------------------------
+def keras_conv2d_same_s2_relu(x, kernel, bias):
+    """Conv2D(filters, (3,3), strides=(2,2), padding='same', activation='relu') on NHWC input (dnn.py:47-50).
+    TF 'same': out = ceil(in/2), total pad = max((out-1)*2 + 3 - in, 0), pad_before = total // 2 (the extra row /
+    column goes to the bottom / right)."""
+    x = np.asarray(x, np.float64)
+    n, h, w, cin = x.shape
+    kh, kw, _, cout = kernel.shape
+    oh, ow = -(-h // 2), -(-w // 2)
+    ph = max((oh - 1) * 2 + kh - h, 0)
+    pw = max((ow - 1) * 2 + kw - w, 0)
+    xp = np.zeros((n, h + ph, w + pw, cin))
+    xp[:, ph // 2:ph // 2 + h, pw // 2:pw // 2 + w, :] = x
+    out = np.zeros((n, oh, ow, cout))
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky:ky + 2 * oh:2, kx:kx + 2 * ow:2, :]          # (n, oh, ow, cin)
+            out += patch @ np.asarray(kernel[ky, kx], np.float64)
+    return np.maximum(out + np.asarray(bias, np.float64), 0.0)
+
+
+def dnn_conv_features(xz, yz, xy, conv_weights):
+    """create_conv_layers on each input, Concatenate()([xz, yz, xy]) on the channel axis, Flatten (dnn.py:68-76):
+    (N, H/4 * W/4 * 96) rows in (h, w, c) order.  conv_weights: per branch (k1, b1, k2, b2)."""
+    outs = []
+    for x, (k1, b1, k2, b2) in zip((xz, yz, xy), conv_weights):
+        x = np.asarray(x, np.float64)
+        if x.ndim == 3:
+            x = x[..., None]
+        outs.append(keras_conv2d_same_s2_relu(keras_conv2d_same_s2_relu(x, k1, b1), k2, b2))
+    cat = np.concatenate(outs, axis=-1)
+    return cat.reshape(cat.shape[0], -1)
+
+
+def dnn_forward(xz, yz, xy, conv_weights, dense_weights):
+    """define_classifier forward at inference (dropout inactive): Dense 64 relu, Dense 64 relu, Dense n softmax
+    (dnn.py:78-88).  dense_weights: [(kernel (in,out), bias)] * 3."""
+    h = dnn_conv_features(xz, yz, xy, conv_weights)
+    (w1, c1), (w2, c2), (w3, c3) = dense_weights
+    h = np.maximum(h @ w1 + c1, 0.0)
+    h = np.maximum(h @ w2 + c2, 0.0)
+    z = h @ w3 + c3
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=1, keepdims=True)

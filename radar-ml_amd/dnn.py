@@ -76,6 +76,21 @@ class Classifier(_module_base()):
         import torch
         return torch.softmax(self.logits(xz, yz, xy).float(), dim=-1)
 
+    def keras_weights(self):
+        """The parameters in Keras layout (conv kernels (kh,kw,cin,cout), dense kernels (in,out)) as float64 numpy:
+        (conv_weights per branch [(k1,b1,k2,b2)], dense_weights [(kernel,bias)]*3) -- what ``model.get_weights()``
+        of the reference's Keras model holds, and what the oracle's restatement takes."""
+        def k(conv):
+            return conv.weight.detach().double().permute(2, 3, 1, 0).cpu().numpy(), conv.bias.detach().double().cpu().numpy()
+        convs = []
+        for br in self.branches:
+            k1, b1 = k(br[0].conv)
+            k2, b2 = k(br[1].conv)
+            convs.append((k1, b1, k2, b2))
+        dense = [(fc.weight.detach().double().t().cpu().numpy(), fc.bias.detach().double().cpu().numpy())
+                 for fc in (self.fc1, self.fc2, self.fc3)]
+        return convs, dense
+
     # ---- fused HIP trunk -------------------------------------------------------------------------------
     def _packed_trunk_weights(self):
         """conv weights in the layout of rml_dnn_trunk (cached; invalidate by deleting ``_trunk_pack``)."""

@@ -116,3 +116,28 @@ def test_sgan_ddp_gloo_two_ranks_keep_replicas_in_sync():
         p.join(timeout=60)
         assert p.exitcode == 0
     np.testing.assert_array_equal(res[0], res[1])      # all-reduced gradients -> identical replicas
+
+
+def test_dnn_module_matches_numpy_oracle(mods):
+    """The PyTorch module against the NumPy restatement of the Keras layers (oracle_np.dnn_forward, dnn.py:45-91):
+    same weights, odd and even sizes ('same' padding differs between them), float32 vs float64."""
+    import oracle_np as O
+    dnn, _, _ = mods
+    rng = np.random.default_rng(3)
+    for (h, w) in ((80, 80), (22, 31), (9, 12)):
+        torch.manual_seed(h)
+        m = dnn.Classifier([(h, w, 1)] * 3, 3).eval()
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)):
+                torch.nn.init.normal_(mod.bias, 0.0, 0.1)
+        convs, dense = m.keras_weights()
+        assert convs[0][0].shape == (3, 3, 1, 64) and convs[0][2].shape == (3, 3, 64, 32) and dense[0][0].shape[1] == 64
+        x = [rng.uniform(-1, 1, (4, h, w)).astype(np.float32) for _ in range(3)]
+        want_f = O.dnn_conv_features(*x, convs)
+        with torch.no_grad():
+            got_f = m.features(*[torch.from_numpy(a).unsqueeze(1) for a in x]).numpy()
+        assert got_f.shape == want_f.shape
+        assert np.abs(got_f - want_f).max() < 1e-4
+        want_p = O.dnn_forward(*x, convs, dense)
+        got_p = m.predict([a[..., None] for a in x], autocast_dtype=None)
+        assert np.abs(got_p - want_p).max() < 1e-5

@@ -133,6 +133,10 @@ def test_dnn_fused_trunk_vs_fp32_cpu(rml):
         assert err.max() <= 2e-2 + 1e-2 * np.abs(want).max() and err.mean() <= 2e-3      # bf16 storage of activations
         got16 = gpu.features_fused(*[torch.from_numpy(a).cuda().to(torch.bfloat16) for a in x]).float().cpu().numpy()
         np.testing.assert_array_equal(got16, got)                 # bf16 planes in == float32 planes rounded on load
+        import oracle_np as O                                      # and against the NumPy restatement of the Keras layers
+        convs, dense = cpu.keras_weights()
+        want_np = O.dnn_conv_features(x[0][:8], x[1][:8], x[2][:8], convs)
+        assert np.abs(got[:8] - want_np).max() <= 2e-2 + 1e-2 * np.abs(want_np).max()
         p_want = cpu.predict([a[..., None] for a in x], autocast_dtype=None)
         p_got = gpu.forward_fused(*[torch.from_numpy(a).cuda() for a in x]).cpu().numpy()
     assert np.abs(p_got - p_want).max() < 3e-2
