@@ -540,8 +540,14 @@ def pil_resize_bicubic(img, out_hw):
 
 
 def scale_unit_range(p, radar_max=255.0):
-    """dnn.py:202-205 / sgan.py:638-641: (p - RADAR_MAX/2) / (RADAR_MAX/2), stored as float32 by Image.fromarray."""
-    return ((np.asarray(p, dtype=np.float64) - radar_max / 2.0) / (radar_max / 2.0)).astype(np.float32)
+    """dnn.py:202-205 / sgan.py:638-641: (p - RADAR_MAX/2.) / (RADAR_MAX/2.) with NumPy's dtype rules -- a float32
+    projection stays float32 through both operations (Python scalars do not widen it), anything else goes through
+    float64 -- then Image.fromarray stores float32 ('F' mode)."""
+    p = np.asarray(p)
+    if p.dtype == np.float32:
+        h = np.float32(radar_max / 2.0)
+        return ((p - h) / h).astype(np.float32)
+    return ((p.astype(np.float64) - radar_max / 2.0) / (radar_max / 2.0)).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------------------------------------------

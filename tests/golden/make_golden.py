@@ -287,6 +287,37 @@ def golden_classifier_threshold(predict):
     print("classifier_threshold:", sum(n == "Unknown" for n in names), "Unknown of", len(names))
 
 
+def golden_generated_data(common):
+    """The only sample data the reference ships in its own data-set format (datasets/README.md:8-20):
+    train-results/sgan/generated_data_{0230,1035}.pickle.save -- GAN output, i.e. NON-integer float32 projections of
+    the Walabot arena grid.  A few samples of each with what the reference computes from them: common.process_samples
+    (all masks on, scale on/off; common.py:123-149) and the dnn preprocessing (dnn.py:202-205, 240-245 via Pillow)."""
+    import pickle
+    from PIL import Image
+    xs, tags = [], []
+    for name in ("generated_data_0230", "generated_data_1035"):
+        with open(os.path.join(REF, "train-results", "sgan", name + ".pickle.save"), "rb") as fp:
+            d = pickle.load(fp)
+        assert set(d.keys()) == {"samples", "labels"} and len(d["samples"]) == 100
+        for idx in (0, 57):
+            xs.append(tuple(np.asarray(p) for p in d["samples"][idx]))
+            tags.append("%s[%d] label=%s" % (name, idx, d["labels"][idx]))
+    out = {"tags": np.array(tags)}
+    for i, nm in enumerate(("xz", "yz", "xy")):
+        out[nm] = np.stack([s[i] for s in xs])
+        assert out[nm].dtype == np.float32
+    pm = common.ProjMask(xz=True, yz=True, xy=True)
+    out["feat_scale0"] = common.process_samples(xs, proj_mask=pm, scale=False)
+    out["feat_scale1"] = common.process_samples(xs, proj_mask=pm, scale=True)
+    res = []
+    for s in xs[:2]:
+        res.append(np.stack([np.asarray(Image.fromarray((p - 255.0 / 2.) / (255.0 / 2.)).resize((80, 80), resample=Image.BICUBIC))
+                             for p in s]))
+    out["dnn_inputs_80"] = np.stack(res)                 # (2, 3, 80, 80): xz, yz, xy of the first two samples
+    np.savez_compressed(os.path.join(HERE, "generated_data.npz"), **out)
+    print("generated_data:", {k: v.shape for k, v in out.items()})
+
+
 def golden_pil_resize():
     """The resize in front of the dnn / sgan classifiers exactly as the reference calls it (dnn.py:202-205, 240-245;
     sgan.py:638-641, 676-681): scale to [-1,1], Image.fromarray(p).resize(RESCALE, resample=Image.BICUBIC).  Inputs
@@ -326,6 +357,9 @@ if __name__ == "__main__":
         golden_pil_resize()
         sys.exit(0)
     common, predict = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "generated":
+        golden_generated_data(common)
+        sys.exit(0)
     golden_index_kats(common)
     golden_common(common, predict)
     golden_svm(common, "svm_small.npz", 8, 10, 16, 500, 120, 256, gamma=0.05)
@@ -338,3 +372,4 @@ if __name__ == "__main__":
     golden_linear(common)
     golden_classifier_threshold(predict)
     golden_pil_resize()
+    golden_generated_data(common)

@@ -55,6 +55,11 @@ def test_resize_bit_exact_vs_pillow_golden(rml):
             np.testing.assert_array_equal(outs[i][b].cpu().numpy(), want)
             np.testing.assert_array_equal(outs16[i][b].float().cpu().numpy(),
                                           torch.from_numpy(want).to(torch.bfloat16).float().numpy())
+    # the reference's own non-integer float32 sample data (generated_data_*.pickle.save), scaled as NumPy scales float32
+    gd = load_golden("generated_data.npz")
+    for i, nm in enumerate(("xz", "yz", "xy")):
+        got = nc.resize_bicubic(torch.from_numpy(gd[nm][:2]).cuda(), (80, 80), scale=True)
+        np.testing.assert_array_equal(got.cpu().numpy(), gd["dnn_inputs_80"][:, i])
     # identity size: a copy (ImagingResample skips both passes); empty batch; bad arguments
     same = nc.resize_bicubic(torch.from_numpy(g["xin_c"][None]).cuda(), (80, 31), scale=False)
     np.testing.assert_array_equal(same[0].cpu().numpy(), g["xin_c"])

@@ -169,3 +169,20 @@ def test_pil_bicubic_resize_matches_pillow():
     # coefficient rows are normalised and the windows stay inside the image
     b, kk = O.pil_resample_coeffs(176, 80)
     assert kk.shape == (80, 11) and np.allclose(kk.sum(1), 1.0) and (b[:, 0] >= 0).all() and (b.sum(1) <= 176).all()
+
+
+def test_reference_generated_data_fixture():
+    """The reference's own sample data (train-results/sgan/generated_data_*.pickle.save, non-integer float32) with the
+    rows common.process_samples makes of them and the dnn inputs Pillow makes of them (make_golden.py)."""
+    g = load_golden("generated_data.npz")
+    samples = [(g["xz"][b], g["yz"][b], g["xy"][b]) for b in range(len(g["xz"]))]
+    for sc in (0, 1):
+        want = g["feat_scale%d" % sc]
+        got = O.process_samples(samples, scale=bool(sc))
+        np.testing.assert_array_equal(got, want)
+        ident = O.features_from_projections(g["xz"], g["yz"], g["xy"], (True, True, True), bool(sc))
+        assert np.abs(ident - want).max() <= (1e-4 if not sc else 1e-6)     # SciPy's spline round trip at zoom 1
+    for b in range(2):
+        for i, nm in enumerate(("xz", "yz", "xy")):
+            got = O.pil_resize_bicubic(O.scale_unit_range(g[nm][b]), (80, 80))
+            np.testing.assert_array_equal(got, g["dnn_inputs_80"][b, i])

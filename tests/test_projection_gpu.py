@@ -264,3 +264,17 @@ def test_uint8_volumes_give_identical_results(rml, shape):
     assert int(a[4].min()) == 1                   # every row is on the code grid
     if min(X, Y, Z) >= 2:
         assert torch.equal(rml.derive_targets(v8, 2), rml.derive_targets(vf, 2))
+
+
+def test_reference_generated_data_rows(rml):
+    """The reference's own (non-integer, float32) sample data: rml.process_samples == the rows the reference's
+    common.process_samples made of them (to SciPy's zoom-1 spline round trip), flags say 'not on the code grid'."""
+    import torch
+    g = load_golden("generated_data.npz")
+    samples = [(g["xz"][b], g["yz"][b], g["xy"][b]) for b in range(len(g["xz"]))]
+    for sc in (0, 1):
+        got = rml.process_samples(samples, scale=bool(sc))
+        want = g["feat_scale%d" % sc]
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert np.abs(got - want).max() <= (1e-4 if not sc else 1e-6)
+        np.testing.assert_array_equal(got, O.features_from_projections(g["xz"], g["yz"], g["xy"], (True, True, True), bool(sc)))
