@@ -48,22 +48,21 @@ def parse():
 def fit_model(rml, torch, X, Y, Z, ntrain, gamma, seed, dev):
     """CPU plumbing (BASELINE config 1 / SURVEY §8d): fit the reference's model object -- SVC(rbf, C=10,
     class_weight='balanced') + CalibratedClassifierCV(prefit, sigmoid) (train.py:478-482,722-724) -- on
-    synthetic max-projection features.  The Gram matrix is formed on the GPU with torch (float64, exact
-    on the integer codes) and handed to scikit-learn's SMO as a precomputed kernel: same optimisation
-    problem, minutes faster than libsvm's own kernel evaluations at D = 20 480."""
+    synthetic max-projection features.  The Gram matrix comes from the library's own kernel-matrix service
+    (rml_svm_kernel_matrix: the exact-integer MFMA path) and is handed to scikit-learn's SMO as a precomputed
+    kernel: same optimisation problem, minutes faster than libsvm's own kernel evaluations at D = 20 480."""
     import warnings
     from sklearn import svm
     from sklearn.calibration import CalibratedClassifierCV
     nval = max(300, ntrain // 8)
     v, cls = rml.synth_volumes(ntrain + nval, X, Y, Z, seed=seed, frame0=1 << 40)
     feat = rml.process_volumes(v, mode="max", scale=False)              # integer codes 0..255, float32
+    rows = rml.process_volumes(v, mode="max", scale=True)               # train.py:667: float32(code / 255.), IEEE division
     del v
-    F = feat.to(torch.float64)
-    G = F @ F.T
-    sq = torch.diagonal(G).clone()
-    d2 = (sq[:, None] + sq[None, :] - 2.0 * G) / (255.0 * 255.0)
-    K = torch.exp(-gamma * d2.clamp_(min=0)).cpu().numpy()
-    del G, d2, F
+    km = rml.KernelMatrix(rows[:ntrain].cpu().numpy(), gamma)           # Gram-matrix service (csrc/svm.hip, exact path)
+    assert km.exact
+    K = km.against(rows).cpu().numpy()                                  # (ntrain + nval, ntrain) float64
+    del km, rows
     y = cls.cpu().numpy()
     tr, va = slice(0, ntrain), slice(ntrain, ntrain + nval)
     clf = svm.SVC(kernel="precomputed", C=10.0, class_weight="balanced", cache_size=2000)

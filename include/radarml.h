@@ -198,6 +198,14 @@ int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
 int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, const double* probB,
                            const double* dec_ovo, int64_t N, double* proba, void* stream);
 
+/* Kernel values against the model's support vectors, K[n][m] = k(x_n, sv_m) for m < M, float64, exact to the
+ * same arithmetic as rml_svm_decision (path AUTO / I8 / F64).  With the training rows loaded as the "support vectors"
+ * of a model (any coefficients) this is the Gram matrix sklearn's SVC(kernel='precomputed') is fitted on and
+ * K(test, train) it predicts with -- the rbf evaluations libsvm would otherwise do one pair at a time
+ * (train.py:462-491 grid search).  kmat: N x ld_k doubles, ld_k >= M. */
+int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, const float* feat, int64_t ld_feat, int64_t N,
+                          double* kmat, int64_t ld_k, void* stream);
+
 /* Fused front door: volumes -> projection (mode, mask fixed at load: D must match) ->
  * SVM outputs, features never returned to the caller.  Workspace is owned by the ctx and
  * grows on demand. */

@@ -11,7 +11,7 @@ from ._lib import RadarMLError
 from .common import (ProjMask, ProjZoom, DerivedTarget, RADAR_MAX, RADAR_MIN,
                      cartesian_to_spherical, spherical_to_cartesian, calculate_matrix_indices,
                      process_samples, process_volumes, project, derive_targets, feature_len)
-from .svm import GpuSVC, GpuCalibratedClassifier, GpuLinearClassifier, from_sklearn
+from .svm import GpuSVC, GpuCalibratedClassifier, GpuLinearClassifier, KernelMatrix, from_sklearn
 from .predict import classifier, classify_batch, calc_proj_zoom
 from .synth import synth_volumes
 
@@ -19,6 +19,6 @@ __all__ = [
     "RadarMLError", "ProjMask", "ProjZoom", "DerivedTarget", "RADAR_MAX", "RADAR_MIN",
     "cartesian_to_spherical", "spherical_to_cartesian", "calculate_matrix_indices",
     "process_samples", "process_volumes", "project", "derive_targets", "feature_len",
-    "GpuSVC", "GpuCalibratedClassifier", "GpuLinearClassifier", "from_sklearn",
+    "GpuSVC", "GpuCalibratedClassifier", "GpuLinearClassifier", "KernelMatrix", "from_sklearn",
     "classifier", "classify_batch", "calc_proj_zoom", "synth_volumes",
 ]

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rml_svm_decision": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_svm_pairwise_proba": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rml_svm_kernel_matrix": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                 c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_linear_load": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, C.POINTER(c_void_p)]),

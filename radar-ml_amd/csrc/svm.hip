@@ -76,6 +76,7 @@ struct GemmArgs {
     double gs;                             // gamma/scale^2 (rbf) ; 1/scale^2 (linear, exact path)
     int kernel;
     double* partial; int64_t Npart;        // ST x Npart x PT
+    double* kmat; int64_t ld_k; int64_t M; // KM instantiations: kernel values K[n][m] for m < M (rml_svm_kernel_matrix)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -83,7 +84,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int PATH, int PT>
+template <int PATH, int PT, bool KM = false>
 __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
                 } else {
                     kv = g;
                 }
+                if constexpr (KM) {
+                    const int64_t mg = (int64_t)stile * kTile + ml;
+                    if (n < a.N && mg < a.M) a.kmat[n * a.ld_k + mg] = kv;
+                }
 #pragma unroll
                 for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
             }
@@ -361,6 +366,10 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #endif
         } else {
             kv = (PATH == PATH_I8) ? (g + xt + e[0]) * a.gs : g;
+        }
+        if constexpr (KM) {
+            const int64_t mg = (int64_t)stile * kTile + ml;
+            if (n < a.N && mg < a.M) a.kmat[n * a.ld_k + mg] = kv;
         }
 #pragma unroll
         for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
@@ -625,7 +634,7 @@ template <typename T> int dev_upload(T** dst, const std::vector<T>& h) {
     return RML_OK;
 }
 
-template <int PATH>
+template <int PATH, bool KM = false>
 int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     // RML_GEMM_LDS_EXTRA pads the request (experiment knob: > 8 KB leaves one GEMM workgroup per CU, so that the
     // HBM-bound projection of the next chunk keeps its wave slots while the two overlap)
@@ -637,11 +646,11 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     case PTV: {                                                                                                    \
         static bool attr_done = false;                                                                             \
         if (!attr_done) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm<PATH, PTV>),                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm<PATH, PTV, KM>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);                     \
             attr_done = true;                                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_svm_gemm<PATH, PTV>), grid, block, lds, st, ga);                                     \
+        hipLaunchKernelGGL((k_svm_gemm<PATH, PTV, KM>), grid, block, lds, st, ga);                                 \
     } break;
     switch (m->PT) {
         RML_GEMM_CASE(1)
@@ -694,7 +703,7 @@ struct DecisionOut {
 // GEMM(s) + finish for one chunk whose operands are already in place.
 int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
-              bool tiles_done = false) {
+              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -708,21 +717,24 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     GemmArgs ga{};
     ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
+    ga.kmat = kmat; ga.ld_k = ld_k; ga.M = m->M;
     if (run_i8) {
         ga.sv = m->sv_q; ga.ld_sv = m->Dq; ga.x = q; ga.ld_x = ld_q; ga.KT = (int)(m->Kq / kStepBytes);
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
-        int rc = launch_gemm<PATH_I8>(m, ga, st);
+        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st);
         if (rc) return rc;
     }
     if (run_gen) {
         ga.sv = reinterpret_cast<const uint8_t*>(m->sv_f32); ga.ld_sv = m->Df * 4;
         ga.x = reinterpret_cast<const uint8_t*>(f32); ga.ld_x = m->Df * 4; ga.KT = (int)(m->Kf * 4 / kStepBytes);
         ga.want = 0; ga.x_nsq = nsq; ga.sv_term = m->sv_nsq; ga.gs = m->gamma;
-        int rc = gen_f32 ? launch_gemm<PATH_F32>(m, ga, st) : launch_gemm<PATH_F64>(m, ga, st);
+        int rc = gen_f32 ? launch_gemm<PATH_F32>(m, ga, st)
+                         : (kmat ? launch_gemm<PATH_F64, true>(m, ga, st) : launch_gemm<PATH_F64>(m, ga, st));
         if (rc) return rc;
     }
+    if (kmat) { RML_HIP(hipGetLastError()); return RML_OK; }      // kernel values only: no decision outputs
     FinishArgs fa{};
     fa.partial = w.partial; fa.Npart = n; fa.ST = ST; fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
     fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
@@ -888,6 +900,38 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
             rc = run_chunk(m, RML_PATH_I8, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
                            nullptr, nullptr, w, out.at(r0, m->C, m->P), st);
         }
+        if (rc) return rc;
+    }
+    return RML_OK;
+}
+
+// ---- kernel matrix K(X, SV): the Gram-matrix service for SVC training with kernel='precomputed' -------------
+extern "C" int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, const float* feat, int64_t ld_feat, int64_t N,
+                                     double* kmat, int64_t ld_k, void* stream) {
+    RML_REQUIRE(ctx && m && N >= 0, RML_ERR_INVALID, "rml_svm_kernel_matrix: bad arguments");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(feat && kmat, RML_ERR_INVALID, "rml_svm_kernel_matrix: NULL argument");
+    RML_REQUIRE(ld_feat >= m->D && ld_k >= m->M, RML_ERR_INVALID, "rml_svm_kernel_matrix: ld_feat < D or ld_k < M");
+    RML_REQUIRE(path == RML_PATH_AUTO || path == RML_PATH_I8 || path == RML_PATH_F64, RML_ERR_INVALID,
+                "rml_svm_kernel_matrix: path must be AUTO, I8 or F64");
+    RML_REQUIRE(path != RML_PATH_I8 || m->exact, RML_ERR_STATE, "rml_svm_kernel_matrix: exact path requested but the model is not on the code grid");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
+    const bool need_q = m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
+    ChunkWs probe = carve(m, CH, nullptr, need_q, true);
+    void* ws = nullptr;
+    int rc = rml_ws_reserve(ctx, probe.bytes, &ws);
+    if (rc) return rc;
+    ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, true);
+    DecisionOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int64_t r0 = 0; r0 < N; r0 += CH) {
+        const int64_t n = std::min(CH, N - r0);
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)n), dim3(256), 0, st, feat + r0 * ld_feat, ld_feat, m->D,
+                           (float)m->code_scale, w.f32, m->Df, w.nsq, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags);
+        RML_HIP(hipGetLastError());
+        rc = run_chunk(m, path, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, none, st,
+                       /*tiles_done=*/false, kmat + r0 * ld_k, ld_k);
         if (rc) return rc;
     }
     return RML_OK;

@@ -176,6 +176,19 @@ class GpuSVC(_Base):
                 _lib.ptr(out["label_vote"]), _lib.ptr(out.get("label_calib")), _lib.stream_ptr(dev)), "rml_project_svm")
         return out
 
+    def kernel_matrix(self, X, path=None):
+        """K[n][m] = k(x_n, sv_m) as a float64 CUDA tensor (N, n_SV): the kernel evaluations of ``decision_function``
+        themselves (exact-integer path on code-grid rows, float64 MFMA elsewhere)."""
+        torch = _torch()
+        lib = _lib.load()
+        Xd = self._rows(X)
+        N = Xd.shape[0]
+        K = torch.empty((N, self.n_sv), dtype=torch.float64, device=Xd.device)
+        with torch.cuda.device(Xd.device):
+            _lib.check(lib.rml_svm_kernel_matrix(self._ctx, self._h, _lib.PATHS[path or self.path], _lib.ptr(Xd), Xd.stride(0), N,
+                                                 _lib.ptr(K), K.stride(0), _lib.stream_ptr(Xd.device)), "rml_svm_kernel_matrix")
+        return K
+
     # -- sklearn protocol -------------------------------------------------------------------
     def decision_function(self, X):
         """SVC.decision_function (sk:svm/_base.py:760-790): (N,C) 'ovr' scores (or the raw
@@ -310,6 +323,28 @@ class GpuLinearClassifier(_Base):
     def _proba(self, Xd):
         _, _, proba, labc = self._run(Xd, want_proba=True)
         return proba, labc
+
+
+class KernelMatrix:
+    """Gram-matrix service for fitting ``SVC(kernel='precomputed')`` on the GPU-resident kernel (the reference's RBF
+    grid search, train.py:462-491, spends its time in libsvm's pairwise kernel evaluations): the training rows are
+    loaded once, ``gram()`` is K(train, train), ``against(X)`` is K(X, train) for validation / test rows."""
+
+    def __init__(self, X_train, gamma, kernel="rbf", device=None):
+        Xt = _f64(X_train)
+        M = Xt.shape[0]
+        if M < 2:
+            raise ValueError("KernelMatrix: at least two training rows")
+        self._svc = GpuSVC(Xt, np.zeros((1, M)), np.zeros(1), np.array([M - 1, 1], dtype=np.int32), gamma,
+                           np.arange(2), kernel=kernel, device=device)
+        self._train = Xt
+        self.exact = self._svc.exact
+
+    def gram(self):
+        return self._svc.kernel_matrix(self._train)
+
+    def against(self, X):
+        return self._svc.kernel_matrix(X)
 
 
 def from_sklearn(obj, **kw):

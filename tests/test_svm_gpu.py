@@ -306,3 +306,39 @@ def test_slice_mode_fused_with_derived_targets(rml):
     np.testing.assert_array_equal(out["label_calib"].cpu().numpy(), ref["label_calib"])
     feat = rml.process_volumes(vol, mode="slice", scale=True).cpu().numpy()
     np.testing.assert_array_equal(feat, OC.features(xz, yz, xy, scale=True))
+
+
+def test_kernel_matrix_service(rml):
+    """rml_svm_kernel_matrix: K(X, SV) equals the oracle's float64 kernel values (exact-integer path: <= 1e-12
+    relative; non-integer rows through the float64 MFMA path), and an SVC fitted on the GPU Gram matrix with
+    kernel='precomputed' predicts exactly like the SVC fitted by libsvm itself (train.py:462-491 workload)."""
+    from sklearn.svm import SVC
+    g = load_golden("svm_small.npz")
+    svc, m = _model(rml, g)
+    X = _test_rows(g, "svm_small.npz")
+    K = svc.kernel_matrix(X).cpu().numpy()
+    want = O.svm_kernel_values(X.astype(np.float64), m["sv"], m["gamma"])
+    assert K.shape == want.shape == (len(X), svc.n_sv)
+    # the exact path works on the integer codes; the oracle (like sklearn) on their float32-rounded c/255: <= 1e-7 * gamma * d^2
+    assert np.abs(K - want).max() <= 5e-7
+    Xn = X.copy()
+    Xn[::3] += np.float32(0.001)                                    # rows off the code grid -> f64 path for their tiles
+    Kn = svc.kernel_matrix(Xn).cpu().numpy()
+    assert np.abs(Kn - O.svm_kernel_values(Xn.astype(np.float64), m["sv"], m["gamma"])).max() <= 5e-7
+    assert np.abs(svc.kernel_matrix(X, path="i8").cpu().numpy() - K).max() == 0.0
+    assert np.abs(svc.kernel_matrix(X, path="f64").cpu().numpy() - want).max() <= 1e-9      # same float32 rows as the oracle
+    # Gram-matrix service: fit on K(train, train), predict with K(test, train)
+    rng = np.random.default_rng(5)
+    Xtr = (rng.integers(0, 256, (300, X.shape[1])).astype(np.float32) / np.float32(255.0))
+    ytr = rng.integers(0, 3, 300)
+    Xtr[ytr == 1, :40] = 1.0
+    Xtr[ytr == 2, 40:80] = 0.0
+    km = rml.KernelMatrix(Xtr, gamma=0.05)
+    assert km.exact
+    G = km.gram().cpu().numpy()
+    assert np.allclose(np.diag(G), 1.0) and np.abs(G - G.T).max() == 0.0
+    direct = SVC(kernel="rbf", gamma=0.05, C=10.0).fit(Xtr.astype(np.float64), ytr)
+    pre = SVC(kernel="precomputed", C=10.0).fit(G, ytr)
+    Kt = km.against(X[:64]).cpu().numpy()
+    np.testing.assert_array_equal(pre.predict(Kt), direct.predict(X[:64].astype(np.float64)))
+    assert np.abs(pre.decision_function(Kt) - direct.decision_function(X[:64].astype(np.float64))).max() < 1e-3
