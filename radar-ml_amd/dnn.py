@@ -127,9 +127,12 @@ class Classifier(_module_base()):
 
     def forward_fused(self, xz, yz, xy):
         """Class probabilities with the fused HIP trunk + bf16 dense tail (hipBLASLt through PyTorch)."""
+        return self.dense_tail(self.features_fused(xz, yz, xy))
+
+    def dense_tail(self, fv):
+        """Dense 64 relu, Dense 64 relu, Dense n softmax (dnn.py:78-88) on bf16 feature rows."""
         import torch
         import torch.nn.functional as F
-        fv = self.features_fused(xz, yz, xy)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             h = F.relu(self.fc1(fv))
             h = F.relu(self.fc2(h))
@@ -137,9 +140,11 @@ class Classifier(_module_base()):
         return torch.softmax(lg.float(), dim=-1)
 
     def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192):
-        """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes -> projections (csrc/project.hip)
-        -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused conv trunk (csrc/dnn.hip) ->
-        dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor."""
+        """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
+        projections (csrc/project.hip) -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused
+        conv trunk (csrc/dnn.hip) -> dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor.
+        One stream: alternating batches between two streams was measured slower (PyTorch's caching allocator cannot
+        reuse blocks across streams without synchronising) and hipBLASLt hung when driven from two streams."""
         import torch
         from . import common, nn_common
         outs = []
@@ -149,7 +154,9 @@ class Classifier(_module_base()):
                 feat = common.process_volumes(volumes[s0:s0 + batch_size], mode=mode, scale=False)
                 xz, yz, xy = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
                 outs.append(self.forward_fused(xz, yz, xy))
-        return torch.cat(outs) if outs else torch.zeros((0, self.n_classes), device=volumes.device)
+        if outs:
+            return torch.cat(outs)
+        return torch.zeros((0, self.n_classes), device=volumes.device if isinstance(volumes, torch.Tensor) else "cuda")
 
     def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""

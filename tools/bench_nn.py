@@ -118,6 +118,12 @@ def main():
             t_res = timeit(lambda: nc.preprocess_features(feat, (X, Y, Z), (80, 80), out_dtype="bfloat16"))
             x16 = nc.preprocess_features(feat, (X, Y, Z), (80, 80), out_dtype="bfloat16")
             t_fwd16 = timeit(lambda: model.forward_fused(*x16))
+            V8 = V.to(torch.uint8)
+            t_hip8 = timeit(lambda: model.predict_volumes(V8, batch_size=bs).argmax(dim=-1), a.steps // 4 or 1)
+            same8 = bool(torch.equal(model.predict_volumes(V8, batch_size=bs).argmax(dim=-1), lab_hip))
+            del V8
+        print(json.dumps({"what": "configs[3] all-HIP from uint8 volumes", "frames": B, "frames_per_s_end_to_end": round(B / t_hip8),
+                          "ms_total": round(t_hip8 * 1e3, 2), "labels_identical_to_f32_ingest": same8}))
         print(json.dumps({"what": "configs[3] all-HIP: projection + resize + fused trunk + dense tail", "frames": B, "batch": bs,
                           "frames_per_s_end_to_end": round(B / t_hip), "ms_total": round(t_hip * 1e3, 2),
                           "projection_ms": round(t_proj * 1e3, 3), "resize_ms": round(t_res * 1e3, 3),
