@@ -24,6 +24,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec HBM3E
+I8_MFMA_PEAK_TOPS = 3944.0        # MI355X_MICROARCH.md: dense int8 MFMA (>= 3944 TOPS)
+
+
+def gemm_roofline(lib, ctx):
+    """In-situ time of the GEMM + finish kernels of every chunk (second stream) -> achieved int8 TOP/s."""
+    nl, ms, ops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    lib.rml_profile_read_gemm(ctx, ctypes.byref(nl), ctypes.byref(ms), ctypes.byref(ops))
+    if nl.value == 0 or ms.value <= 0:
+        return None
+    ach = ops.value / (ms.value * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_svm_gemm<I8> + k_svm_finish", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS,
+            "unit": "TOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "launches": int(nl.value),
+            "avg_chunk_ms": round(ms.value / nl.value, 4), "note": "algorithmic 2*D*M ops per frame; runs concurrently with the projection of the next chunk"}
 
 
 def parse():
@@ -144,6 +157,7 @@ def run_workload(a, env, grid, frames, primary):
     dt = time.perf_counter() - t0
     nl, ms, nf = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
     lib.rml_profile_read(ctx, ctypes.byref(nl), ctypes.byref(ms), ctypes.byref(nf))
+    groof = gemm_roofline(lib, ctx)
     lib.rml_profile_enable(ctx, 0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -178,6 +192,7 @@ def run_workload(a, env, grid, frames, primary):
         dt8 = time.perf_counter() - t0
         nl8, ms8, nf8 = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
         lib.rml_profile_read(ctx, ctypes.byref(nl8), ctypes.byref(ms8), ctypes.byref(nf8))
+        groof8 = gemm_roofline(lib, ctx)
         lib.rml_profile_enable(ctx, 0)
         t8 = torch.tensor([dt8], dtype=torch.float64, device=dev)
         if world > 1:
@@ -203,7 +218,8 @@ def run_workload(a, env, grid, frames, primary):
                            "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach8 / HBM_PEAK_GBS, 4), "traffic": tr8, "launches": int(l8),
                            "avg_launch_ms": round(a8, 4), "frames_per_launch": nf8.value / l8,
-                           "algorithmic_bytes_per_frame": X * Y * Z + 16}}
+                           "algorithmic_bytes_per_frame": X * Y * Z + 16},
+              "gemm_roofline": groof8}
         del V8, out8
         torch.cuda.empty_cache()
 
@@ -233,6 +249,25 @@ def run_workload(a, env, grid, frames, primary):
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_frame": alg_bytes_frame}
+
+    # ---- the GEMM alone (one 8 192-frame chunk of code rows, nothing else on the GPU) ------------------------
+    if groof is not None:
+        nb = int(min(8192, B))
+        _, q, isum, isq, flags = rml.process_volumes(V[:nb], mode="max", scale=True, codes=True)
+        if q.stride(0) % 16 == 0:
+            for _ in range(2):
+                svc.decide_codes(q, isum, isq, flags, want_proba=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                svc.decide_codes(q, isum, isq, flags, want_proba=True)
+            e1.record()
+            e1.synchronize()
+            alone_ms = e0.elapsed_time(e1) / 5
+            alone = 2.0 * D * M * nb / (alone_ms * 1e-3) / 1e12
+            groof["alone"] = {"frames": nb, "ms": round(alone_ms, 4), "achieved": round(alone, 1),
+                              "frac": round(alone / I8_MFMA_PEAK_TOPS, 4)}
+        del q, isum, isq, flags
 
     # ---- parity gate on a slab of the very frames the GPU classified ----------------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -283,7 +318,7 @@ def run_workload(a, env, grid, frames, primary):
                    "gamma": a.gamma, "parallelism": "frames sharded x%d, labels all-gathered (RCCL)" % world
                    if world > 1 else "single GPU"},
         "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "uint8_ingest": u8,
+        "roofline": roofline, "gemm_roofline": groof, "cpu_baseline": cpu, "parity": parity, "uint8_ingest": u8,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
     del V, out, svc
@@ -329,7 +364,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
             "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
-            "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "parity": res["parity"],
+            "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"], "cpu_baseline": res["cpu_baseline"],
+            "parity": res["parity"],
             "uint8_ingest": res["uint8_ingest"], "model": res["model"],
         }
         if wal is not None:

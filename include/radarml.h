@@ -86,6 +86,9 @@ int rml_ctx_device(const rml_ctx* ctx);
  * elapsed time and the frames they covered, and resets the counters. */
 int rml_profile_enable(rml_ctx* ctx, int on);
 int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_ms, int64_t* frames);
+/* The same for the GEMM + finish kernels of every chunk (the context's second stream): launches, summed
+ * milliseconds, and the algorithmic operations 2*D*M per frame they covered. */
+int rml_profile_read_gemm(rml_ctx* ctx, int64_t* launches, double* total_ms, double* ops);
 
 /* Feature-row length for a grid and mask: X*Z + Y*Z + X*Y over the selected planes
  * (train_svc.log:19 "Feature vector length: 10010" at (22,31,176)). */

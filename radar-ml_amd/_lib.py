@@ -33,6 +33,7 @@ SIGNATURES = {
     "rml_ctx_device": (c_int, [c_void_p]),
     "rml_profile_enable": (c_int, [c_void_p, c_int]),
     "rml_profile_read": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_int64)]),
+    "rml_profile_read_gemm": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_double)]),
     "rml_feature_len": (c_int64, [c_int, c_int, c_int, c_uint32]),
     "rml_project": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

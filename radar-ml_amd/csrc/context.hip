@@ -104,6 +104,7 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_ev_g) (void)hipEventDestroy(e);
     for (const rml_resize_tab& t : ctx->resize_tabs) (void)hipFree(const_cast<double*>(t.kk));
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->proj_stream) (void)hipStreamDestroy(ctx->proj_stream);
@@ -121,11 +122,43 @@ void rml_prof_mark(rml_ctx* ctx, hipStream_t st) {
     (void)hipEventRecord(ctx->prof_ev[ctx->prof_used++], st);
 }
 
+void rml_prof_mark_gemm(rml_ctx* ctx, hipStream_t st) {
+    if (!ctx->profiling) return;
+    if (ctx->prof_used_g == ctx->prof_ev_g.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
+        ctx->prof_ev_g.push_back(e);
+    }
+    (void)hipEventRecord(ctx->prof_ev_g[ctx->prof_used_g++], st);
+}
+
+extern "C" int rml_profile_read_gemm(rml_ctx* ctx, int64_t* launches, double* total_ms, double* ops) {
+    RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_read_gemm: ctx is NULL");
+    RML_HIP(hipSetDevice(ctx->device));
+    double tot = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used_g; i += 2) {
+        RML_HIP(hipEventSynchronize(ctx->prof_ev_g[i + 1]));
+        float ms = 0.0f;
+        RML_HIP(hipEventElapsedTime(&ms, ctx->prof_ev_g[i], ctx->prof_ev_g[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = tot;
+    if (ops) *ops = ctx->prof_ops_g;
+    ctx->prof_used_g = 0;
+    ctx->prof_ops_g = 0.0;
+    return RML_OK;
+}
+
 extern "C" int rml_profile_enable(rml_ctx* ctx, int on) {
     RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_enable: ctx is NULL");
     ctx->profiling = on != 0;
     ctx->prof_used = 0;
     ctx->prof_frames = 0;
+    ctx->prof_used_g = 0;
+    ctx->prof_ops_g = 0.0;
     return RML_OK;
 }
 

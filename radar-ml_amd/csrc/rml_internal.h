@@ -31,11 +31,15 @@ struct rml_ctx {
     std::vector<hipEvent_t> prof_ev;    // start/stop pairs
     size_t prof_used = 0;
     int64_t prof_frames = 0;
+    std::vector<hipEvent_t> prof_ev_g;  // the same for the GEMM + finish of every chunk (aux stream)
+    size_t prof_used_g = 0;
+    double prof_ops_g = 0.0;
     std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
 };
 
 // records an event on st when profiling is on (no-op otherwise)
 void rml_prof_mark(rml_ctx* ctx, hipStream_t st);
+void rml_prof_mark_gemm(rml_ctx* ctx, hipStream_t st);
 
 void rml_set_error(const char* fmt, ...);
 int rml_hip_fail(hipError_t e, const char* what, const char* file, int line);

@@ -1022,8 +1022,11 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
+        rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok);
+        rml_prof_mark_gemm(ctx, aux);
+        if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
         RML_HIP(hipEventRecord(ev_done[c & 1], aux));
     }

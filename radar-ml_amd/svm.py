@@ -138,6 +138,29 @@ class GpuSVC(_Base):
                 "rml_svm_decision")
         return ovo, ovr, vote, proba, lab
 
+    def decide_codes(self, codes, row_isum, row_isq, row_flags=None, want_proba=False):
+        """Decision from biased uint8 code rows as ``process_volumes(..., codes=True)`` returns them (exact path only:
+        no row preparation, the GEMM + finish kernels alone).  Returns (dec_ovo, dec_ovr, label_vote, proba, label_calib)."""
+        torch = _torch()
+        lib = _lib.load()
+        N = codes.shape[0]
+        C_ = len(self.classes_)
+        P = C_ * (C_ - 1) // 2
+        dev = codes.device
+        ovo = torch.empty((N, P), dtype=torch.float64, device=dev)
+        ovr = torch.empty((N,) if C_ == 2 else (N, C_), dtype=torch.float64, device=dev)
+        vote = torch.empty((N,), dtype=torch.int32, device=dev)
+        proba = lab = None
+        if want_proba:
+            proba = torch.empty((N, C_), dtype=torch.float64, device=dev)
+            lab = torch.empty((N,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_svm_decision(
+                self._ctx, self._h, _lib.PATH_I8, None, 0, _lib.ptr(codes), codes.stride(0), _lib.ptr(row_isum), _lib.ptr(row_isq),
+                _lib.ptr(row_flags), N, _lib.ptr(ovo), _lib.ptr(ovr), _lib.ptr(proba), _lib.ptr(vote), _lib.ptr(lab),
+                _lib.stream_ptr(dev)), "rml_svm_decision")
+        return ovo, ovr, vote, proba, lab
+
     def decide_volumes(self, volumes, mode="max", ijk=None, proj_mask=ProjMask(True, True, True), scale=True,
                        want_proba=None):
         """Fused batched path: (B,X,Y,Z) volumes -> projection -> SVM, features never leave the GPU.

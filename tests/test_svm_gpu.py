@@ -157,6 +157,10 @@ def test_fused_volumes_to_labels(rml, name, shape):
     out8 = svc.decide_volumes(g["test_vol_u8"], mode="max", proj_mask=mask, scale=True)
     for k in ("dec_ovo", "dec_ovr", "proba", "label_vote", "label_calib"):
         assert torch.equal(out8[k], out[k]), k
+    # and the two halves separately: code rows from the projection, then the GEMM + finish alone
+    _, q, isum, isq, flags = rml.process_volumes(torch.from_numpy(vol).cuda(), mode="max", proj_mask=mask, scale=True, codes=True)
+    ovo_c, ovr_c, vote_c, proba_c, lab_c = svc.decide_codes(q, isum, isq, flags, want_proba=True)
+    assert torch.equal(ovo_c, out["dec_ovo"]) and torch.equal(vote_c, out["label_vote"]) and torch.equal(lab_c, out["label_calib"])
     # a frame with a non-integer return drops its tile to the f32 path; results stay within tolerance
     vol2 = vol.copy()
     vol2[3, 0, 0, 0] = 0.5
