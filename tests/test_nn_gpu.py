@@ -157,3 +157,29 @@ def test_dnn_fused_trunk_vs_fp32_cpu(rml):
             w = small.features(*[torch.from_numpy(a).unsqueeze(1) for a in xs]).numpy()
             g = sg.features_fused(*[torch.from_numpy(a).cuda() for a in xs]).float().cpu().numpy()
         assert g.shape == w.shape and np.abs(g - w).max() <= 2e-2 + 1e-2 * np.abs(w).max(), (h_, w_)
+
+
+def test_resize_random_shapes_property(rml):
+    """Property test: csrc/resize.hip equals the Pillow restatement (oracle_np.pil_resize_bicubic) bit for bit on random
+    geometries -- upscale, downscale (window sizes 5..33), either axis unchanged, strided input rows, bf16 output."""
+    import oracle_np as O
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+
+    @settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 60), st.integers(1, 90), st.integers(1, 96), st.integers(1, 96), st.integers(1, 3),
+           st.integers(0, 2 ** 31 - 1), st.booleans())
+    def check(H, W, OH, OW, B, seed, scale):
+        rng = np.random.default_rng(seed)
+        x = (rng.integers(0, 256, (B, H, W)).astype(np.float32) if scale else rng.normal(size=(B, H, W)).astype(np.float32))
+        pad = seed % 5                                        # rows inside wider rows (feature-row style addressing)
+        wide = torch.zeros((B, H * W + pad), dtype=torch.float32, device="cuda")
+        wide[:, :H * W] = torch.from_numpy(x.reshape(B, -1)).cuda()
+        got = nc.resize_bicubic(wide[:, :H * W], (OH, OW), shape=(H, W), scale=scale)
+        got16 = nc.resize_bicubic(wide[:, :H * W], (OH, OW), shape=(H, W), scale=scale, out_dtype="bfloat16")
+        for b in range(B):
+            want = O.pil_resize_bicubic(O.scale_unit_range(x[b]) if scale else x[b], (OH, OW))
+            np.testing.assert_array_equal(got[b].cpu().numpy(), want)
+            np.testing.assert_array_equal(got16[b].float().cpu().numpy(), torch.from_numpy(want).to(torch.bfloat16).float().numpy())
+
+    check()

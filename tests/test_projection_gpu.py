@@ -278,3 +278,36 @@ def test_reference_generated_data_rows(rml):
         assert got.shape == want.shape and got.dtype == np.float32
         assert np.abs(got - want).max() <= (1e-4 if not sc else 1e-6)
         np.testing.assert_array_equal(got, O.features_from_projections(g["xz"], g["yz"], g["xy"], (True, True, True), bool(sc)))
+
+
+def test_uint8_random_shapes_property(rml):
+    """Property test for the uint8 ingest over random grids (byte-native kernel when Z % 16 == 0, widening kernels
+    otherwise; 1..8 rows per lane): max / sum / slice projections and the code rows equal NumPy's on the same values."""
+    import torch
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 24), st.integers(1, 70), st.integers(1, 20), st.integers(1, 3), st.integers(0, 2 ** 31 - 1),
+           st.sampled_from([16, 16, 16, 4, 1]))
+    def check(X, Y, Zq, B, seed, zmul):
+        Z = Zq * zmul
+        rng = np.random.default_rng(seed)
+        v8 = rng.integers(0, 256, (B, X, Y, Z)).astype(np.uint8)
+        if seed & 1:
+            v8[rng.random((B, X, Y, Z)) < 0.7] = 0                 # sparse frames: many ties, zero planes
+        vf = v8.astype(np.float32)
+        for g, w in zip(rml.project(v8, mode="max"), O.project_max(vf)):
+            np.testing.assert_array_equal(g, w)
+        for g, w in zip(rml.project(v8, mode="sum"), O.project_sum(vf)):
+            np.testing.assert_array_equal(g, w)
+        feat, q, isum, isq, flags = rml.process_volumes(torch.from_numpy(v8).cuda(), mode="max", scale=True, codes=True)
+        xz, yz, xy = O.project_max(vf)
+        rows = O.features_from_projections(xz, yz, xy, (True, True, True), False)
+        D = rows.shape[1]
+        np.testing.assert_array_equal(feat.cpu().numpy(), (rows / np.float32(255.0)).astype(np.float32))
+        np.testing.assert_array_equal((q[:, :D].cpu().numpy() ^ 0x80).astype(np.float32), rows)
+        assert int(q[:, D:].to(torch.int32).sum()) == 0 and bool((flags == 1).all())
+        np.testing.assert_array_equal(isum.cpu().numpy(), rows.sum(1).astype(np.int64))
+        np.testing.assert_array_equal(isq.cpu().numpy(), (rows.astype(np.int64) ** 2).sum(1))
+
+    check()
