@@ -18,12 +18,12 @@
 //      N = strip pixels, K = 9 taps x 64 channels; the pixel fragments are read straight from the conv1 image (16
 //      contiguous bytes = 8 input channels of one tap); the K range is split over two wave pairs and reduced
 //      through LDS, each half finishing part of the pixel tiles,
-//   4. relu, bf16, and a coalesced store at ((h*OW2 + w)*96 + branch*32 + n).
+//   4. relu, bf16, and 8-byte stores straight from the accumulator layout to ((h*OW2 + w)*96 + branch*32 + n).
 // The conv1 image uses a padded pixel stride (144 B) so that the ds_read_b128 fragment reads are bank-conflict
-// free; the output staging buffer lies over it (it is dead between conv2 and the next strip).  Barriers are
+// free.  Barriers are
 // LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) so that they do not drain the plane prefetch.
 // Numerics: bf16 operands (conv1 bias included), float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
-// Measured (8192 samples of 3 x 80x80, MI355X): 0.85 ms = 9.7 M samples/s; the same layers through PyTorch/MIOpen
+// Measured (8192 samples of 3 x 80x80, MI355X): 0.75 ms = 11.0 M samples/s; the same layers through PyTorch/MIOpen
 // in bf16 channels_last take 13.9 ms.
 #include "rml_internal.h"
 
@@ -75,8 +75,7 @@ struct TrunkLayout {        // LDS carve-up, shared by the kernel and the launch
         nt1 = (R1 * OW1 + 15) >> 4;          // pixel tiles of a strip's conv1 image
         off_c1 = ((size_t)(H + 5) * RS * 2 + 15) & ~(size_t)15;
         const size_t image = ((size_t)R1 * (OW1 + 1) + 1) * PIX_STRIDE;
-        const size_t stage = (size_t)SR * (W / 4) * C2 * 2;      // o_s lies over the image
-        off_red = off_c1 + (((image > stage ? image : stage) + 15) & ~(size_t)15);
+        off_red = off_c1 + ((image + 15) & ~(size_t)15);
         total = off_red + (size_t)2 * MT_MAX * 64 * 16;
     }
 };
@@ -98,17 +97,17 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     uint16_t* in_s = reinterpret_cast<uint16_t*>(smem);          // [H+5][W+2] bf16: plane + zero pad
     unsigned char* c1_s = smem + L.off_c1;                       // [R1][OW1+1] pixels x 144 B (+ 1 dummy pixel)
     float* red_s = reinterpret_cast<float*>(smem + L.off_red);   // [2 nt][MT_MAX][64 lanes][4]: K-split partials
-    uint16_t* o_s = reinterpret_cast<uint16_t*>(c1_s);           // [SR*OW2][32] bf16 output staging (aliases the image)
     const int dummy_off = R1 * (OW1 + 1) * PIX_STRIDE;
 
     const float* __restrict__ w1 = a.w1 + br * C1 * KTAPS;
     const float* __restrict__ b1 = a.b1 + br * C1;
     const float* __restrict__ b2 = a.b2 + br * C2;
 
-    // everything the window reads may touch -> 0 once: the planes only ever overwrite [0,H) x [0,W)
+    // everything the window reads may touch -> 0 once: the planes only ever overwrite [0,H) x [0,W); the conv1 image
+    // too (its pad column is never written)
     {
         uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < (int)(L.off_c1 >> 4); i += 256) *reinterpret_cast<uint4*>(smem + i * 16) = z;
+        for (int i = tid; i < (int)(L.off_red >> 4); i += 256) *reinterpret_cast<uint4*>(smem + i * 16) = z;
     }
     lds_barrier();
     // the workgroup is persistent: it walks samples blockIdx.x, +gridDim.x, ... of its branch, and while one sample
@@ -227,10 +226,6 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
             const int lo = (live < 0 ? 0 : live) * (OW1 + 1) * (PIX_STRIDE / 16);
             for (int i = lo + tid; i < R1 * (OW1 + 1) * (PIX_STRIDE / 16); i += 256) *reinterpret_cast<uint4*>(c1_s + i * 16) = z;
         }
-        if (tid < R1 * (PIX_STRIDE / 16)) {   // the pad column again: the staging buffers of the last strip lay over it
-            const int cr = tid / (PIX_STRIDE / 16), part = tid - cr * (PIX_STRIDE / 16);
-            *reinterpret_cast<uint4*>(c1_s + (cr * (OW1 + 1) + OW1) * PIX_STRIDE + part * 16) = make_uint4(0, 0, 0, 0);
-        }
         const uint16_t* plane0 = in_s + (4 * r0) * RS;
 #pragma unroll
         for (int g = 0; g < TPW / 3; ++g) {
@@ -306,27 +301,22 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4) = acc[m];
         }
-        lds_barrier();                    // partials visible, and every wave is done reading the conv1 image (o_s lies over it)
-        // C/D map: rows (channels) nt*16 + (lane>>4)*4 + r, column (pixel) lane&15: 4 channels = one 8-byte store
+        lds_barrier();                    // partials visible
+        // C/D map: rows (channels) nt*16 + (lane>>4)*4 + r, column (pixel) lane&15: a lane holds 4 consecutive channels
+        // of one pixel -> one 8-byte store straight to ((h*OW2 + w)*96 + br*32 + channel); the four lanes of a pixel
+        // cover 32 contiguous bytes and the partner wave (other nt) the other half of the branch's 64
+        const int rows = (OH2 - r0) < SR ? (OH2 - r0) : SR;
+        const int Pv = rows * OW2;
+        uint16_t* dst0 = a.feat + b * (int64_t)OH2 * OW2 * 96 + (int64_t)r0 * OW2 * 96 + br * 32 + nt * 16 + kg * 4;
 #pragma unroll
         for (int m = 0; m < MT_MAX; ++m) {
             if ((m < 3) == (kh == 0)) {
                 const int q = m * 16 + (lane & 15);
                 const f32x4 o = *reinterpret_cast<const f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4);
                 const f32x4 s4 = acc[m] + o;
-                if (q < P)
-                    *reinterpret_cast<uint2*>(o_s + q * C2 + nt * 16 + kg * 4) =
-                        make_uint2(pk_relu(pk_bf16(s4[0], s4[1])), pk_relu(pk_bf16(s4[2], s4[3])));
+                if (q < Pv)
+                    *reinterpret_cast<uint2*>(dst0 + q * 96) = make_uint2(pk_relu(pk_bf16(s4[0], s4[1])), pk_relu(pk_bf16(s4[2], s4[3])));
             }
-        }
-        lds_barrier();
-        // 4. coalesced store: 64 B (32 channels) per pixel at ((h*OW2 + w)*96 + br*32); the strip's pixels are
-        //    consecutive in the output
-        const int rows = (OH2 - r0) < SR ? (OH2 - r0) : SR;
-        uint16_t* dst0 = a.feat + b * (int64_t)OH2 * OW2 * 96 + (int64_t)r0 * OW2 * 96 + br * 32;
-        for (int i = tid; i < rows * OW2 * 4; i += 256) {
-            const int q = i >> 2, part = i & 3;
-            *reinterpret_cast<uint4*>(dst0 + q * 96 + part * 8) = *reinterpret_cast<const uint4*>(o_s + q * C2 + part * 8);
         }
 #ifdef RML_DNN_TIMING
         t4_ = __builtin_readcyclecounter();
