@@ -270,24 +270,29 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
         f32x4 acc[MT_MAX];
 #pragma unroll
         for (int m = 0; m < MT_MAX; ++m) acc[m] = b2r;
-#pragma unroll
-        for (int t0 = 0; t0 < 9; t0 += 3) {         // three K-steps at a time: fragment reads in flight, then the MFMAs
+        {
+            // software pipeline over the wave's 9 K-steps: the fragment reads of step t+2 are issued before the MFMAs
+            // of step t, so an LDS round trip is always covered by ten MFMAs
             bf16x8 afrag[3][MT_MAX];
-#pragma unroll
-            for (int tt = 0; tt < 3; ++tt) {
-                const int ks = kh * 9 + t0 + tt;
+            auto ldk = [&](int tt, bf16x8 (&dst)[MT_MAX]) {
+                const int ks = kh * 9 + tt;
                 const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3;
                 const int aoff = (ky * (OW1 + 1) + kx) * PIX_STRIDE + (ks & 1) * 64;
 #pragma unroll
-                for (int m = 0; m < MT_MAX; ++m) afrag[tt][m] = *reinterpret_cast<const bf16x8*>(c1_s + poff[m] + aoff);
-            }
+                for (int m = 0; m < MT_MAX; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(c1_s + poff[m] + aoff);
+            };
+            ldk(0, afrag[0]);
+            ldk(1, afrag[1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tt = 0; tt < 3; ++tt)
+            for (int tt = 0; tt < 9; ++tt) {
+                if (tt + 2 < 9) ldk(tt + 2, afrag[(tt + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MT_MAX; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[t0 + tt], afrag[tt][m], acc[m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tt], afrag[tt % 3][m], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #ifdef RML_DNN_TIMING
         t3_ = __builtin_readcyclecounter();
