@@ -242,20 +242,30 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
                     to[i] = (tout[3 * g + i] >> 24) < live ? (tout[3 * g + i] & 0xFFFFFF) : dummy_off + kg * 8;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                // C/D map: rows (channels) ct*16 + (lane>>4)*4 + r, column (pixel) lane&15.  Two tiles in flight: the
+                // MFMAs of tile i+1 are issued before the results of tile i are converted and stored
+                f32x4 c[2][4];
+                auto mm = [&](int i) {
                     const bf16x8 xfrag = *reinterpret_cast<bf16x8*>(&u[i]);
-                    // C/D map: rows (channels) ct*16 + (lane>>4)*4 + r, column (pixel) lane&15
-                    f32x4 c[4];
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        c[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1frag[ct], xfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);      // four independent MFMAs back to back, then the stores
+                        c[i & 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1frag[ct], xfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                };
+                auto st = [&](int i) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
                         *reinterpret_cast<uint2*>(c1_s + to[i] + ct * 32) =
-                            make_uint2(pk_relu(pk_bf16(c[ct][0], c[ct][1])), pk_relu(pk_bf16(c[ct][2], c[ct][3])));
-                }
+                            make_uint2(pk_relu(pk_bf16(c[i & 1][ct][0], c[i & 1][ct][1])), pk_relu(pk_bf16(c[i & 1][ct][2], c[i & 1][ct][3])));
+                };
+                mm(0);
+                mm(1);
+                __builtin_amdgcn_sched_barrier(0);
+                st(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2);
+                __builtin_amdgcn_sched_barrier(0);
+                st(1);
+                st(2);
             }
         }
 #ifdef RML_DNN_TIMING
