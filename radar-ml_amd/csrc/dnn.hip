@@ -9,10 +9,10 @@
 // walks that branch's samples; while one sample is convolved the next plane is already in flight into registers.
 // Per sample the conv2 output is produced in strips of SR rows:
 //   1. the plane is written to LDS as bf16 (rows >= H and columns >= W are TensorFlow's bottom/right 'same' zeros),
-//   2. conv1 + bias + relu on the matrix cores, transposed: M = 64 channels (the weights = A), N = 16 strip pixels
+//   2. conv1 + bias + relu on the matrix cores (v_mfma_f32_32x32x16_bf16), transposed: M = 64 channels (the weights = A), N = 32 strip pixels
 //      per tile (B = the pixels' 3x3 windows, five LDS reads per lane: the K order is chosen so that row pairs of the
 //      window are single aligned 32-bit reads, and K slots with zero weights may hold anything finite), K = 9 taps +
-//      1 bias slot (pixel side forced to 1.0) padded to 32.  relu is one v_pk_max_i16 on the packed bf16 pair, and a
+//      1 bias slot (pixel side forced to 1.0) padded to 16.  relu is one v_pk_max_i16 on the packed bf16 pair, and a
 //      lane holds 4 consecutive channels of one pixel: one 8-byte LDS store into the conv1 image [rows][cols+1][64],
 //   3. conv2 is an implicit GEMM (v_mfma_f32_16x16x32_bf16): M = 32 output channels (weights, in registers),
 //      N = strip pixels, K = 9 taps x 64 channels; the pixel fragments are read straight from the conv1 image (16
@@ -23,7 +23,7 @@
 // free.  Barriers are
 // LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) so that they do not drain the plane prefetch.
 // Numerics: bf16 operands (conv1 bias included), float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
-// Measured (8192 samples of 3 x 80x80, MI355X): 0.75 ms = 11.0 M samples/s; the same layers through PyTorch/MIOpen
+// Measured (8192 samples of 3 x 80x80, MI355X): 0.69 ms = 11.8 M samples/s; the same layers through PyTorch/MIOpen
 // in bf16 channels_last take 13.9 ms.
 #include "rml_internal.h"
 
@@ -32,14 +32,15 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C1 = 64, C2 = 32, KTAPS = 9;
 constexpr int K2 = KTAPS * C1;            // 576
 constexpr int PIX_STRIDE = C1 * 2 + 16;    // 144 B per conv1 pixel in LDS
-constexpr int MT_MAX = 5;                  // conv2 pixel tiles per strip
-constexpr int TPW = 6;                     // conv1 pixel tiles per wave and strip
+constexpr int MT_MAX = 5;                  // conv2 pixel tiles per strip (template MT <= MT_MAX)
+constexpr int TPW = 3;                     // conv1 pixel tiles (32 pixels) per wave and strip
 constexpr int PLD = 7;                     // 16-byte loads of the input plane per thread that are prefetched
 
 struct TrunkArgs {
@@ -69,26 +70,28 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct TrunkLayout {        // LDS carve-up, shared by the kernel and the launcher
     int RS, nt1;
     size_t off_c1, off_red, total;
-    __host__ __device__ TrunkLayout(int H, int W, int SR) {
+    __host__ __device__ TrunkLayout(int H, int W, int SR, int MT) {
         const int R1 = 2 * SR + 1, OW1 = W / 2;
         RS = W + 2;
-        nt1 = (R1 * OW1 + 15) >> 4;          // pixel tiles of a strip's conv1 image
+        nt1 = (R1 * OW1 + 31) >> 5;          // 32-pixel tiles of a strip's conv1 image
         off_c1 = ((size_t)(H + 5) * RS * 2 + 15) & ~(size_t)15;
         const size_t image = ((size_t)R1 * (OW1 + 1) + 1) * PIX_STRIDE;
         off_red = off_c1 + ((image + 15) & ~(size_t)15);
-        total = off_red + (size_t)2 * MT_MAX * 64 * 16;
+        total = off_red + (size_t)2 * MT * 64 * 16;
     }
 };
 
-template <int SR, bool INBF>
-__global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
+// MT = conv2 pixel tiles per strip, PF = prefetch the next plane into registers, WPC = workgroups per CU the register
+// budget is compiled for (2: 256 VGPRs, 3: 168)
+template <int SR, bool INBF, int MT, bool PF, int WPC>
+__global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = a.H, W = a.W;
     const int OH1 = H / 2, OW1 = W / 2, OH2 = H / 4, OW2 = W / 4;
     constexpr int R1 = 2 * SR + 1;        // conv1 rows per strip
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int br = blockIdx.y;
-    const TrunkLayout L(H, W, SR);
+    const TrunkLayout L(H, W, SR, MT);
     const int RS = L.RS;
 #ifdef RML_DNN_TIMING
     const unsigned long long tentry = __builtin_readcyclecounter();
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     constexpr int QE = INBF ? 8 : 4;        // elements per quad
     constexpr int NLD = INBF ? (PLD + 1) / 2 : PLD;
     const int WQ = W / QE, nquad = H * WQ;
-    const bool prefetch = nquad <= 256 * NLD;
+    const bool prefetch = PF && nquad <= 256 * NLD;
     int lofs[NLD];                          // LDS destination (bf16 units) of the thread's quads, -1 past the plane
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
@@ -153,19 +156,21 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) bfrag[t] = *reinterpret_cast<const bf16x8*>(g + (kh * 9 + t) * 64);
     }
-    // conv1 weights as four A fragments (channel = ct*16 + lane&15).  K slots of k-group 0: the window's
-    // (r0c0 r0c1)(r1c0 r1c1)(r2c0 r2c1)(r0c2 r1c2), k-group 1: r2c2, then the bias (its pixel-side slot is forced
-    // to 1.0), then zeros, k-groups 2 and 3: zeros.
-    bf16x8 w1frag[4];
+    // conv1 runs as v_mfma_f32_32x32x16_bf16: M = 32 channels (two A fragments = the weights), N = 32 strip pixels per
+    // tile, K = 16 = 9 taps + 1 bias slot + 6 zeros -- half the matrix-core time of a K = 32 instruction, and both
+    // k-groups of lanes (lane / 32) carry window data.  K slots of k-group 0: the window's (r0c0 r0c1)(r1c0 r1c1)
+    // (r2c0 r2c1)(r0c2 r1c2); k-group 1: r2c2, then the bias (its pixel-side slot is forced to 1.0), then zeros.
+    const int l32 = lane & 31, kg1 = lane >> 5;
+    bf16x8 w1frag[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const float* wr_ = w1 + (ct * 16 + (lane & 15)) * KTAPS;
+    for (int ct = 0; ct < 2; ++ct) {
+        const float* wr_ = w1 + (ct * 32 + l32) * KTAPS;
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (kg == 0) u = make_uint4(pk_bf16(wr_[0], wr_[1]), pk_bf16(wr_[3], wr_[4]), pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[2], wr_[5]));
-        else if (kg == 1) u.x = pk_bf16(wr_[8], b1[ct * 16 + (lane & 15)]);
+        if (kg1 == 0) u = make_uint4(pk_bf16(wr_[0], wr_[1]), pk_bf16(wr_[3], wr_[4]), pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[2], wr_[5]));
+        else u.x = pk_bf16(wr_[8], b1[ct * 32 + l32]);
         w1frag[ct] = *reinterpret_cast<bf16x8*>(&u);
     }
-    const uint32_t one_mask = kg == 1 ? 0xFFFF0000u : 0u;      // k-group 1 lanes: high half of dword 0 := bf16(1.0)
+    const uint32_t one_mask = kg1 == 1 ? 0xFFFF0000u : 0u;     // k-group 1 lanes: high half of dword 0 := bf16(1.0)
     f32x4 b2r;
 #pragma unroll
     for (int r = 0; r < 4; ++r) b2r[r] = kh == 0 ? b2[nt * 16 + kg * 4 + r] : 0.0f;
@@ -175,17 +180,18 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
     int tin[TPW], tout[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-        const int q = (wave + 4 * j) * 16 + (lane & 15);
+        const int q = (wave + 4 * j) * 32 + l32;
         const int qq = q < R1 * OW1 ? q : R1 * OW1 - 1;
         const int cr = qq / OW1, cc = qq - cr * OW1;
-        tin[j] = (2 * cr) * RS + 2 * cc + (kg == 1 ? 2 * RS + 2 : 0);
-        tout[j] = (((q < R1 * OW1) ? (cr * (OW1 + 1) + cc) * PIX_STRIDE : dummy_off) + kg * 8) | (cr << 24);
+        tin[j] = (2 * cr) * RS + 2 * cc + (kg1 == 1 ? 2 * RS + 2 : 0);
+        tout[j] = (((q < R1 * OW1) ? (cr * (OW1 + 1) + cc) * PIX_STRIDE : dummy_off) + kg1 * 8) | (cr << 24);
     }
 
     const int P = SR * OW2;                 // output pixels per strip
-    int poff[MT_MAX];                       // conv2: byte offset of the lane's pixel window in the conv1 image
+    constexpr int MS = (MT + 1) / 2;        // pixel tiles finished by the kh = 0 waves
+    int poff[MT];                       // conv2: byte offset of the lane's pixel window in the conv1 image
 #pragma unroll
-    for (int m = 0; m < MT_MAX; ++m) {
+    for (int m = 0; m < MT; ++m) {
         int q = m * 16 + (lane & 15);
         q = q < P ? q : P - 1;
         const int pr = q / OW2, pc = q - pr * OW2;
@@ -227,45 +233,42 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
             for (int i = lo + tid; i < R1 * (OW1 + 1) * (PIX_STRIDE / 16); i += 256) *reinterpret_cast<uint4*>(c1_s + i * 16) = z;
         }
         const uint16_t* plane0 = in_s + (4 * r0) * RS;
+        {
+            // the wave's (up to TPW) tiles: all window reads in flight before the first MFMA
+            uint4 u[TPW];
+            int to[TPW];
 #pragma unroll
-        for (int g = 0; g < TPW / 3; ++g) {
-            if (12 * g < NT1) {             // three tiles at a time: all window reads in flight before the first MFMA
-                uint4 u[3];
-                int to[3];
+            for (int i = 0; i < TPW; ++i) {
+                const uint16_t* xin = plane0 + tin[i];
+                u[i].x = (*reinterpret_cast<const uint32_t*>(xin) & ~one_mask) | (0x3F800000u & one_mask);
+                u[i].y = *reinterpret_cast<const uint32_t*>(xin + RS);
+                u[i].z = *reinterpret_cast<const uint32_t*>(xin + 2 * RS);
+                u[i].w = (uint32_t)xin[2] | ((uint32_t)xin[RS + 2] << 16);
+                to[i] = (tout[i] >> 24) < live ? (tout[i] & 0xFFFFFF) : dummy_off + kg1 * 8;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // C/D map of the 32x32 tile: column (pixel) lane & 31, rows (channels) ct*32 + 8*(r/4) + 4*(lane/32) + r%4:
+            // every four accumulator registers are 4 consecutive channels of the lane's pixel = one 8-byte store
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const uint16_t* xin = plane0 + tin[3 * g + i];
-                    u[i].x = (*reinterpret_cast<const uint32_t*>(xin) & ~one_mask) | (0x3F800000u & one_mask);
-                    u[i].y = *reinterpret_cast<const uint32_t*>(xin + RS);
-                    u[i].z = *reinterpret_cast<const uint32_t*>(xin + 2 * RS);
-                    u[i].w = (uint32_t)xin[2] | ((uint32_t)xin[RS + 2] << 16);
-                    to[i] = (tout[3 * g + i] >> 24) < live ? (tout[3 * g + i] & 0xFFFFFF) : dummy_off + kg * 8;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // C/D map: rows (channels) ct*16 + (lane>>4)*4 + r, column (pixel) lane&15.  Two tiles in flight: the
-                // MFMAs of tile i+1 are issued before the results of tile i are converted and stored
-                f32x4 c[2][4];
-                auto mm = [&](int i) {
+            for (int i = 0; i < TPW; ++i) {
+                if (wave + 4 * i < NT1) {
                     const bf16x8 xfrag = *reinterpret_cast<bf16x8*>(&u[i]);
+                    f32x16 c[2];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        c[i & 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1frag[ct], xfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                };
-                auto st = [&](int i) {
+                    for (int ct = 0; ct < 2; ++ct) {
+                        f32x16 z;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        *reinterpret_cast<uint2*>(c1_s + to[i] + ct * 32) =
-                            make_uint2(pk_relu(pk_bf16(c[i & 1][ct][0], c[i & 1][ct][1])), pk_relu(pk_bf16(c[i & 1][ct][2], c[i & 1][ct][3])));
-                };
-                mm(0);
-                mm(1);
-                __builtin_amdgcn_sched_barrier(0);
-                st(0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(2);
-                __builtin_amdgcn_sched_barrier(0);
-                st(1);
-                st(2);
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        c[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1frag[ct], xfrag, z, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<uint2*>(c1_s + to[i] + ct * 64 + j * 16) =
+                                make_uint2(pk_relu(pk_bf16(c[ct][4 * j], c[ct][4 * j + 1])), pk_relu(pk_bf16(c[ct][4 * j + 2], c[ct][4 * j + 3])));
+                }
             }
         }
 #ifdef RML_DNN_TIMING
@@ -275,21 +278,21 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #ifdef RML_DNN_TIMING
         t2_ = __builtin_readcyclecounter();
 #endif
-        // 3. conv2 as implicit GEMM: wave = (K half kh, channel tile nt), all MT_MAX pixel tiles (tiles past the strip
+        // 3. conv2 as implicit GEMM: wave = (K half kh, channel tile nt), all MT pixel tiles (tiles past the strip
         //    recompute its last pixel and are dropped in the epilogue: no divergent loads in the MFMA loop)
-        f32x4 acc[MT_MAX];
+        f32x4 acc[MT];
 #pragma unroll
-        for (int m = 0; m < MT_MAX; ++m) acc[m] = b2r;
+        for (int m = 0; m < MT; ++m) acc[m] = b2r;
         {
             // software pipeline over the wave's 9 K-steps: the fragment reads of step t+2 are issued before the MFMAs
             // of step t, so an LDS round trip is always covered by ten MFMAs
-            bf16x8 afrag[3][MT_MAX];
-            auto ldk = [&](int tt, bf16x8 (&dst)[MT_MAX]) {
+            bf16x8 afrag[3][MT];
+            auto ldk = [&](int tt, bf16x8 (&dst)[MT]) {
                 const int ks = kh * 9 + tt;
                 const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3;
                 const int aoff = (ky * (OW1 + 1) + kx) * PIX_STRIDE + (ks & 1) * 64;
 #pragma unroll
-                for (int m = 0; m < MT_MAX; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(c1_s + poff[m] + aoff);
+                for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(c1_s + poff[m] + aoff);
             };
             ldk(0, afrag[0]);
             ldk(1, afrag[1]);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
                 if (tt + 2 < 9) ldk(tt + 2, afrag[(tt + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT_MAX; ++m)
+                for (int m = 0; m < MT; ++m)
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tt], afrag[tt % 3][m], acc[m], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -307,14 +310,14 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #ifdef RML_DNN_TIMING
         t3_ = __builtin_readcyclecounter();
 #endif
-        // K-split reduction, both halves busy: the kh=0 wave finishes pixel tiles 0..2, the kh=1 wave tiles 3..4;
+        // K-split reduction, both halves busy: the kh=0 wave finishes pixel tiles 0..MS-1, the kh=1 wave the rest;
         // each hands the other its partials of the tiles it does not finish
         if (kh == 0) {
 #pragma unroll
-            for (int m = 3; m < MT_MAX; ++m) *reinterpret_cast<f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4) = acc[m];
+            for (int m = MS; m < MT; ++m) *reinterpret_cast<f32x4*>(red_s + ((nt * MT + m) * 64 + lane) * 4) = acc[m];
         } else {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4) = acc[m];
+            for (int m = 0; m < MS; ++m) *reinterpret_cast<f32x4*>(red_s + ((nt * MT + m) * 64 + lane) * 4) = acc[m];
         }
         lds_barrier();                    // partials visible
         // C/D map: rows (channels) nt*16 + (lane>>4)*4 + r, column (pixel) lane&15: a lane holds 4 consecutive channels
@@ -324,10 +327,10 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
         const int Pv = rows * OW2;
         uint16_t* dst0 = a.feat + b * (int64_t)OH2 * OW2 * 96 + (int64_t)r0 * OW2 * 96 + br * 32 + nt * 16 + kg * 4;
 #pragma unroll
-        for (int m = 0; m < MT_MAX; ++m) {
-            if ((m < 3) == (kh == 0)) {
+        for (int m = 0; m < MT; ++m) {
+            if ((m < MS) == (kh == 0)) {
                 const int q = m * 16 + (lane & 15);
-                const f32x4 o = *reinterpret_cast<const f32x4*>(red_s + ((nt * MT_MAX + m) * 64 + lane) * 4);
+                const f32x4 o = *reinterpret_cast<const f32x4*>(red_s + ((nt * MT + m) * 64 + lane) * 4);
                 const f32x4 s4 = acc[m] + o;
                 if (q < Pv)
                     *reinterpret_cast<uint2*>(dst0 + q * 96) = make_uint2(pk_relu(pk_bf16(s4[0], s4[1])), pk_relu(pk_bf16(s4[2], s4[3])));
@@ -346,15 +349,16 @@ __global__ __launch_bounds__(256, 2) void k_dnn_trunk(TrunkArgs a) {
 #endif
 }
 
-template <int SR, bool INBF>
+template <int SR, bool INBF, int MT, bool PF, int WPC>
 int launch_trunk(const TrunkArgs& a, int num_cu, hipStream_t stream) {
-    const TrunkLayout L(a.H, a.W, SR);
-    if (SR * (a.W / 4) > 16 * MT_MAX || L.nt1 > 4 * TPW || L.total > 150 * 1024) return RML_ERR_UNSUPPORTED;
+    const TrunkLayout L(a.H, a.W, SR, MT);
+    if (SR * (a.W / 4) > 16 * MT || L.nt1 > 4 * TPW || L.total > 150 * 1024) return RML_ERR_UNSUPPORTED;
+    if (L.total * WPC > 160 * 1024) return RML_ERR_UNSUPPORTED;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR, INBF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
-    const int64_t slots = L.total <= 80 * 1024 ? 2 * (int64_t)num_cu : num_cu;      // workgroups resident at once
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR, INBF, MT, PF, WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    const int64_t slots = (int64_t)WPC * num_cu;                                     // workgroups resident at once
     const int64_t gx = slots / 3 > 0 ? slots / 3 : 1;
-    hipLaunchKernelGGL((k_dnn_trunk<SR, INBF>), dim3((unsigned)(a.B < gx ? a.B : gx), 3), dim3(256), L.total, stream, a);
+    hipLaunchKernelGGL((k_dnn_trunk<SR, INBF, MT, PF, WPC>), dim3((unsigned)(a.B < gx ? a.B : gx), 3), dim3(256), L.total, stream, a);
     return RML_OK;
 }
 
@@ -363,11 +367,13 @@ int launch_trunk(const TrunkArgs& a, int num_cu, hipStream_t stream) {
 namespace {
 template <bool INBF>
 int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
-    // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
     int rc = RML_ERR_UNSUPPORTED;
-    if (4 * (a.W / 4) <= 16 * MT_MAX && TrunkLayout(a.H, a.W, 4).total <= 80 * 1024) rc = launch_trunk<4, INBF>(a, num_cu, st);
-    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<2, INBF>(a, num_cu, st);
-    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<1, INBF>(a, num_cu, st);
+    // (measured and dropped: 2-row strips at three workgroups per CU -- 148 VGPRs, 49 KB LDS -- 0.78 ms against 0.69:
+    // the extra conv1 rows, tile padding and barriers cost more than the third wave per SIMD hides)
+    // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<4, INBF, 5, true, 2>(a, num_cu, st);
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<2, INBF, 5, true, 1>(a, num_cu, st);
+    if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<1, INBF, 5, true, 1>(a, num_cu, st);
     return rc;
 }
 }  // namespace
