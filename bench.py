@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-walabot", action="store_true", help="skip the secondary Walabot-arena-grid workload")
     ap.add_argument("--no-u8", action="store_true", help="skip the uint8-ingest row (the same frames as 1-byte voxels)")
     ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
+    ap.add_argument("--no-dnn", action="store_true", help="skip the multi-view CNN inference row (BASELINE configs[3])")
+    ap.add_argument("--dnn-frames", type=int, default=65536, help="frames per GPU of the CNN inference row")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -326,6 +328,65 @@ def run_workload(a, env, grid, frames, primary):
     return res
 
 
+def run_dnn(a, env):
+    """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection (csrc/project.hip) ->
+    [-1,1] scaling + Pillow-exact bicubic resize to 80x80 (csrc/resize.hip) -> fused conv trunk (csrc/dnn.hip) -> dense
+    tail (hipBLASLt through PyTorch), bf16, random-init weights of the reference's architecture (dnn.py:45-91).
+    Frames are sharded over the ranks, nothing is exchanged.  Returns the result dict on rank 0."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    rml, dev, rank, world = env["rml"], env["dev"], env["rank"], env["world"]
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    X, Y, Z = 22, 31, 176
+    B = a.dnn_frames
+    torch.manual_seed(a.seed)
+    model = dnn.define_classifier(device=dev).eval()
+    V, _ = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 7, frame0=rank * B, device=dev)
+    res = {}
+    for tag, vol in (("f32", V), ("u8", V.to(torch.uint8))):
+        for _ in range(max(1, a.warmup)):
+            p = model.predict_volumes(vol)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            p = model.predict_volumes(vol)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        res[tag] = (float(dt.item()), p)
+    if rank != 0:
+        return None
+    # parity on a few frames: NumPy restatement of the whole chain (oracle projections, Pillow restatement, Keras layers)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_np as O
+    npar = 8
+    vh = V[:npar].cpu().numpy()
+    planes = [[], [], []]
+    for v in vh:
+        for i, pr in enumerate(O.project_max(v)):
+            planes[i].append(O.pil_resize_bicubic(O.scale_unit_range(pr), (80, 80)))
+    convs, dense = model.keras_weights()
+    want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
+    got = res["f32"][1][:npar].float().cpu().numpy()
+    out = {"metric": "radar frames/s (3D-proj->resize->CNN forward)", "unit": "frames/s", "dtype": "bf16 operands, f32 accumulate",
+           "value": round(world * B * a.steps / res["f32"][0], 1), "ms_per_step": round(res["f32"][0] / a.steps * 1e3, 3),
+           "value_uint8_volumes": round(world * B * a.steps / res["u8"][0], 1),
+           "uint8_identical_labels": bool(torch.equal(res["u8"][1].argmax(1), res["f32"][1].argmax(1))),
+           "config": {"workload": "configs[3]: %d frames/GPU of %dx%dx%d -> 3 x 80x80 -> multi-view CNN (2.52 M parameters, "
+                                  "54.7 MFLOP/frame), random-init weights" % (B, X, Y, Z), "frames_per_gpu": B},
+           "parity": {"frames": npar, "proba_max_abs_err_vs_float64_oracle": float(np.abs(got - want).max()),
+                      "label_mismatch": int((got.argmax(1) != want.argmax(1)).sum())}}
+    return out
+
+
 def main():
     a = parse()
     import torch
@@ -357,6 +418,10 @@ def main():
     if not a.no_walabot and grid != (22, 31, 176):
         wal = run_workload(a, env, (22, 31, 176), a.walabot_frames, primary=False)
 
+    dnn_row = None
+    if not a.no_dnn:
+        dnn_row = run_dnn(a, env)
+
     if rank == 0:
         line = {
             "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
@@ -370,6 +435,8 @@ def main():
         }
         if wal is not None:
             line["walabot_grid"] = wal
+        if dnn_row is not None:
+            line["dnn_forward"] = dnn_row
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
