@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
     ap.add_argument("--no-dnn", action="store_true", help="skip the multi-view CNN inference row (BASELINE configs[3])")
     ap.add_argument("--dnn-frames", type=int, default=65536, help="frames per GPU of the CNN inference row")
+    ap.add_argument("--no-sgan", action="store_true", help="skip the SGAN discriminator train-step row (configs[4]; N = 1 only)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -387,6 +388,36 @@ def run_dnn(a, env):
     return out
 
 
+def run_sgan(a, env):
+    """BASELINE configs[4] on one GPU: the SGAN discriminator/classifier train step (c_model + d_model(real) updates,
+    sgan.py:525-532) on 128x128 projections, PyTorch-ROCm (MIOpen convolutions), fp16 autocast with loss scaling."""
+    import importlib
+    import torch
+    dev = env["dev"]
+    sgan = importlib.import_module("radar_ml_amd.sgan")
+    n = 256
+    d = sgan.define_discriminator(device=dev)
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16", ddp=False)
+    g = torch.Generator(device=dev).manual_seed(a.seed)
+    x = [torch.rand((n, 128, 128), device=dev, generator=g) * 2 - 1 for _ in range(3)]
+    y = torch.randint(0, 3, (n,), device=dev, generator=g)
+    yr = torch.full((n, 1), 0.9, device=dev)
+    for _ in range(3):
+        tr.train_on_batch_c(x, y)
+        tr.train_on_batch_d(x, yr)
+    torch.cuda.synchronize(dev)
+    steps = max(10, a.steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lc, acc = tr.train_on_batch_c(x, y)
+        ld = tr.train_on_batch_d(x, yr)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(2 * n / dt, 1), "unit": "samples/s",
+            "ms_per_step": round(dt * 1e3, 2), "batch": n, "dtype": "fp16 autocast (MIOpen), fp32 master weights",
+            "c_loss": round(lc, 4), "d_loss": round(ld, 4)}
+
+
 def main():
     a = parse()
     import torch
@@ -422,6 +453,13 @@ def main():
     if not a.no_dnn:
         dnn_row = run_dnn(a, env)
 
+    sgan_row = None
+    if not a.no_sgan and world == 1:
+        try:
+            sgan_row = run_sgan(a, env)
+        except Exception as e:          # a library-side failure must not cost the headline line
+            sgan_row = {"error": repr(e)[:200]}
+
     if rank == 0:
         line = {
             "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
@@ -437,6 +475,8 @@ def main():
             line["walabot_grid"] = wal
         if dnn_row is not None:
             line["dnn_forward"] = dnn_row
+        if sgan_row is not None:
+            line["sgan_train_step"] = sgan_row
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
