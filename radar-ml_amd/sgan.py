@@ -101,8 +101,11 @@ class DiscriminatorTrainer:
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.net = DDP(model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                            gradient_as_bucket_view=True)
-        self.opt_c = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7)
-        self.opt_d = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7)
+        # Adam(lr=0.0002, beta_1=0.5), Keras epsilon 1e-7 (sgan.py:206,214); one fused update kernel on the GPU
+        # (the per-parameter kernels of the default implementation were 8 % of the step)
+        fused = self.device.type == "cuda"
+        self.opt_c = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7, fused=fused)
+        self.opt_d = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7, fused=fused)
         self.amp_dtype = getattr(torch, amp_dtype) if (amp_dtype and self.device.type == "cuda") else None
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
 
