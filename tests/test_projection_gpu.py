@@ -311,3 +311,28 @@ def test_uint8_random_shapes_property(rml):
         np.testing.assert_array_equal(isq.cpu().numpy(), (rows.astype(np.int64) ** 2).sum(1))
 
     check()
+
+
+def test_misaligned_and_strided_volume_views(rml):
+    """Volumes that start at an odd element of a larger buffer (no 16-byte alignment: the vector kernels must step aside)
+    and non-contiguous views (made contiguous by the front door) give the same projections."""
+    import torch
+    X, Y, Z = 6, 9, 48
+    rng = np.random.default_rng(3)
+    raw8 = torch.from_numpy(rng.integers(0, 256, 3 * X * Y * Z + 7, dtype=np.uint8)).cuda()
+    rawf = raw8.float()
+    for off in (0, 1, 3, 4):
+        v8 = raw8[off:off + 3 * X * Y * Z].view(3, X, Y, Z)
+        vf = rawf[off:off + 3 * X * Y * Z].view(3, X, Y, Z)
+        want = O.project_max(vf.cpu().numpy())
+        for v in (v8, vf):
+            assert v.is_contiguous()
+            got = rml.project(v, mode="max")
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g.cpu().numpy(), w)
+    big = torch.from_numpy(rng.integers(0, 256, (3, X, Y, 2 * Z), dtype=np.uint8)).cuda()
+    view = big[..., ::2]                                   # stride 2 along z
+    assert not view.is_contiguous()
+    got = rml.project(view, mode="max")
+    for g, w in zip(got, O.project_max(view.float().cpu().numpy())):
+        np.testing.assert_array_equal(g.cpu().numpy(), w)
