@@ -245,6 +245,31 @@ int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, 
                   const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
                   uint16_t* feat, void* stream);
 
+/* ---- SGAN discriminator branches: fused BatchNorm(train) + LeakyReLU + 'same' pad (sgan.py:137-158) -------------
+ * x: N x H x W x C (NHWC, dense) float16 (dtype 0) or bfloat16 (dtype 1), the convolution output; y: N x (H+pad_h) x
+ * (W+pad_w) x C, the zero-padded input of the next stride-2 'same' convolution (pad 0: plain output).  Batch
+ * statistics in float32/float64 (deterministic), running estimates updated as torch.nn.BatchNorm2d does
+ * (momentum = 1 - Keras momentum).  workspace: rml_bn_workspace_floats(ctx, C) + 2*C floats (all three entry points).  backward: dy has y's
+ * layout; returns dx (x's layout) and the float32 parameter gradients. */
+int64_t rml_bn_workspace_floats(rml_ctx* ctx, int C);
+int rml_bn_lrelu_pad_forward(rml_ctx* ctx, const void* x, int dtype, int64_t N, int H, int W, int C, int pad_h, int pad_w,
+                             const float* gamma, const float* beta, float eps, float momentum, float slope,
+                             float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                             float* workspace, void* y, void* stream);
+int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void* dy, int dtype, int64_t N, int H, int W, int C,
+                              int pad_h, int pad_w, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_rstd, float slope, float* workspace, void* dx, float* dgamma, float* dbeta,
+                              void* stream);
+
+/* Backward of [3x3 stride-2 'same' convolution of a 1-channel image] + BatchNorm + LeakyReLU + pad (the first layer of a
+ * branch; the image needs no gradient): z = the convolution output (bias-free), image = its zero-padded half-precision
+ * input N x (2H+1) x (2W+1); returns the weight gradient dweight[tap][c] (tap = ky*3+kx) and the batch-norm parameter
+ * gradients without ever materialising the gradient of z. */
+int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, const void* dy, const void* image, int dtype, int64_t N,
+                                    int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_rstd, float slope, float* workspace,
+                                    float* dweight, float* dgamma, float* dbeta, void* stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------- */
 int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
                       int n_classes, float* V, int32_t* cls /* B or NULL */, void* stream);

@@ -66,6 +66,14 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "rml_dnn_trunk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p]),
+    "rml_bn_workspace_floats": (c_int64, [c_void_p, c_int]),
+    "rml_bn_lrelu_pad_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_bn_lrelu_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_bn_lrelu_pad_backward_conv1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
 }

@@ -1,0 +1,405 @@
+// Fused training-mode BatchNorm + LeakyReLU + TensorFlow-'same' zero pad for the SGAN discriminator branches
+// (sgan.py:137-158: Conv2D -> BatchNormalization -> LeakyReLU(0.2), three times per branch) on NHWC half tensors.
+//
+// In PyTorch these are separate passes over the layer activation (268 MB for layer 1 at batch 256): batch-norm
+// statistics, normalise, LeakyReLU, the pad copy in front of the next stride-2 convolution, and the mirror images of all
+// of them in backward -- 12 of the step's 19 ms of GPU time.  Here the forward is two passes (per-channel sums; then
+// normalise + LeakyReLU written straight into the padded layout the next convolution reads) and the backward two
+// (per-channel sums of g and g*x_hat with g = dy * leaky'(z); then dx), all HBM-bound streaming over 16-byte
+// (8-channel) lanes.  Statistics are float32 partial sums per workgroup, combined in a fixed order in float64:
+// deterministic.  Algorithmic bytes per element (2-byte activations): forward 2 + 2 + 2, backward 2*(2 + 2) + 2.
+//
+// Semantics = torch.nn.BatchNorm2d(training) (biased variance for the normalisation, unbiased for the running
+// estimate, momentum m: running = (1-m)*running + m*batch) followed by LeakyReLU(slope) and F.pad(0, pw, 0, ph).
+#include "rml_internal.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+template <bool BF> __device__ __forceinline__ float h2f(uint16_t h);
+template <> __device__ __forceinline__ float h2f<true>(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+template <> __device__ __forceinline__ float h2f<false>(uint16_t h) {
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+}
+template <bool BF> __device__ __forceinline__ uint16_t f2h(float f);
+template <> __device__ __forceinline__ uint16_t f2h<true>(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <> __device__ __forceinline__ uint16_t f2h<false>(float f) {
+    _Float16 v = (_Float16)f;
+    uint16_t h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+}
+
+template <bool BF> __device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = h2f<BF>((uint16_t)(w[i] & 0xFFFFu)); v[2 * i + 1] = h2f<BF>((uint16_t)(w[i] >> 16)); }
+}
+template <bool BF> __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2h<BF>(v[2 * i]) | ((uint32_t)f2h<BF>(v[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// workgroup-level sum of per-thread [2][8] partials over the threads that share a channel group -> part[blockIdx][2][C]
+__device__ __forceinline__ void block_channel_sums(const float (&a)[8], const float (&b)[8], int CG, int C, float* part, float* lds) {
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG, PL = kT / CG;
+    float* mine = lds + (size_t)tid * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mine[i] = a[i]; mine[8 + i] = b[i]; }
+    __syncthreads();
+    // thread (cg, j) for j < 16 sums column j of its channel group over the PL pixel lanes
+    for (int item = tid; item < CG * 16; item += kT) {
+        const int g = item / 16, j = item - g * 16;
+        float s = 0.0f;
+        for (int p = 0; p < PL; ++p) s += lds[(size_t)(p * CG + g) * 16 + j];
+        part[(size_t)blockIdx.x * 2 * C + (j >> 3) * C + g * 8 + (j & 7)] = s;
+    }
+    (void)cg; (void)pl;
+}
+
+// ---- forward pass 1: per-channel sum and sum of squares ---------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_bn_stats(const uint16_t* __restrict__ x, int64_t M, int C, float* part) {
+    __shared__ float lds[kT * 16];
+    const int CG = C >> 3, PL = kT / CG;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
+    if (pl < PL) {
+        for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
+            float v[8];
+            unpack8<BF>(*reinterpret_cast<const uint4*>(x + p * C + cg * 8), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+        }
+    }
+    block_channel_sums(s, q, CG, C, part, lds);
+}
+
+// ---- combine the workgroup partials in a fixed order (float64) -----------------------------------------------------
+// mode 0 (forward): a = sum x, b = sum x^2 -> mean, rstd, running statistics.  mode 1 (backward): a = sum g,
+// b = sum g*x_hat -> dbeta, dgamma, c1 = a/M, c2 = b/M.
+__global__ __launch_bounds__(kT) void k_bn_finalize(const float* part, int G, int C, double M, int mode, float eps, float momentum,
+                                                    float* o0, float* o1, float* o2, float* o3) {
+    // one workgroup per channel: strided float64 partial sums, then a fixed-shape tree
+    __shared__ double sa[kT], sb[kT];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int g = t; g < G; g += kT) { a += (double)part[(size_t)g * 2 * C + c]; b += (double)part[(size_t)g * 2 * C + C + c]; }
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    for (int off = kT / 2; off >= 1; off >>= 1) {
+        if (t < off) { sa[t] += sa[t + off]; sb[t] += sb[t + off]; }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    a = sa[0]; b = sb[0];
+    if (mode == 0) {
+        const double mean = a / M;
+        double var = b / M - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        o0[c] = (float)mean;
+        o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (o2) o2[c] = (float)((1.0 - (double)momentum) * (double)o2[c] + (double)momentum * mean);                     // running_mean
+        if (o3) o3[c] = (float)((1.0 - (double)momentum) * (double)o3[c] + (double)momentum * var * (M > 1.0 ? M / (M - 1.0) : 1.0));
+    } else {
+        o0[c] = (float)a;            // dbeta
+        o1[c] = (float)b;            // dgamma
+        o2[c] = (float)(a / M);
+        o3[c] = (float)(b / M);
+    }
+}
+
+// ---- forward pass 2: normalise + LeakyReLU, written into the (H+ph) x (W+pw) padded layout ---------------------------
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_bn_apply_pad(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C,
+                                                     int ph, int pw, const float* mean, const float* rstd, const float* gamma,
+                                                     const float* beta, float slope) {
+    const int CG = C >> 3, Wp = W + pw, Hp = H + ph;
+    const int64_t row = blockIdx.x;                 // n * Hp + h
+    const int64_t n = row / Hp;
+    const int h = (int)(row - n * Hp);
+    uint16_t* yr = y + row * (int64_t)Wp * C;
+    const uint16_t* xr = x + (n * H + h) * (int64_t)W * C;
+    for (int item = threadIdx.x; item < Wp * CG; item += kT) {
+        const int w = item / CG, cg = item - w * CG;
+        uint4 out = make_uint4(0, 0, 0, 0);
+        if (h < H && w < W) {
+            float v[8], r[8];
+            unpack8<BF>(*reinterpret_cast<const uint4*>(xr + (int64_t)w * C + cg * 8), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cg * 8 + i;
+                const float z = (v[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+                r[i] = z > 0.0f ? z : z * slope;
+            }
+            out = pack8<BF>(r);
+        }
+        *reinterpret_cast<uint4*>(yr + (int64_t)w * C + cg * 8) = out;
+    }
+}
+
+// ---- backward pass 1: sum g and sum g * x_hat, g = dy * leaky'(z) --------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_bn_bwd_reduce(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t N, int H, int W,
+                                                      int C, int ph, int pw, const float* mean, const float* rstd, const float* gamma,
+                                                      const float* beta, float slope, float* part) {
+    __shared__ float lds[kT * 16];
+    const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    const int64_t M = N * H * W;
+    float s[8], q[8], mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s[i] = 0.0f; q[i] = 0.0f;
+        const int c = cg * 8 + i;
+        mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c];
+    }
+    if (pl < PL) {
+        for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
+            const int64_t nh = p / W;
+            const int w = (int)(p - nh * W);
+            const int64_t n = nh / H;
+            const int h = (int)(nh - n * H);
+            float v[8], d[8];
+            unpack8<BF>(*reinterpret_cast<const uint4*>(x + p * C + cg * 8), v);
+            unpack8<BF>(*reinterpret_cast<const uint4*>(dy + ((n * Hp + h) * (int64_t)Wp + w) * C + cg * 8), d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[i] - mu[i]) * rs[i];
+                const float z = xh * ga[i] + be[i];
+                const float g = z > 0.0f ? d[i] : d[i] * slope;
+                s[i] += g;
+                q[i] = fmaf(g, xh, q[i]);
+            }
+        }
+    }
+    block_channel_sums(s, q, CG, C, part, lds);
+}
+
+// ---- backward pass 2: dx = gamma * rstd * (g - c1 - x_hat * c2) ----------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_bn_bwd_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+                                                     int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
+                                                     const float* gamma, const float* beta, const float* c1, const float* c2, float slope) {
+    const int CG = C >> 3, Wp = W + pw, Hp = H + ph;
+    const int64_t row = blockIdx.x;                 // n * H + h
+    const int64_t n = row / H;
+    const int h = (int)(row - n * H);
+    const uint16_t* xr = x + row * (int64_t)W * C;
+    const uint16_t* dr = dy + (n * Hp + h) * (int64_t)Wp * C;
+    uint16_t* or_ = dx + row * (int64_t)W * C;
+    for (int item = threadIdx.x; item < W * CG; item += kT) {
+        const int w = item / CG, cg = item - w * CG;
+        float v[8], d[8], r[8];
+        unpack8<BF>(*reinterpret_cast<const uint4*>(xr + (int64_t)w * C + cg * 8), v);
+        unpack8<BF>(*reinterpret_cast<const uint4*>(dr + (int64_t)w * C + cg * 8), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cg * 8 + i;
+            const float xh = (v[i] - mean[c]) * rstd[c];
+            const float z = xh * gamma[c] + beta[c];
+            const float g = z > 0.0f ? d[i] : d[i] * slope;
+            r[i] = gamma[c] * rstd[c] * (g - c1[c] - xh * c2[c]);
+        }
+        *reinterpret_cast<uint4*>(or_ + (int64_t)w * C + cg * 8) = pack8<BF>(r);
+    }
+}
+
+// ---- backward pass 2 of the FIRST layer of a branch: the convolution in front has a 1-channel input that needs no
+// gradient, so dz = gamma * rstd * (g - c1 - x_hat * c2) is not written at all -- it is multiplied with the 9 input
+// taps of its pixel on the fly and summed into the weight gradient dW[k][c] (tap k = ky*3 + kx of the 3x3 stride-2
+// convolution; the padded input image is tiny and L1/L2 resident).  Workgroup partials [G][9][C], combined by
+// k_sum_partials in a fixed order.
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_bn_bwd_wgrad1(const uint16_t* __restrict__ z, const uint16_t* __restrict__ dy,
+                                                      const uint16_t* __restrict__ img, int64_t N, int H, int W, int C, int ph, int pw,
+                                                      const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                      const float* c1, const float* c2, float slope, float* part) {
+    __shared__ float lds[kT * 8];
+    const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
+    const int IH = 2 * H + 1, IW = 2 * W + 1;           // the 'same'-padded input of a stride-2 3x3 convolution
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    const int64_t M = N * H * W;
+    float acc[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[k][i] = 0.0f;
+    float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c]; k1[i] = c1[c]; k2[i] = c2[c];
+    }
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
+        const int64_t nh = p / W;
+        const int w = (int)(p - nh * W);
+        const int64_t n = nh / H;
+        const int h = (int)(nh - n * H);
+        float v[8], d[8], t[9];
+        unpack8<BF>(*reinterpret_cast<const uint4*>(z + p * C + cg * 8), v);
+        unpack8<BF>(*reinterpret_cast<const uint4*>(dy + ((n * Hp + h) * (int64_t)Wp + w) * C + cg * 8), d);
+        const uint16_t* ip = img + (n * IH + 2 * h) * (int64_t)IW + 2 * w;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = h2f<BF>(ip[ky * IW + kx]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (v[i] - mu[i]) * rs[i];
+            const float zz = xh * ga[i] + be[i];
+            const float g = zz > 0.0f ? d[i] : d[i] * slope;
+            const float dz = ga[i] * rs[i] * (g - k1[i] - xh * k2[i]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(dz, t[k], acc[k][i]);
+        }
+    }
+    // per tap: sum the pixel lanes of the workgroup in a fixed order
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
+        __syncthreads();
+        for (int c = tid; c < C; c += kT) {
+            float s = 0.0f;
+            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
+            part[((size_t)blockIdx.x * 9 + k) * C + c] = s;
+        }
+    }
+}
+
+// out[j] = sum over g of part[g][j] (float64, strided partial sums + fixed tree): one workgroup per j
+__global__ __launch_bounds__(kT) void k_sum_partials(const float* part, int G, int L, float* out) {
+    __shared__ double sa[kT];
+    const int j = blockIdx.x, t = threadIdx.x;
+    double a = 0.0;
+    for (int g = t; g < G; g += kT) a += (double)part[(size_t)g * L + j];
+    sa[t] = a;
+    __syncthreads();
+    for (int off = kT / 2; off >= 1; off >>= 1) {
+        if (t < off) sa[t] += sa[t + off];
+        __syncthreads();
+    }
+    if (t == 0) out[j] = (float)sa[0];
+}
+
+int stats_grid(rml_ctx* ctx, int64_t M, int C) {
+    const int PL = kT / (C >> 3);
+    int64_t g = (M + PL - 1) / PL;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+int check_common(const char* who, rml_ctx* ctx, int64_t N, int H, int W, int C, int ph, int pw, int dtype) {
+    RML_REQUIRE(ctx && N >= 0 && H > 0 && W > 0 && C > 0, RML_ERR_INVALID, "%s: bad arguments", who);
+    RML_REQUIRE(C % 8 == 0 && C <= 2048 && kT % (C >> 3) == 0, RML_ERR_UNSUPPORTED, "%s: C = %d (multiples of 8 that divide 2048)", who, C);
+    RML_REQUIRE((ph == 0 || ph == 1) && (pw == 0 || pw == 1), RML_ERR_INVALID, "%s: pad must be 0 or 1", who);
+    RML_REQUIRE(dtype == 0 || dtype == 1, RML_ERR_INVALID, "%s: dtype 0 = float16, 1 = bfloat16", who);
+    RML_REQUIRE(N * (int64_t)(H + ph) < ((int64_t)1 << 31), RML_ERR_UNSUPPORTED, "%s: too many rows for one launch", who);
+    return RML_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t rml_bn_workspace_floats(rml_ctx* ctx, int C) {
+    return ctx ? (int64_t)ctx->num_cu * 8 * 9 * C : 0;      // sized for the 9-tap partials of the conv1 backward
+}
+
+extern "C" int rml_bn_lrelu_pad_forward(rml_ctx* ctx, const void* x, int dtype, int64_t N, int H, int W, int C, int pad_h, int pad_w,
+                                        const float* gamma, const float* beta, float eps, float momentum, float slope,
+                                        float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                                        float* workspace, void* y, void* stream) {
+    int rc = check_common("rml_bn_lrelu_pad_forward", ctx, N, H, W, C, pad_h, pad_w, dtype);
+    if (rc) return rc;
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && workspace, RML_ERR_INVALID, "rml_bn_lrelu_pad_forward: NULL argument");
+    RML_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, RML_ERR_INVALID,
+                "rml_bn_lrelu_pad_forward: x and y must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = N * H * W;
+    const int G = stats_grid(ctx, M, C);
+    const uint16_t* xs = static_cast<const uint16_t*>(x);
+    uint16_t* ys = static_cast<uint16_t*>(y);
+    if (dtype) hipLaunchKernelGGL(k_bn_stats<true>, dim3(G), dim3(kT), 0, st, xs, M, C, workspace);
+    else hipLaunchKernelGGL(k_bn_stats<false>, dim3(G), dim3(kT), 0, st, xs, M, C, workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 0, eps, momentum,
+                       save_mean, save_rstd, running_mean, running_var);
+    const unsigned rows = (unsigned)(N * (H + pad_h));
+    if (dtype) hipLaunchKernelGGL(k_bn_apply_pad<true>, dim3(rows), dim3(kT), 0, st, xs, ys, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+    else hipLaunchKernelGGL(k_bn_apply_pad<false>, dim3(rows), dim3(kT), 0, st, xs, ys, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void* dy, int dtype, int64_t N, int H, int W, int C,
+                                         int pad_h, int pad_w, const float* gamma, const float* beta, const float* save_mean,
+                                         const float* save_rstd, float slope, float* workspace, void* dx, float* dgamma, float* dbeta,
+                                         void* stream) {
+    int rc = check_common("rml_bn_lrelu_pad_backward", ctx, N, H, W, C, pad_h, pad_w, dtype);
+    if (rc) return rc;
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(x && dy && dx && gamma && beta && save_mean && save_rstd && workspace && dgamma && dbeta, RML_ERR_INVALID,
+                "rml_bn_lrelu_pad_backward: NULL argument");
+    RML_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0, RML_ERR_INVALID,
+                "rml_bn_lrelu_pad_backward: x, dy and dx must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = N * H * W;
+    const int G = stats_grid(ctx, M, C);
+    const uint16_t* xs = static_cast<const uint16_t*>(x);
+    const uint16_t* ds = static_cast<const uint16_t*>(dy);
+    uint16_t* os = static_cast<uint16_t*>(dx);
+    float* c1 = workspace + (size_t)G * 2 * C;          // the two per-channel means live behind the partials
+    float* c2 = c1 + C;
+    if (dtype) hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(G), dim3(kT), 0, st, xs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
+    else hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(G), dim3(kT), 0, st, xs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
+    const unsigned rows = (unsigned)(N * H);
+    if (dtype) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(rows), dim3(kT), 0, st, xs, ds, os, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope);
+    else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(rows), dim3(kT), 0, st, xs, ds, os, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, const void* dy, const void* image, int dtype, int64_t N,
+                                               int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
+                                               const float* save_mean, const float* save_rstd, float slope, float* workspace,
+                                               float* dweight, float* dgamma, float* dbeta, void* stream) {
+    int rc = check_common("rml_bn_lrelu_pad_backward_conv1", ctx, N, H, W, C, pad_h, pad_w, dtype);
+    if (rc) return rc;
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(z && dy && image && gamma && beta && save_mean && save_rstd && workspace && dweight && dgamma && dbeta, RML_ERR_INVALID,
+                "rml_bn_lrelu_pad_backward_conv1: NULL argument");
+    RML_REQUIRE(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, RML_ERR_INVALID,
+                "rml_bn_lrelu_pad_backward_conv1: z and dy must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = N * H * W;
+    const int G = stats_grid(ctx, M, C);
+    const uint16_t* zs = static_cast<const uint16_t*>(z);
+    const uint16_t* ds = static_cast<const uint16_t*>(dy);
+    const uint16_t* is = static_cast<const uint16_t*>(image);
+    // workspace: [G][9][C] partials (the first [G][2][C] double as the statistics partials), then c1, c2
+    float* c1 = workspace + (size_t)G * 9 * C;
+    float* c2 = c1 + C;
+    if (dtype) hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(G), dim3(kT), 0, st, zs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
+    else hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(G), dim3(kT), 0, st, zs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
+    if (dtype) hipLaunchKernelGGL(k_bn_bwd_wgrad1<true>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    else hipLaunchKernelGGL(k_bn_bwd_wgrad1<false>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    hipLaunchKernelGGL(k_sum_partials, dim3(9 * C), dim3(kT), 0, st, workspace, G, 9 * C, dweight);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

@@ -118,3 +118,160 @@ def preprocess_features(feat, grid, rescale, out_dtype="bfloat16"):
         outs.append(resize_bicubic(feat[:, off:off + h * w], (rescale[1], rescale[0]), shape=(h, w), out_dtype=out_dtype))
         off += h * w
     return outs
+
+
+def _bn_lrelu_pad_function():
+    """torch.autograd.Function around csrc/bnact.hip (built lazily: torch is imported on first use)."""
+    torch = _torch()
+    if getattr(_bn_lrelu_pad_function, "_cls", None) is not None:
+        return _bn_lrelu_pad_function._cls
+    from . import _lib
+
+    class BnLReluPad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, pad, conv_bias):
+            # conv_bias: the bias of the convolution that produced x WITHOUT it.  Batch norm subtracts the batch mean, so
+            # a per-channel constant in front of it changes nothing and its gradient is exactly zero: it is not added, and
+            # backward hands back zeros (the parameter still takes part in the graph, which DDP requires).
+            lib = _lib.load()
+            n, c, h, w = x.shape
+            dev = x.device
+            y = torch.empty((n, c, h + pad, w + pad), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            mean = torch.empty((c,), dtype=torch.float32, device=dev)
+            rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                hctx = _lib.context(dev)
+                ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
+                _lib.check(lib.rml_bn_lrelu_pad_forward(
+                    hctx, _lib.ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma), _lib.ptr(beta),
+                    float(eps), float(momentum), float(slope), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean),
+                    _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_forward")
+            ctx.save_for_backward(x, gamma, beta, mean, rstd)
+            ctx.meta = (float(slope), int(pad))
+            ctx.bias_like = conv_bias
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            lib = _lib.load()
+            x, gamma, beta, mean, rstd = ctx.saved_tensors
+            slope, pad = ctx.meta
+            n, c, h, w = x.shape
+            dev = x.device
+            if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+                dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                hctx = _lib.context(dev)
+                ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
+                _lib.check(lib.rml_bn_lrelu_pad_backward(
+                    hctx, _lib.ptr(x), _lib.ptr(dy), 1 if x.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma),
+                    _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), slope, _lib.ptr(ws), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                    _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_backward")
+            dbias = torch.zeros_like(ctx.bias_like) if ctx.bias_like is not None else None
+            return dx, dgamma.to(gamma.dtype), dbeta.to(beta.dtype), None, None, None, None, None, None, dbias
+
+    _bn_lrelu_pad_function._cls = BnLReluPad
+    return BnLReluPad
+
+
+def bn_lrelu_pad(x, bn, slope=0.2, pad=0, conv_bias=None):
+    """``F.pad(F.leaky_relu(bn(x), slope), (0, pad, 0, pad))`` for a training-mode ``nn.BatchNorm2d`` on a CUDA half
+    tensor in channels_last layout, as one fused HIP op (csrc/bnact.hip): two streaming passes forward, two backward,
+    written straight into the padded layout the next stride-2 TF-'same' convolution reads.  Falls back to the PyTorch ops
+    for anything else (CPU, float32, eval mode, channel counts that are not multiples of 8).  ``conv_bias``: see
+    ``BnLReluPad.forward`` -- the bias of the producing convolution, which then must NOT have been added to ``x``."""
+    torch = _torch()
+    import torch.nn.functional as F
+    c = x.shape[1]
+    fused = (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and bn.training and bn.track_running_stats and bn.affine
+             and bn.momentum is not None and c % 8 == 0 and 256 % (c // 8) == 0)
+    if not fused:
+        if conv_bias is not None:
+            x = x + conv_bias.to(x.dtype).reshape(1, -1, 1, 1)
+        y = F.leaky_relu(bn(x), slope)
+        return F.pad(y, (0, pad, 0, pad)) if pad else y
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    y = _bn_lrelu_pad_function().apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope, pad,
+                                       conv_bias)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return y
+
+
+def _conv1_bn_lrelu_pad_function():
+    """First layer of an SGAN branch as ONE autograd node: 3x3 stride-2 convolution of the (already padded) 1-channel
+    image -> training-mode batch norm -> LeakyReLU -> pad.  Forward = the library convolution + the fused batch-norm
+    kernels; backward never materialises the gradient of the convolution output: csrc/bnact.hip multiplies it with the
+    nine input taps on the fly and sums the weight gradient (MIOpen's own backward for this shape converts the 268 MB
+    gradient to float32 and runs an im2col GEMM per image: 3.4 of the 8.5 ms of an update)."""
+    torch = _torch()
+    if getattr(_conv1_bn_lrelu_pad_function, "_cls", None) is not None:
+        return _conv1_bn_lrelu_pad_function._cls
+    import torch.nn.functional as F
+    from . import _lib
+
+    class Conv1BnLReluPad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x_padded, weight, conv_bias, gamma, beta, running_mean, running_var, eps, momentum, slope, pad, dtype):
+            lib = _lib.load()
+            xh = x_padded.to(dtype).contiguous()
+            z = F.conv2d(xh, weight.to(dtype), None, stride=2)
+            if not z.is_contiguous(memory_format=torch.channels_last):
+                z = z.contiguous(memory_format=torch.channels_last)
+            n, c, h, w = z.shape
+            dev = z.device
+            y = torch.empty((n, c, h + pad, w + pad), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
+            mean = torch.empty((c,), dtype=torch.float32, device=dev)
+            rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                hctx = _lib.context(dev)
+                ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
+                _lib.check(lib.rml_bn_lrelu_pad_forward(
+                    hctx, _lib.ptr(z), 1 if z.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma), _lib.ptr(beta),
+                    float(eps), float(momentum), float(slope), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean),
+                    _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_forward")
+            ctx.save_for_backward(xh, z, gamma, beta, mean, rstd)
+            ctx.meta = (float(slope), int(pad), weight.shape, weight.dtype)
+            ctx.bias_like = conv_bias
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            lib = _lib.load()
+            xh, z, gamma, beta, mean, rstd = ctx.saved_tensors
+            slope, pad, wshape, wdtype = ctx.meta
+            n, c, h, w = z.shape
+            dev = z.device
+            if dy.dtype != z.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+                dy = dy.to(z.dtype).contiguous(memory_format=torch.channels_last)
+            dw = torch.empty((9, c), dtype=torch.float32, device=dev)
+            dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                hctx = _lib.context(dev)
+                ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
+                _lib.check(lib.rml_bn_lrelu_pad_backward_conv1(
+                    hctx, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(xh), 1 if z.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad,
+                    _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), slope, _lib.ptr(ws), _lib.ptr(dw), _lib.ptr(dgamma),
+                    _lib.ptr(dbeta), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_backward_conv1")
+            dbias = torch.zeros_like(ctx.bias_like) if ctx.bias_like is not None else None
+            return (None, dw.t().reshape(wshape).to(wdtype), dbias, dgamma.to(gamma.dtype), dbeta.to(beta.dtype),
+                    None, None, None, None, None, None, None)
+
+    _conv1_bn_lrelu_pad_function._cls = Conv1BnLReluPad
+    return Conv1BnLReluPad
+
+
+def conv1_bn_lrelu_pad(x_padded, conv, bn, slope, pad, dtype):
+    """See ``Conv1BnLReluPad``: ``conv`` is the inner nn.Conv2d(1, C, 3, stride=2) whose input ``x_padded`` already carries
+    the TF-'same' zero row/column (N, 1, 2H+1, 2W+1)."""
+    torch = _torch()
+    y = _conv1_bn_lrelu_pad_function().apply(x_padded, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             bn.eps, bn.momentum, slope, pad, dtype)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return y

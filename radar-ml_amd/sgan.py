@@ -51,10 +51,43 @@ class Discriminator(_nn().Module):
                 nn.init.normal_(mod.weight, 0.0, 0.02)      # RandomNormal(stddev=0.02), sgan.py:176
                 nn.init.zeros_(mod.bias)
 
+    @staticmethod
+    def _branch(x, br):
+        """[Conv2D 'same' s2 + BatchNorm + LeakyReLU] x 3 (sgan.py:137-158).  On the GPU under half-precision autocast and
+        in training mode: batch norm + LeakyReLU + the bottom/right zero pad of the next convolution are one fused HIP op
+        (nn_common.bn_lrelu_pad), the convolutions run without their bias (batch norm cancels it; its gradient is exactly
+        zero and is handed back as such), and the 1-channel first layer is one autograd node whose backward sums the weight
+        gradient without materialising the gradient of the convolution output (nn_common.conv1_bn_lrelu_pad).
+        Otherwise the plain PyTorch layers run."""
+        import torch
+        import torch.nn.functional as F
+        from .nn_common import bn_lrelu_pad, conv1_bn_lrelu_pad, tf_same_pad
+        layers = list(br)
+        nlayer = len(layers) // 3
+        even = all(s % (2 ** nlayer) == 0 for s in x.shape[-2:])
+        adt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else None
+        if not (x.is_cuda and br.training and even and adt in (torch.float16, torch.bfloat16)):
+            return br(x)
+        ph, pw = tf_same_pad(x.shape[-2], 3, 2), tf_same_pad(x.shape[-1], 3, 2)
+        # the 1-channel input of the first convolution; tagged channels_last explicitly (for C = 1 the strides alone do
+        # not say), otherwise MIOpen answers in NCHW and 268 MB layout copies appear on both sides of layer 1
+        x = F.pad(x, (pw[0], pw[1], ph[0], ph[1])).contiguous(memory_format=torch.channels_last)
+        for li in range(nlayer):
+            conv, bn, act = layers[3 * li].conv, layers[3 * li + 1], layers[3 * li + 2]      # the inner Conv2d: input is padded
+            pad = 1 if li + 1 < nlayer else 0
+            c = conv.out_channels
+            if (li == 0 and conv.in_channels == 1 and not x.requires_grad and x.shape[-1] % 2 == 1 and x.shape[-2] % 2 == 1
+                    and c % 8 == 0 and 256 % (c // 8) == 0 and bn.track_running_stats and bn.affine and bn.momentum is not None):
+                x = conv1_bn_lrelu_pad(x, conv, bn, act.negative_slope, pad, adt)
+                continue
+            z = F.conv2d(x, conv.weight, None, stride=2)
+            x = bn_lrelu_pad(z, bn, act.negative_slope, pad=pad, conv_bias=conv.bias)
+        return x
+
     def forward(self, xz, yz, xy):
         """Pre-activation class scores (N, n_classes) -- the shared ``cls`` tensor of sgan.py:199."""
         import torch
-        outs = [br(x) for x, br in zip((xz, yz, xy), self.branches)]
+        outs = [self._branch(x, br) for x, br in zip((xz, yz, xy), self.branches)]
         fv = flatten_nhwc(torch.cat(outs, dim=1))
         h = self.drop(self.act(self.bn1(self.fc1(fv))))
         h = self.drop(self.act(self.bn2(self.fc2(h))))

@@ -183,3 +183,85 @@ def test_resize_random_shapes_property(rml):
             np.testing.assert_array_equal(got16[b].float().cpu().numpy(), torch.from_numpy(want).to(torch.bfloat16).float().numpy())
 
     check()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,pad", [((6, 128, 64, 64), 1), ((5, 64, 32, 32), 1), ((7, 32, 16, 16), 0), ((3, 8, 6, 10), 1)])
+def test_fused_bn_lrelu_pad_matches_torch(rml, dtype, shape, pad):
+    """csrc/bnact.hip (training-mode BatchNorm + LeakyReLU + bottom/right pad, forward and backward) against the same
+    PyTorch layers evaluated in float32 on the same half-precision input."""
+    import torch.nn.functional as F
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    torch.manual_seed(1)
+    n, c, h, w = shape
+    x16 = (torch.randn(shape, device="cuda") * 1.5 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(bn)
+    dy = torch.randn((n, c, h + pad, w + pad), device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    xa = x16.clone().requires_grad_(True)
+    ya = nc.bn_lrelu_pad(xa, bn, 0.2, pad)
+    assert ya.dtype == dtype and ya.shape == dy.shape and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy)
+    xb = x16.float().clone().requires_grad_(True)
+    yb = F.pad(F.leaky_relu(ref(xb), 0.2), (0, pad, 0, pad))
+    yb.backward(dy.float())
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert (ya.float() - yb).abs().max() <= tol * (1 + yb.abs().max())
+    if pad:
+        assert float(ya[:, :, -1, :].abs().max()) == 0.0 and float(ya[:, :, :, -1].abs().max()) == 0.0
+    assert (xa.grad.float() - xb.grad).abs().max() <= tol * (1 + xb.grad.abs().max())
+    assert (bn.weight.grad - ref.weight.grad).abs().max() <= tol * (1 + ref.weight.grad.abs().max())
+    assert (bn.bias.grad - ref.bias.grad).abs().max() <= tol * (1 + ref.bias.grad.abs().max())
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    # deterministic: a second evaluation gives the same bits
+    bn2 = copy.deepcopy(ref)
+    with torch.no_grad():
+        bn2.running_mean.zero_(); bn2.running_var.fill_(1.0)
+    y2 = nc.bn_lrelu_pad(x16, bn2, 0.2, pad)
+    assert torch.equal(y2, ya.detach())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_conv1_bn_lrelu_pad_matches_torch(rml, dtype):
+    """The first layer of an SGAN branch as one node (library convolution forward; weight gradient summed inside the
+    batch-norm backward, csrc/bnact.hip) against conv -> BatchNorm -> LeakyReLU -> pad in float32 PyTorch."""
+    import torch.nn.functional as F
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    torch.manual_seed(2)
+    n, c, hw = 6, 128, 32
+    img = torch.rand((n, 1, hw, hw), device="cuda") * 2 - 1
+    xpad = F.pad(img, (0, 1, 0, 1))
+    conv = torch.nn.Conv2d(1, c, 3, stride=2, padding=0).cuda()
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.3); conv.bias.zero_(); bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    conv_r, bn_r = copy.deepcopy(conv), copy.deepcopy(bn)
+    # batch norm cancels a convolution bias: the fused node never adds it (checked here on the float32 reference; with a
+    # non-zero bias the two would round z differently and a few elements would land on the other side of the LeakyReLU kink)
+    with torch.no_grad():
+        cb = copy.deepcopy(conv_r); cb.bias.normal_(0, 0.2)
+        xr0 = xpad.to(dtype).float()
+        a0 = F.leaky_relu(copy.deepcopy(bn_r)(conv_r(xr0)), 0.2)
+        a1 = F.leaky_relu(copy.deepcopy(bn_r)(cb(xr0)), 0.2)
+        assert (a0 - a1).abs().max() < 1e-4
+    dy = torch.randn((n, c, hw // 2 + 1, hw // 2 + 1), device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    y = nc.conv1_bn_lrelu_pad(xpad, conv, bn, 0.2, 1, dtype)
+    y.backward(dy)
+    # reference: same half-rounded image and weights, float32 arithmetic, bias included (batch norm cancels it)
+    xr = xpad.to(dtype).float()
+    with torch.no_grad():
+        conv_r.weight.copy_(conv_r.weight.to(dtype).float())
+    zr = conv_r(xr)
+    zr = zr + (zr.to(dtype).float() - zr).detach()              # the library convolution stores z in half precision
+    yr = F.pad(F.leaky_relu(bn_r(zr), 0.2), (0, 1, 0, 1))
+    yr.backward(dy.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-3
+    assert (y.float() - yr).abs().max() <= tol * (1 + yr.abs().max())
+    assert (conv.weight.grad - conv_r.weight.grad).abs().max() <= 2 * tol * (1 + conv_r.weight.grad.abs().max())
+    assert float(conv.bias.grad.abs().max()) == 0.0 and conv_r.bias.grad.abs().max() <= 1e-2 * (1 + dy.float().abs().sum() ** 0.5)
+    assert (bn.weight.grad - bn_r.weight.grad).abs().max() <= tol * (1 + bn_r.weight.grad.abs().max())
+    assert (bn.bias.grad - bn_r.bias.grad).abs().max() <= tol * (1 + bn_r.bias.grad.abs().max())
+    assert torch.allclose(bn.running_var, bn_r.running_var, rtol=2e-2, atol=1e-4)
