@@ -402,11 +402,11 @@ def run_sgan(a, env):
     x = [torch.rand((n, 128, 128), device=dev, generator=g) * 2 - 1 for _ in range(3)]
     y = torch.randint(0, 3, (n,), device=dev, generator=g)
     yr = torch.full((n, 1), 0.9, device=dev)
-    for _ in range(3):
+    for _ in range(6):
         tr.train_on_batch_c(x, y)
         tr.train_on_batch_d(x, yr)
     torch.cuda.synchronize(dev)
-    steps = max(10, a.steps)
+    steps = max(30, a.steps)
     t0 = time.perf_counter()
     for _ in range(steps):
         lc, acc = tr.train_on_batch_c(x, y)
@@ -414,7 +414,7 @@ def run_sgan(a, env):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(2 * n / dt, 1), "unit": "samples/s",
-            "ms_per_step": round(dt * 1e3, 2), "batch": n, "dtype": "fp16 autocast (MIOpen), fp32 master weights",
+            "ms_per_step": round(dt * 1e3, 2), "batch": n, "dtype": "fp16 autocast (MIOpen convolutions, csrc/bnact.hip batch-norm/activation/pad), fp32 master weights",
             "c_loss": round(lc, 4), "d_loss": round(ld, 4)}
 
 
