@@ -409,13 +409,13 @@ def run_sgan(a, env):
     steps = max(30, a.steps)
     t0 = time.perf_counter()
     for _ in range(steps):
-        lc, acc = tr.train_on_batch_c(x, y)
-        ld = tr.train_on_batch_d(x, yr)
+        lc, acc = tr.train_on_batch_c(x, y, sync=False)
+        ld = tr.train_on_batch_d(x, yr, sync=False)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(2 * n / dt, 1), "unit": "samples/s",
             "ms_per_step": round(dt * 1e3, 2), "batch": n, "dtype": "fp16 autocast (MIOpen convolutions, csrc/bnact.hip batch-norm/activation/pad), fp32 master weights",
-            "c_loss": round(lc, 4), "d_loss": round(ld, 4)}
+            "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4)}
 
 
 def main():

@@ -270,6 +270,18 @@ int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, const void* dy,
                                     const float* save_mean, const float* save_rstd, float slope, float* workspace,
                                     float* dweight, float* dgamma, float* dbeta, void* stream);
 
+/* The same first layer with its convolution folded in: the convolution output is never stored; every pass recomputes
+ * it (9 FMAs per element) from the zero-padded half-precision image N x (2H+1) x (2W+1) and the float32 weights
+ * weight[tap][c].  forward: image -> y; backward: image, dy -> dweight[tap][c], dgamma, dbeta. */
+int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, const float* weight, int dtype, int64_t N, int H, int W,
+                                   int C, int pad_h, int pad_w, const float* gamma, const float* beta, float eps,
+                                   float momentum, float slope, float* running_mean, float* running_var, float* save_mean,
+                                   float* save_rstd, float* workspace, void* y, void* stream);
+int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, const float* weight, const void* dy, int dtype, int64_t N,
+                                    int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_rstd, float slope, float* workspace,
+                                    float* dweight, float* dgamma, float* dbeta, void* stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------- */
 int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
                       int n_classes, float* V, int32_t* cls /* B or NULL */, void* stream);

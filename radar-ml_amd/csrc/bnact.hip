@@ -279,6 +279,172 @@ __global__ __launch_bounds__(kT) void k_bn_bwd_wgrad1(const uint16_t* __restrict
     }
 }
 
+// ---- the first layer with its convolution folded in: z is never stored ---------------------------------------------
+// z[n,h,w,c] = sum_k wk[k][c] * img[n, 2h+ky, 2w+kx] (3x3, stride 2, 1 input channel, bias-free) costs 9 FMAs per element,
+// far less than reading it back from HBM: every pass below recomputes it from the (tiny, cache-resident) image.  A
+// thread keeps the 9 x 8 weights of its channel group in registers.
+template <bool BF>
+struct Conv1 {
+    float wk[9][8];
+    const uint16_t* img;
+    int IH, IW;
+    __device__ __forceinline__ void init(const float* wgt /* [9][C] */, int C, int cg, const uint16_t* image, int H, int W) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wk[k][i] = wgt[k * C + cg * 8 + i];
+        img = image; IH = 2 * H + 1; IW = 2 * W + 1;
+    }
+    __device__ __forceinline__ void taps(int64_t n, int h, int w, float (&t)[9]) const {
+        const uint16_t* ip = img + (n * IH + 2 * h) * (int64_t)IW + 2 * w;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = h2f<BF>(ip[ky * IW + kx]);
+    }
+    __device__ __forceinline__ void z(const float (&t)[9], float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a = fmaf(wk[k][i], t[k], a);
+            v[i] = a;
+        }
+    }
+};
+
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_c1_stats(const uint16_t* __restrict__ image, const float* __restrict__ wgt, int64_t N, int H, int W,
+                                                 int C, float* part) {
+    __shared__ float lds[kT * 16];
+    const int CG = C >> 3, PL = kT / CG;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    const int64_t M = N * H * W;
+    Conv1<BF> cv;
+    cv.init(wgt, C, cg, image, H, W);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
+        const int64_t nh = p / W;
+        const int w = (int)(p - nh * W);
+        const int64_t n = nh / H;
+        const int h = (int)(nh - n * H);
+        float t[9], v[8];
+        cv.taps(n, h, w, t);
+        cv.z(t, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+    }
+    block_channel_sums(s, q, CG, C, part, lds);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_c1_apply_pad(const uint16_t* __restrict__ image, const float* __restrict__ wgt, uint16_t* __restrict__ y,
+                                                     int64_t nrows, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
+                                                     const float* gamma, const float* beta, float slope) {
+    const int CG = C >> 3, Wp = W + pw, Hp = H + ph;
+    // threads keep their channel group (item = w * CG + cg with kT % CG == 0) and the workgroup walks many rows, so the
+    // 72 weights and the batch-norm scale/shift of a thread are loaded once
+    const int cg = threadIdx.x % CG;
+    Conv1<BF> cv;
+    cv.init(wgt, C, cg, image, H, W);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        sc[i] = rstd[c] * gamma[c];
+        sh[i] = beta[c] - mean[c] * sc[i];
+    }
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {       // row = n * Hp + h
+        const int64_t n = row / Hp;
+        const int h = (int)(row - n * Hp);
+        uint16_t* yr = y + row * (int64_t)Wp * C;
+        for (int w = threadIdx.x / CG; w < Wp; w += kT / CG) {
+            uint4 out = make_uint4(0, 0, 0, 0);
+            if (h < H && w < W) {
+                float t[9], v[8], r[8];
+                cv.taps(n, h, w, t);
+                cv.z(t, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float zz = fmaf(v[i], sc[i], sh[i]);
+                    r[i] = zz > 0.0f ? zz : zz * slope;
+                }
+                out = pack8<BF>(r);
+            }
+            *reinterpret_cast<uint4*>(yr + (int64_t)w * C + cg * 8) = out;
+        }
+    }
+}
+
+// MODE 0: sums of g and g * x_hat (batch-norm parameter gradients and the two means of the input gradient);
+// MODE 1: weight gradient dW[k][c] = sum dz * tap_k with dz = gamma * rstd * (g - c1 - x_hat * c2)
+template <bool BF, int MODE>
+__global__ __launch_bounds__(kT) void k_c1_bwd(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
+                                               int64_t N, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
+                                               const float* gamma, const float* beta, const float* c1, const float* c2, float slope,
+                                               float* part) {
+    __shared__ float lds[kT * 16];
+    const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    const int64_t M = N * H * W;
+    Conv1<BF> cv;
+    cv.init(wgt, C, cg, image, H, W);
+    constexpr int NA = MODE == 0 ? 2 : 9;
+    float acc[NA][8];
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[k][i] = 0.0f;
+    float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c];
+        k1[i] = MODE == 1 ? c1[c] : 0.0f; k2[i] = MODE == 1 ? c2[c] : 0.0f;
+    }
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
+        const int64_t nh = p / W;
+        const int w = (int)(p - nh * W);
+        const int64_t n = nh / H;
+        const int h = (int)(nh - n * H);
+        float t[9], v[8], d[8];
+        cv.taps(n, h, w, t);
+        cv.z(t, v);
+        unpack8<BF>(*reinterpret_cast<const uint4*>(dy + ((n * Hp + h) * (int64_t)Wp + w) * C + cg * 8), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (v[i] - mu[i]) * rs[i];
+            const float zz = xh * ga[i] + be[i];
+            const float g = zz > 0.0f ? d[i] : d[i] * slope;
+            if constexpr (MODE == 0) {
+                acc[0][i] += g;
+                acc[1][i] = fmaf(g, xh, acc[1][i]);
+            } else {
+                const float dz = ga[i] * rs[i] * (g - k1[i] - xh * k2[i]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(dz, t[k], acc[k][i]);
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        block_channel_sums(acc[0], acc[1], CG, C, part, lds);
+    } else {
+        for (int k = 0; k < 9; ++k) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
+            __syncthreads();
+            for (int c = tid; c < C; c += kT) {
+                float s = 0.0f;
+                for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
+                part[((size_t)blockIdx.x * 9 + k) * C + c] = s;
+            }
+        }
+    }
+}
+
 // out[j] = sum over g of part[g][j] (float64, strided partial sums + fixed tree): one workgroup per j
 __global__ __launch_bounds__(kT) void k_sum_partials(const float* part, int G, int L, float* out) {
     __shared__ double sa[kT];
@@ -399,6 +565,63 @@ extern "C" int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, cons
     hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
     if (dtype) hipLaunchKernelGGL(k_bn_bwd_wgrad1<true>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
     else hipLaunchKernelGGL(k_bn_bwd_wgrad1<false>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    hipLaunchKernelGGL(k_sum_partials, dim3(9 * C), dim3(kT), 0, st, workspace, G, 9 * C, dweight);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// ---- first layer, convolution folded in: image (N x (2H+1) x (2W+1), half) + weights [9][C] float32 -> y ------------
+extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, const float* weight, int dtype, int64_t N, int H, int W,
+                                              int C, int pad_h, int pad_w, const float* gamma, const float* beta, float eps,
+                                              float momentum, float slope, float* running_mean, float* running_var, float* save_mean,
+                                              float* save_rstd, float* workspace, void* y, void* stream) {
+    int rc = check_common("rml_conv1_bn_lrelu_pad_forward", ctx, N, H, W, C, pad_h, pad_w, dtype);
+    if (rc) return rc;
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(image && weight && y && gamma && beta && save_mean && save_rstd && workspace, RML_ERR_INVALID,
+                "rml_conv1_bn_lrelu_pad_forward: NULL argument");
+    RML_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, RML_ERR_INVALID, "rml_conv1_bn_lrelu_pad_forward: y must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = N * H * W;
+    const int G = stats_grid(ctx, M, C);
+    const uint16_t* is = static_cast<const uint16_t*>(image);
+    uint16_t* ys = static_cast<uint16_t*>(y);
+    if (dtype) hipLaunchKernelGGL(k_c1_stats<true>, dim3(G), dim3(kT), 0, st, is, weight, N, H, W, C, workspace);
+    else hipLaunchKernelGGL(k_c1_stats<false>, dim3(G), dim3(kT), 0, st, is, weight, N, H, W, C, workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 0, eps, momentum,
+                       save_mean, save_rstd, running_mean, running_var);
+    const unsigned rows = (unsigned)(N * (H + pad_h));
+    const unsigned ga = rows < (unsigned)(ctx->num_cu * 8) ? rows : (unsigned)(ctx->num_cu * 8);
+    if (dtype) hipLaunchKernelGGL(k_c1_apply_pad<true>, dim3(ga), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+    else hipLaunchKernelGGL(k_c1_apply_pad<false>, dim3(ga), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, const float* weight, const void* dy, int dtype, int64_t N,
+                                               int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
+                                               const float* save_mean, const float* save_rstd, float slope, float* workspace,
+                                               float* dweight, float* dgamma, float* dbeta, void* stream) {
+    int rc = check_common("rml_conv1_bn_lrelu_pad_backward", ctx, N, H, W, C, pad_h, pad_w, dtype);
+    if (rc) return rc;
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(image && weight && dy && gamma && beta && save_mean && save_rstd && workspace && dweight && dgamma && dbeta, RML_ERR_INVALID,
+                "rml_conv1_bn_lrelu_pad_backward: NULL argument");
+    RML_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, RML_ERR_INVALID, "rml_conv1_bn_lrelu_pad_backward: dy must be 16-byte aligned");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = N * H * W;
+    const int G = stats_grid(ctx, M, C);
+    const uint16_t* is = static_cast<const uint16_t*>(image);
+    const uint16_t* ds = static_cast<const uint16_t*>(dy);
+    float* c1 = workspace + (size_t)G * 9 * C;
+    float* c2 = c1 + C;
+    if (dtype) hipLaunchKernelGGL((k_c1_bwd<true, 0>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    else hipLaunchKernelGGL((k_c1_bwd<false, 0>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
+    if (dtype) hipLaunchKernelGGL((k_c1_bwd<true, 1>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
+    else hipLaunchKernelGGL((k_c1_bwd<false, 1>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
     hipLaunchKernelGGL(k_sum_partials, dim3(9 * C), dim3(kT), 0, st, workspace, G, 9 * C, dweight);
     RML_HIP(hipGetLastError());
     return RML_OK;

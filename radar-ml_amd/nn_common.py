@@ -204,10 +204,12 @@ def bn_lrelu_pad(x, bn, slope=0.2, pad=0, conv_bias=None):
 
 def _conv1_bn_lrelu_pad_function():
     """First layer of an SGAN branch as ONE autograd node: 3x3 stride-2 convolution of the (already padded) 1-channel
-    image -> training-mode batch norm -> LeakyReLU -> pad.  Forward = the library convolution + the fused batch-norm
-    kernels; backward never materialises the gradient of the convolution output: csrc/bnact.hip multiplies it with the
-    nine input taps on the fly and sums the weight gradient (MIOpen's own backward for this shape converts the 268 MB
-    gradient to float32 and runs an im2col GEMM per image: 3.4 of the 8.5 ms of an update)."""
+    image -> training-mode batch norm -> LeakyReLU -> pad, entirely in csrc/bnact.hip.  The convolution output (268 MB at
+    batch 256) is never stored: it costs 9 FMAs per element to recompute from the tiny image, so every pass (statistics,
+    normalise + activation + pad, backward sums, weight gradient) recomputes it; the gradient of the convolution output is
+    not materialised either -- it is multiplied with the nine input taps on the fly and summed into the weight gradient.
+    (MIOpen's own backward for this shape converts the 268 MB gradient to float32 and runs an im2col GEMM per image:
+    3.4 of the 8.5 ms of an update.)"""
     torch = _torch()
     if getattr(_conv1_bn_lrelu_pad_function, "_cls", None) is not None:
         return _conv1_bn_lrelu_pad_function._cls
@@ -218,46 +220,46 @@ def _conv1_bn_lrelu_pad_function():
         @staticmethod
         def forward(ctx, x_padded, weight, conv_bias, gamma, beta, running_mean, running_var, eps, momentum, slope, pad, dtype):
             lib = _lib.load()
-            xh = x_padded.to(dtype).contiguous()
-            z = F.conv2d(xh, weight.to(dtype), None, stride=2)
-            if not z.is_contiguous(memory_format=torch.channels_last):
-                z = z.contiguous(memory_format=torch.channels_last)
-            n, c, h, w = z.shape
-            dev = z.device
-            y = torch.empty((n, c, h + pad, w + pad), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
+            xh = x_padded.to(dtype).contiguous()                               # (N, 1, 2H+1, 2W+1), half
+            c = weight.shape[0]
+            wk = weight.to(dtype).float().reshape(c, 9).t().contiguous()       # [tap][c], rounded like the autocast operand
+            n = xh.shape[0]
+            h, w = (xh.shape[2] - 1) // 2, (xh.shape[3] - 1) // 2
+            dev = xh.device
+            y = torch.empty((n, c, h + pad, w + pad), dtype=dtype, device=dev, memory_format=torch.channels_last)
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             rstd = torch.empty((c,), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 hctx = _lib.context(dev)
                 ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
-                _lib.check(lib.rml_bn_lrelu_pad_forward(
-                    hctx, _lib.ptr(z), 1 if z.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma), _lib.ptr(beta),
-                    float(eps), float(momentum), float(slope), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean),
-                    _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_forward")
-            ctx.save_for_backward(xh, z, gamma, beta, mean, rstd)
-            ctx.meta = (float(slope), int(pad), weight.shape, weight.dtype)
+                _lib.check(lib.rml_conv1_bn_lrelu_pad_forward(
+                    hctx, _lib.ptr(xh), _lib.ptr(wk), 1 if dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma),
+                    _lib.ptr(beta), float(eps), float(momentum), float(slope), _lib.ptr(running_mean), _lib.ptr(running_var),
+                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_conv1_bn_lrelu_pad_forward")
+            ctx.save_for_backward(xh, wk, gamma, beta, mean, rstd)
+            ctx.meta = (float(slope), int(pad), weight.shape, weight.dtype, h, w)
             ctx.bias_like = conv_bias
             return y
 
         @staticmethod
         def backward(ctx, dy):
             lib = _lib.load()
-            xh, z, gamma, beta, mean, rstd = ctx.saved_tensors
-            slope, pad, wshape, wdtype = ctx.meta
-            n, c, h, w = z.shape
-            dev = z.device
-            if dy.dtype != z.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
-                dy = dy.to(z.dtype).contiguous(memory_format=torch.channels_last)
+            xh, wk, gamma, beta, mean, rstd = ctx.saved_tensors
+            slope, pad, wshape, wdtype, h, w = ctx.meta
+            n, c = xh.shape[0], wk.shape[1]
+            dev = xh.device
+            if dy.dtype != xh.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+                dy = dy.to(xh.dtype).contiguous(memory_format=torch.channels_last)
             dw = torch.empty((9, c), dtype=torch.float32, device=dev)
             dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 hctx = _lib.context(dev)
                 ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
-                _lib.check(lib.rml_bn_lrelu_pad_backward_conv1(
-                    hctx, _lib.ptr(z), _lib.ptr(dy), _lib.ptr(xh), 1 if z.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad,
+                _lib.check(lib.rml_conv1_bn_lrelu_pad_backward(
+                    hctx, _lib.ptr(xh), _lib.ptr(wk), _lib.ptr(dy), 1 if xh.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad,
                     _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), slope, _lib.ptr(ws), _lib.ptr(dw), _lib.ptr(dgamma),
-                    _lib.ptr(dbeta), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_backward_conv1")
+                    _lib.ptr(dbeta), _lib.stream_ptr(dev)), "rml_conv1_bn_lrelu_pad_backward")
             dbias = torch.zeros_like(ctx.bias_like) if ctx.bias_like is not None else None
             return (None, dw.t().reshape(wshape).to(wdtype), dbias, dgamma.to(gamma.dtype), dbeta.to(beta.dtype),
                     None, None, None, None, None, None, None)

@@ -161,21 +161,22 @@ class DiscriminatorTrainer:
         self.scaler.update()
         return loss.detach(), logits.detach()
 
-    def train_on_batch_c(self, x, y):
-        """c_model.train_on_batch([xz,yz,xy], y) -> (loss, accuracy)."""
+    def train_on_batch_c(self, x, y, sync=True):
+        """c_model.train_on_batch([xz,yz,xy], y) -> (loss, accuracy) as Python floats (Keras), or as 0-d CUDA tensors
+        with ``sync=False`` (no host synchronisation: the next step's launches overlap this step's kernels)."""
         import torch
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).long().reshape(-1)
         loss, logits = self._step(self.opt_c, lambda lg: c_loss(lg, yt), x)
         acc = (logits.argmax(dim=-1) == yt).float().mean()
-        return float(loss), float(acc)
+        return (float(loss), float(acc)) if sync else (loss, acc)
 
-    def train_on_batch_d(self, x, y, sample_weight=None):
-        """d_model.train_on_batch([xz,yz,xy], y[, weights]) -> loss."""
+    def train_on_batch_d(self, x, y, sample_weight=None, sync=True):
+        """d_model.train_on_batch([xz,yz,xy], y[, weights]) -> loss (float, or a 0-d CUDA tensor with ``sync=False``)."""
         import torch
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).float()
         sw = None if sample_weight is None else torch.as_tensor(np.asarray(sample_weight)).to(self.device)
         loss, _ = self._step(self.opt_d, lambda lg: d_loss(lg, yt, sw), x)
-        return float(loss)
+        return float(loss) if sync else loss
 
     def predict(self, x, batch_size=4096):
         """c_model.predict: softmax class probabilities, float32 numpy."""

@@ -150,13 +150,13 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            lc, acc = tr.train_on_batch_c(x, y)
-            ld = tr.train_on_batch_d(x, yr)
+            lc, acc = tr.train_on_batch_c(x, y, sync=False)
+            ld = tr.train_on_batch_d(x, yr, sync=False)
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"what": "configs[4]: sgan discriminator step (c + d_real updates)", "dtype": a.dtype or "float16",
                           "batch": n, "ms_per_step": round(dtm * 1e3, 2), "samples_per_s": round(2 * n / dtm),
-                          "c_loss": round(lc, 4), "d_loss": round(ld, 4)}))
+                          "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4)}))
 
 
 if __name__ == "__main__":
