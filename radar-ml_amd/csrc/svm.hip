@@ -703,7 +703,7 @@ struct DecisionOut {
 // GEMM(s) + finish for one chunk whose operands are already in place.
 int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
-              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0) {
+              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -715,7 +715,8 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
         hipLaunchKernelGGL(k_tile_flags, dim3(FT), dim3(128), 0, st, flags, n, FT,
                            run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
     GemmArgs ga{};
-    ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = w.tile_exact;
+    // all_exact_known: every row is on the code grid by construction (uint8 volumes): no tile predicate at all
+    ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = all_exact_known ? nullptr : w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
     ga.kmat = kmat; ga.ld_k = ld_k; ga.M = m->M;
     if (run_i8) {
@@ -738,7 +739,8 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     FinishArgs fa{};
     fa.partial = w.partial; fa.Npart = n; fa.ST = ST; fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
     fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
-    fa.row_flags = flags; fa.tile_exact = w.tile_exact; fa.forced_i8 = (run_i8 && !run_gen);
+    fa.row_flags = all_exact_known ? nullptr : flags; fa.tile_exact = all_exact_known ? nullptr : w.tile_exact;
+    fa.forced_i8 = (run_i8 && !run_gen);
     fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
     fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
     hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
@@ -994,6 +996,27 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
+        // uint8 volumes are on the code grid by construction: one projection pass (codes + statistics), the exact GEMM on
+        // every tile, no flag kernels, no predicated second pass and no predicated float64 GEMM launch
+        const bool u8_exact = grid_ok && vdtype == RML_VOL_U8;
+        if (u8_exact) {
+            o.row_flags = nullptr;
+            rml_prof_mark(ctx, st);
+            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, st);
+            rml_prof_mark(ctx, st);
+            if (ctx->profiling) ctx->prof_frames += n;
+            if (rc) return rc;
+            RML_HIP(hipEventRecord(ev_proj[c & 1], st));
+            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
+            rml_prof_mark_gemm(ctx, aux);
+            rc = run_chunk(m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
+                           /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true);
+            rml_prof_mark_gemm(ctx, aux);
+            if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
+            if (rc) return rc;
+            RML_HIP(hipEventRecord(ev_done[c & 1], aux));
+            continue;
+        }
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
             rml_prof_mark(ctx, st);
