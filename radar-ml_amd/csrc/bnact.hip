@@ -378,31 +378,74 @@ __global__ __launch_bounds__(kT) void k_c1_apply_pad(const uint16_t* __restrict_
     }
 }
 
-// MODE 0: sums of g and g * x_hat (batch-norm parameter gradients and the two means of the input gradient);
-// MODE 1: weight gradient dW[k][c] = sum dz * tap_k with dz = gamma * rstd * (g - c1 - x_hat * c2)
-template <bool BF, int MODE>
-__global__ __launch_bounds__(kT) void k_c1_bwd(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
-                                               int64_t N, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
-                                               const float* gamma, const float* beta, const float* c1, const float* c2, float slope,
-                                               float* part) {
-    __shared__ float lds[kT * 16];
+// ---- single-pass backward of the first layer -------------------------------------------------------------------------
+// dW[k][c] = sum_p dz * t_k with dz = gamma*rstd*(g - c1 - x_hat*c2) expands to
+//     gamma*rstd * ( A[k][c] - c1[c]*B[k] - c2[c]*D[k][c] ),
+// A[k][c] = sum g*t_k, B[k] = sum t_k, D[k][c] = sum x_hat*t_k = rstd*(sum_j w[j][c]*T2[j][k] - mean*B[k]), T2 = sum t_j*t_k.
+// B and T2 depend on the image only (k_c1_imgstats, 8.5 MB), so ONE pass over dy accumulates A, sum g and sum g*x_hat
+// (k_c1_bwd1) and k_c1_wgrad_combine finishes in float64 -- dy is read once instead of twice.
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__ image, int64_t N, int H, int W, float* part /* [G][54] */) {
+    __shared__ float lds[kT];
+    const int IH = 2 * H + 1, IW = 2 * W + 1;
+    const int64_t M = N * H * W;
+    float b[9], t2[45];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) b[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 45; ++k) t2[k] = 0.0f;
+    for (int64_t p = (int64_t)blockIdx.x * kT + threadIdx.x; p < M; p += (int64_t)gridDim.x * kT) {
+        const int64_t nh = p / W;
+        const int w = (int)(p - nh * W);
+        const int64_t n = nh / H;
+        const int h = (int)(nh - n * H);
+        const uint16_t* ip = image + (n * IH + 2 * h) * (int64_t)IW + 2 * w;
+        float t[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = h2f<BF>(ip[ky * IW + kx]);
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            b[j] += t[j];
+#pragma unroll
+            for (int k = j; k < 9; ++k) { t2[q] = fmaf(t[j], t[k], t2[q]); ++q; }
+        }
+    }
+    // 54 block sums (fixed tree), one after the other
+    for (int v = 0; v < 54; ++v) {
+        __syncthreads();
+        lds[threadIdx.x] = v < 9 ? b[v] : t2[v - 9];
+        __syncthreads();
+        for (int off = kT / 2; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * 54 + v] = lds[0];
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
+                                                int64_t N, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
+                                                const float* gamma, const float* beta, float slope, float* part /* [G][11][C] */) {
+    __shared__ float lds[kT * 8];
     const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
     const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
     const int64_t M = N * H * W;
     Conv1<BF> cv;
     cv.init(wgt, C, cg, image, H, W);
-    constexpr int NA = MODE == 0 ? 2 : 9;
-    float acc[NA][8];
+    float acc[11][8];                   // 0..8: A[k], 9: sum g, 10: sum g*x_hat
 #pragma unroll
-    for (int k = 0; k < NA; ++k)
+    for (int k = 0; k < 11; ++k)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[k][i] = 0.0f;
-    float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
+    float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = cg * 8 + i;
         mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c];
-        k1[i] = MODE == 1 ? c1[c] : 0.0f; k2[i] = MODE == 1 ? c2[c] : 0.0f;
     }
     for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
         const int64_t nh = p / W;
@@ -418,30 +461,44 @@ __global__ __launch_bounds__(kT) void k_c1_bwd(const uint16_t* __restrict__ imag
             const float xh = (v[i] - mu[i]) * rs[i];
             const float zz = xh * ga[i] + be[i];
             const float g = zz > 0.0f ? d[i] : d[i] * slope;
-            if constexpr (MODE == 0) {
-                acc[0][i] += g;
-                acc[1][i] = fmaf(g, xh, acc[1][i]);
-            } else {
-                const float dz = ga[i] * rs[i] * (g - k1[i] - xh * k2[i]);
+            acc[9][i] += g;
+            acc[10][i] = fmaf(g, xh, acc[10][i]);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(dz, t[k], acc[k][i]);
-            }
+            for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(g, t[k], acc[k][i]);
         }
     }
-    if constexpr (MODE == 0) {
-        block_channel_sums(acc[0], acc[1], CG, C, part, lds);
-    } else {
-        for (int k = 0; k < 9; ++k) {
-            __syncthreads();
+    for (int k = 0; k < 11; ++k) {
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
-            __syncthreads();
-            for (int c = tid; c < C; c += kT) {
-                float s = 0.0f;
-                for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
-                part[((size_t)blockIdx.x * 9 + k) * C + c] = s;
-            }
+        for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
+        __syncthreads();
+        for (int c = tid; c < C; c += kT) {
+            float s = 0.0f;
+            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
+            part[((size_t)blockIdx.x * 11 + k) * C + c] = s;
         }
+    }
+}
+
+// sums [11][C] (A, sum g, sum g*x_hat) and img [54] (B, packed upper triangle of T2) -> dW[9][C], dgamma, dbeta
+__global__ void k_c1_wgrad_combine(const float* sums, const float* img, const float* wgt, const float* mean, const float* rstd,
+                                   const float* gamma, int C, double M, float* dweight, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double sg = sums[9 * C + c], sgx = sums[10 * C + c];
+    dbeta[c] = (float)sg;
+    dgamma[c] = (float)sgx;
+    const double c1 = sg / M, c2 = sgx / M, rs = rstd[c], mu = mean[c], ga = gamma[c];
+    for (int k = 0; k < 9; ++k) {
+        double wt2 = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            const int a = j < k ? j : k, b = j < k ? k : j;                 // packed index of (a <= b)
+            const int q = a * 9 - a * (a - 1) / 2 + (b - a);
+            wt2 += (double)wgt[j * C + c] * (double)img[9 + q];
+        }
+        const double Bk = img[k];
+        const double D = rs * (wt2 - mu * Bk);
+        dweight[k * C + c] = (float)(ga * rs * ((double)sums[k * C + c] - c1 * Bk - c2 * D));
     }
 }
 
@@ -479,7 +536,8 @@ int check_common(const char* who, rml_ctx* ctx, int64_t N, int H, int W, int C, 
 }  // namespace
 
 extern "C" int64_t rml_bn_workspace_floats(rml_ctx* ctx, int C) {
-    return ctx ? (int64_t)ctx->num_cu * 8 * 9 * C : 0;      // sized for the 9-tap partials of the conv1 backward
+    // sized for the first-layer backward: [G][11][C] partials + [11][C] sums + image statistics (256*54 + 54)
+    return ctx ? (int64_t)ctx->num_cu * 8 * 11 * C + (int64_t)11 * C + 256 * 54 + 54 : 0;
 }
 
 extern "C" int rml_bn_lrelu_pad_forward(rml_ctx* ctx, const void* x, int dtype, int64_t N, int H, int W, int C, int pad_h, int pad_w,
@@ -613,16 +671,22 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t M = N * H * W;
     const int G = stats_grid(ctx, M, C);
+    const int GI = 256;                                     // image-statistics workgroups
     const uint16_t* is = static_cast<const uint16_t*>(image);
     const uint16_t* ds = static_cast<const uint16_t*>(dy);
-    float* c1 = workspace + (size_t)G * 9 * C;
-    float* c2 = c1 + C;
-    if (dtype) hipLaunchKernelGGL((k_c1_bwd<true, 0>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    else hipLaunchKernelGGL((k_c1_bwd<false, 0>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
-    if (dtype) hipLaunchKernelGGL((k_c1_bwd<true, 1>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    else hipLaunchKernelGGL((k_c1_bwd<false, 1>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    hipLaunchKernelGGL(k_sum_partials, dim3(9 * C), dim3(kT), 0, st, workspace, G, 9 * C, dweight);
+    // workspace (rml_bn_workspace_floats = num_cu*8*11*C + ...): [G][11][C] partials | sums [11][C] | [GI][54] | img [54]
+    float* part = workspace;
+    float* sums = part + (size_t)G * 11 * C;
+    float* ipart = sums + (size_t)11 * C;
+    float* img = ipart + (size_t)GI * 54;
+    if (dtype) hipLaunchKernelGGL(k_c1_imgstats<true>, dim3(GI), dim3(kT), 0, st, is, N, H, W, ipart);
+    else hipLaunchKernelGGL(k_c1_imgstats<false>, dim3(GI), dim3(kT), 0, st, is, N, H, W, ipart);
+    hipLaunchKernelGGL(k_sum_partials, dim3(54), dim3(kT), 0, st, ipart, GI, 54, img);
+    if (dtype) hipLaunchKernelGGL(k_c1_bwd1<true>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+    else hipLaunchKernelGGL(k_c1_bwd1<false>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(11 * C), dim3(kT), 0, st, part, G, 11 * C, sums);
+    hipLaunchKernelGGL(k_c1_wgrad_combine, dim3((C + 63) / 64), dim3(64), 0, st, sums, img, weight, save_mean, save_rstd, gamma, C, (double)M,
+                       dweight, dgamma, dbeta);
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
