@@ -261,16 +261,8 @@ int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void* dy, int d
                               const float* save_rstd, float slope, float* workspace, void* dx, float* dgamma, float* dbeta,
                               void* stream);
 
-/* Backward of [3x3 stride-2 'same' convolution of a 1-channel image] + BatchNorm + LeakyReLU + pad (the first layer of a
- * branch; the image needs no gradient): z = the convolution output (bias-free), image = its zero-padded half-precision
- * input N x (2H+1) x (2W+1); returns the weight gradient dweight[tap][c] (tap = ky*3+kx) and the batch-norm parameter
- * gradients without ever materialising the gradient of z. */
-int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, const void* dy, const void* image, int dtype, int64_t N,
-                                    int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
-                                    const float* save_mean, const float* save_rstd, float slope, float* workspace,
-                                    float* dweight, float* dgamma, float* dbeta, void* stream);
-
-/* The same first layer with its convolution folded in: the convolution output is never stored; every pass recomputes
+/* First layer of a branch, [3x3 stride-2 'same' convolution of a 1-channel image] + BatchNorm + LeakyReLU + pad with the
+ * convolution folded in (the image needs no gradient): the convolution output is never stored; every pass recomputes
  * it (9 FMAs per element) from the zero-padded half-precision image N x (2H+1) x (2W+1) and the float32 weights
  * weight[tap][c].  forward: image -> y; backward: image, dy -> dweight[tap][c], dgamma, dbeta. */
 int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, const float* weight, int dtype, int64_t N, int H, int W,

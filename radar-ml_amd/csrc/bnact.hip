@@ -216,69 +216,6 @@ __global__ __launch_bounds__(kT) void k_bn_bwd_apply(const uint16_t* __restrict_
     }
 }
 
-// ---- backward pass 2 of the FIRST layer of a branch: the convolution in front has a 1-channel input that needs no
-// gradient, so dz = gamma * rstd * (g - c1 - x_hat * c2) is not written at all -- it is multiplied with the 9 input
-// taps of its pixel on the fly and summed into the weight gradient dW[k][c] (tap k = ky*3 + kx of the 3x3 stride-2
-// convolution; the padded input image is tiny and L1/L2 resident).  Workgroup partials [G][9][C], combined by
-// k_sum_partials in a fixed order.
-template <bool BF>
-__global__ __launch_bounds__(kT) void k_bn_bwd_wgrad1(const uint16_t* __restrict__ z, const uint16_t* __restrict__ dy,
-                                                      const uint16_t* __restrict__ img, int64_t N, int H, int W, int C, int ph, int pw,
-                                                      const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                                      const float* c1, const float* c2, float slope, float* part) {
-    __shared__ float lds[kT * 8];
-    const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
-    const int IH = 2 * H + 1, IW = 2 * W + 1;           // the 'same'-padded input of a stride-2 3x3 convolution
-    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
-    const int64_t M = N * H * W;
-    float acc[9][8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[k][i] = 0.0f;
-    float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = cg * 8 + i;
-        mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c]; k1[i] = c1[c]; k2[i] = c2[c];
-    }
-    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
-        const int64_t nh = p / W;
-        const int w = (int)(p - nh * W);
-        const int64_t n = nh / H;
-        const int h = (int)(nh - n * H);
-        float v[8], d[8], t[9];
-        unpack8<BF>(*reinterpret_cast<const uint4*>(z + p * C + cg * 8), v);
-        unpack8<BF>(*reinterpret_cast<const uint4*>(dy + ((n * Hp + h) * (int64_t)Wp + w) * C + cg * 8), d);
-        const uint16_t* ip = img + (n * IH + 2 * h) * (int64_t)IW + 2 * w;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = h2f<BF>(ip[ky * IW + kx]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xh = (v[i] - mu[i]) * rs[i];
-            const float zz = xh * ga[i] + be[i];
-            const float g = zz > 0.0f ? d[i] : d[i] * slope;
-            const float dz = ga[i] * rs[i] * (g - k1[i] - xh * k2[i]);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(dz, t[k], acc[k][i]);
-        }
-    }
-    // per tap: sum the pixel lanes of the workgroup in a fixed order
-    for (int k = 0; k < 9; ++k) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
-        __syncthreads();
-        for (int c = tid; c < C; c += kT) {
-            float s = 0.0f;
-            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
-            part[((size_t)blockIdx.x * 9 + k) * C + c] = s;
-        }
-    }
-}
-
 // ---- the first layer with its convolution folded in: z is never stored ---------------------------------------------
 // z[n,h,w,c] = sum_k wk[k][c] * img[n, 2h+ky, 2w+kx] (3x3, stride 2, 1 input channel, bias-free) costs 9 FMAs per element,
 // far less than reading it back from HBM: every pass below recomputes it from the (tiny, cache-resident) image.  A
@@ -593,37 +530,6 @@ extern "C" int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void
     const unsigned rows = (unsigned)(N * H);
     if (dtype) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(rows), dim3(kT), 0, st, xs, ds, os, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope);
     else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(rows), dim3(kT), 0, st, xs, ds, os, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope);
-    RML_HIP(hipGetLastError());
-    return RML_OK;
-}
-
-extern "C" int rml_bn_lrelu_pad_backward_conv1(rml_ctx* ctx, const void* z, const void* dy, const void* image, int dtype, int64_t N,
-                                               int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
-                                               const float* save_mean, const float* save_rstd, float slope, float* workspace,
-                                               float* dweight, float* dgamma, float* dbeta, void* stream) {
-    int rc = check_common("rml_bn_lrelu_pad_backward_conv1", ctx, N, H, W, C, pad_h, pad_w, dtype);
-    if (rc) return rc;
-    if (N == 0) return RML_OK;
-    RML_REQUIRE(z && dy && image && gamma && beta && save_mean && save_rstd && workspace && dweight && dgamma && dbeta, RML_ERR_INVALID,
-                "rml_bn_lrelu_pad_backward_conv1: NULL argument");
-    RML_REQUIRE(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, RML_ERR_INVALID,
-                "rml_bn_lrelu_pad_backward_conv1: z and dy must be 16-byte aligned");
-    RML_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t M = N * H * W;
-    const int G = stats_grid(ctx, M, C);
-    const uint16_t* zs = static_cast<const uint16_t*>(z);
-    const uint16_t* ds = static_cast<const uint16_t*>(dy);
-    const uint16_t* is = static_cast<const uint16_t*>(image);
-    // workspace: [G][9][C] partials (the first [G][2][C] double as the statistics partials), then c1, c2
-    float* c1 = workspace + (size_t)G * 9 * C;
-    float* c2 = c1 + C;
-    if (dtype) hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(G), dim3(kT), 0, st, zs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
-    else hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(G), dim3(kT), 0, st, zs, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, workspace);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 1, 0.0f, 0.0f, dbeta, dgamma, c1, c2);
-    if (dtype) hipLaunchKernelGGL(k_bn_bwd_wgrad1<true>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    else hipLaunchKernelGGL(k_bn_bwd_wgrad1<false>, dim3(G), dim3(kT), 0, st, zs, ds, is, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, c1, c2, slope, workspace);
-    hipLaunchKernelGGL(k_sum_partials, dim3(9 * C), dim3(kT), 0, st, workspace, G, 9 * C, dweight);
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
