@@ -323,7 +323,6 @@ __global__ __launch_bounds__(kT) void k_c1_apply_pad(const uint16_t* __restrict_
 // (k_c1_bwd1) and k_c1_wgrad_combine finishes in float64 -- dy is read once instead of twice.
 template <bool BF>
 __global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__ image, int64_t N, int H, int W, float* part /* [G][54] */) {
-    __shared__ float lds[kT];
     const int IH = 2 * H + 1, IW = 2 * W + 1;
     const int64_t M = N * H * W;
     float b[9], t2[45];
@@ -350,16 +349,21 @@ __global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__
             for (int k = j; k < 9; ++k) { t2[q] = fmaf(t[j], t[k], t2[q]); ++q; }
         }
     }
-    // 54 block sums (fixed tree), one after the other
+    // 54 block sums: butterfly inside each wave, then the four waves through LDS (fixed order)
+    __shared__ float wsum[kT / 64][54];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
     for (int v = 0; v < 54; ++v) {
-        __syncthreads();
-        lds[threadIdx.x] = v < 9 ? b[v] : t2[v - 9];
-        __syncthreads();
-        for (int off = kT / 2; off >= 1; off >>= 1) {
-            if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) part[(size_t)blockIdx.x * 54 + v] = lds[0];
+        float x = v < 9 ? b[v] : t2[v - 9];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) wsum[wave][v] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 54) {
+        float x = 0.0f;
+        for (int w = 0; w < kT / 64; ++w) x += wsum[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 54 + threadIdx.x] = x;
     }
 }
 
