@@ -268,11 +268,12 @@ int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void* dy, int d
 int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, const float* weight, int dtype, int64_t N, int H, int W,
                                    int C, int pad_h, int pad_w, const float* gamma, const float* beta, float eps,
                                    float momentum, float slope, float* running_mean, float* running_var, float* save_mean,
-                                   float* save_rstd, float* workspace, void* y, void* stream);
+                                   float* save_rstd, float* img_stats /* 54 floats out: sums of the taps and of their products */,
+                                   float* workspace, void* y, void* stream);
 int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, const float* weight, const void* dy, int dtype, int64_t N,
                                     int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
-                                    const float* save_mean, const float* save_rstd, float slope, float* workspace,
-                                    float* dweight, float* dgamma, float* dbeta, void* stream);
+                                    const float* save_mean, const float* save_rstd, const float* img_stats /* from forward */,
+                                    float slope, float* workspace, float* dweight, float* dgamma, float* dbeta, void* stream);
 
 /* ---- synthetic data (bench / tests) --------------------------------------- */
 int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,

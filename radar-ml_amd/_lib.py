@@ -73,10 +73,10 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_conv1_bn_lrelu_pad_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                               c_void_p, c_void_p]),
+                                               c_void_p, c_void_p, c_void_p]),
     "rml_conv1_bn_lrelu_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
-                                                c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                c_void_p]),
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
 }

@@ -251,32 +251,6 @@ struct Conv1 {
 };
 
 template <bool BF>
-__global__ __launch_bounds__(kT) void k_c1_stats(const uint16_t* __restrict__ image, const float* __restrict__ wgt, int64_t N, int H, int W,
-                                                 int C, float* part) {
-    __shared__ float lds[kT * 16];
-    const int CG = C >> 3, PL = kT / CG;
-    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
-    const int64_t M = N * H * W;
-    Conv1<BF> cv;
-    cv.init(wgt, C, cg, image, H, W);
-    float s[8], q[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
-    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
-        const int64_t nh = p / W;
-        const int w = (int)(p - nh * W);
-        const int64_t n = nh / H;
-        const int h = (int)(nh - n * H);
-        float t[9], v[8];
-        cv.taps(n, h, w, t);
-        cv.z(t, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
-    }
-    block_channel_sums(s, q, CG, C, part, lds);
-}
-
-template <bool BF>
 __global__ __launch_bounds__(kT) void k_c1_apply_pad(const uint16_t* __restrict__ image, const float* __restrict__ wgt, uint16_t* __restrict__ y,
                                                      int64_t nrows, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
                                                      const float* gamma, const float* beta, float slope) {
@@ -443,6 +417,30 @@ __global__ void k_c1_wgrad_combine(const float* sums, const float* img, const fl
     }
 }
 
+// batch statistics of the first layer from the image statistics alone: mean_c = sum_j w[j][c]*B[j] / M,
+// E[z^2]_c = sum_jk w[j][c]*w[k][c]*T2[j][k] / M -- no pass over the (virtual) convolution output at all
+__global__ void k_c1_stats_from_img(const float* img, const float* wgt, int C, double M, float eps, float momentum,
+                                    float* mean_o, float* rstd_o, float* running_mean, float* running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double m1 = 0.0, m2 = 0.0;
+    for (int j = 0; j < 9; ++j) {
+        const double wj = wgt[j * C + c];
+        m1 += wj * (double)img[j];
+        for (int k = 0; k < 9; ++k) {
+            const int a = j < k ? j : k, b = j < k ? k : j;
+            m2 += wj * (double)wgt[k * C + c] * (double)img[9 + a * 9 - a * (a - 1) / 2 + (b - a)];
+        }
+    }
+    const double mean = m1 / M;
+    double var = m2 / M - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    if (running_var) running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * var * (M > 1.0 ? M / (M - 1.0) : 1.0));
+}
+
 // out[j] = sum over g of part[g][j] (float64, strided partial sums + fixed tree): one workgroup per j
 __global__ __launch_bounds__(kT) void k_sum_partials(const float* part, int G, int L, float* out) {
     __shared__ double sa[kT];
@@ -542,22 +540,24 @@ extern "C" int rml_bn_lrelu_pad_backward(rml_ctx* ctx, const void* x, const void
 extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, const float* weight, int dtype, int64_t N, int H, int W,
                                               int C, int pad_h, int pad_w, const float* gamma, const float* beta, float eps,
                                               float momentum, float slope, float* running_mean, float* running_var, float* save_mean,
-                                              float* save_rstd, float* workspace, void* y, void* stream) {
+                                              float* save_rstd, float* img_stats, float* workspace, void* y, void* stream) {
     int rc = check_common("rml_conv1_bn_lrelu_pad_forward", ctx, N, H, W, C, pad_h, pad_w, dtype);
     if (rc) return rc;
     if (N == 0) return RML_OK;
-    RML_REQUIRE(image && weight && y && gamma && beta && save_mean && save_rstd && workspace, RML_ERR_INVALID,
+    RML_REQUIRE(image && weight && y && gamma && beta && save_mean && save_rstd && img_stats && workspace, RML_ERR_INVALID,
                 "rml_conv1_bn_lrelu_pad_forward: NULL argument");
     RML_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, RML_ERR_INVALID, "rml_conv1_bn_lrelu_pad_forward: y must be 16-byte aligned");
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t M = N * H * W;
-    const int G = stats_grid(ctx, M, C);
+    const int GI = 256;                                     // image-statistics workgroups
     const uint16_t* is = static_cast<const uint16_t*>(image);
     uint16_t* ys = static_cast<uint16_t*>(y);
-    if (dtype) hipLaunchKernelGGL(k_c1_stats<true>, dim3(G), dim3(kT), 0, st, is, weight, N, H, W, C, workspace);
-    else hipLaunchKernelGGL(k_c1_stats<false>, dim3(G), dim3(kT), 0, st, is, weight, N, H, W, C, workspace);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(kT), 0, st, workspace, G, C, (double)M, 0, eps, momentum,
+    // statistics of the image (B[9], T2 packed [45]) -> batch statistics of the convolution output, no pass over it
+    if (dtype) hipLaunchKernelGGL(k_c1_imgstats<true>, dim3(GI), dim3(kT), 0, st, is, N, H, W, workspace);
+    else hipLaunchKernelGGL(k_c1_imgstats<false>, dim3(GI), dim3(kT), 0, st, is, N, H, W, workspace);
+    hipLaunchKernelGGL(k_sum_partials, dim3(54), dim3(kT), 0, st, workspace, GI, 54, img_stats);
+    hipLaunchKernelGGL(k_c1_stats_from_img, dim3((C + 63) / 64), dim3(64), 0, st, img_stats, weight, C, (double)M, eps, momentum,
                        save_mean, save_rstd, running_mean, running_var);
     const unsigned rows = (unsigned)(N * (H + pad_h));
     const unsigned ga = rows < (unsigned)(ctx->num_cu * 8) ? rows : (unsigned)(ctx->num_cu * 8);
@@ -569,29 +569,24 @@ extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, c
 
 extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, const float* weight, const void* dy, int dtype, int64_t N,
                                                int H, int W, int C, int pad_h, int pad_w, const float* gamma, const float* beta,
-                                               const float* save_mean, const float* save_rstd, float slope, float* workspace,
-                                               float* dweight, float* dgamma, float* dbeta, void* stream) {
+                                               const float* save_mean, const float* save_rstd, const float* img_stats, float slope,
+                                               float* workspace, float* dweight, float* dgamma, float* dbeta, void* stream) {
     int rc = check_common("rml_conv1_bn_lrelu_pad_backward", ctx, N, H, W, C, pad_h, pad_w, dtype);
     if (rc) return rc;
     if (N == 0) return RML_OK;
-    RML_REQUIRE(image && weight && dy && gamma && beta && save_mean && save_rstd && workspace && dweight && dgamma && dbeta, RML_ERR_INVALID,
-                "rml_conv1_bn_lrelu_pad_backward: NULL argument");
+    RML_REQUIRE(image && weight && dy && gamma && beta && save_mean && save_rstd && img_stats && workspace && dweight && dgamma && dbeta,
+                RML_ERR_INVALID, "rml_conv1_bn_lrelu_pad_backward: NULL argument");
     RML_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, RML_ERR_INVALID, "rml_conv1_bn_lrelu_pad_backward: dy must be 16-byte aligned");
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t M = N * H * W;
     const int G = stats_grid(ctx, M, C);
-    const int GI = 256;                                     // image-statistics workgroups
     const uint16_t* is = static_cast<const uint16_t*>(image);
     const uint16_t* ds = static_cast<const uint16_t*>(dy);
-    // workspace (rml_bn_workspace_floats = num_cu*8*11*C + ...): [G][11][C] partials | sums [11][C] | [GI][54] | img [54]
+    // workspace: [G][11][C] partials | sums [11][C]
     float* part = workspace;
     float* sums = part + (size_t)G * 11 * C;
-    float* ipart = sums + (size_t)11 * C;
-    float* img = ipart + (size_t)GI * 54;
-    if (dtype) hipLaunchKernelGGL(k_c1_imgstats<true>, dim3(GI), dim3(kT), 0, st, is, N, H, W, ipart);
-    else hipLaunchKernelGGL(k_c1_imgstats<false>, dim3(GI), dim3(kT), 0, st, is, N, H, W, ipart);
-    hipLaunchKernelGGL(k_sum_partials, dim3(54), dim3(kT), 0, st, ipart, GI, 54, img);
+    const float* img = img_stats;
     if (dtype) hipLaunchKernelGGL(k_c1_bwd1<true>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
     else hipLaunchKernelGGL(k_c1_bwd1<false>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
     hipLaunchKernelGGL(k_sum_partials, dim3(11 * C), dim3(kT), 0, st, part, G, 11 * C, sums);

@@ -229,14 +229,16 @@ def _conv1_bn_lrelu_pad_function():
             y = torch.empty((n, c, h + pad, w + pad), dtype=dtype, device=dev, memory_format=torch.channels_last)
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+            istat = torch.empty((54,), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 hctx = _lib.context(dev)
                 ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
                 _lib.check(lib.rml_conv1_bn_lrelu_pad_forward(
                     hctx, _lib.ptr(xh), _lib.ptr(wk), 1 if dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad, _lib.ptr(gamma),
                     _lib.ptr(beta), float(eps), float(momentum), float(slope), _lib.ptr(running_mean), _lib.ptr(running_var),
-                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_conv1_bn_lrelu_pad_forward")
-            ctx.save_for_backward(xh, wk, gamma, beta, mean, rstd)
+                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(istat), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)),
+                    "rml_conv1_bn_lrelu_pad_forward")
+            ctx.save_for_backward(xh, wk, gamma, beta, mean, rstd, istat)
             ctx.meta = (float(slope), int(pad), weight.shape, weight.dtype, h, w)
             ctx.bias_like = conv_bias
             return y
@@ -244,7 +246,7 @@ def _conv1_bn_lrelu_pad_function():
         @staticmethod
         def backward(ctx, dy):
             lib = _lib.load()
-            xh, wk, gamma, beta, mean, rstd = ctx.saved_tensors
+            xh, wk, gamma, beta, mean, rstd, istat = ctx.saved_tensors
             slope, pad, wshape, wdtype, h, w = ctx.meta
             n, c = xh.shape[0], wk.shape[1]
             dev = xh.device
@@ -258,8 +260,8 @@ def _conv1_bn_lrelu_pad_function():
                 ws = torch.empty((int(lib.rml_bn_workspace_floats(hctx, c)) + 2 * c,), dtype=torch.float32, device=dev)
                 _lib.check(lib.rml_conv1_bn_lrelu_pad_backward(
                     hctx, _lib.ptr(xh), _lib.ptr(wk), _lib.ptr(dy), 1 if xh.dtype == torch.bfloat16 else 0, n, h, w, c, pad, pad,
-                    _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), slope, _lib.ptr(ws), _lib.ptr(dw), _lib.ptr(dgamma),
-                    _lib.ptr(dbeta), _lib.stream_ptr(dev)), "rml_conv1_bn_lrelu_pad_backward")
+                    _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(istat), slope, _lib.ptr(ws), _lib.ptr(dw),
+                    _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.stream_ptr(dev)), "rml_conv1_bn_lrelu_pad_backward")
             dbias = torch.zeros_like(ctx.bias_like) if ctx.bias_like is not None else None
             return (None, dw.t().reshape(wshape).to(wdtype), dbias, dgamma.to(gamma.dtype), dbeta.to(beta.dtype),
                     None, None, None, None, None, None, None)
