@@ -72,6 +72,8 @@ class GpuSVC(_Base):
         dc, ic, ns = _f64(dual_coef), _f64(intercept), np.ascontiguousarray(n_support, dtype=np.int32)
         if dc.shape != (C_ - 1, sv.shape[0]):
             raise ValueError("dual_coef must be (n_classes-1, n_SV) in libsvm order (SVC._dual_coef_)")
+        if not torch.cuda.is_available():
+            raise _lib.RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
         self._dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = _lib.context(self._dev)
         self.code_scale = _detect_code_scale(sv)
@@ -281,6 +283,8 @@ class GpuLinearClassifier(_Base):
 
     def __init__(self, coef, intercept, classes, calib_a=None, calib_b=None, device=None):
         torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
         lib = _lib.load()
         cf, ic = _f64(coef), _f64(intercept)
         self.classes_ = np.asarray(classes)

