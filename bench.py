@@ -397,7 +397,7 @@ def run_sgan(a, env):
     sgan = importlib.import_module("radar_ml_amd.sgan")
     n = 256
     d = sgan.define_discriminator(device=dev)
-    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16", ddp=False)
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16", ddp=False, use_graph=True)      # fwd+bwd replayed from HIP graphs
     g = torch.Generator(device=dev).manual_seed(a.seed)
     x = [torch.rand((n, 128, 128), device=dev, generator=g) * 2 - 1 for _ in range(3)]
     y = torch.randint(0, 3, (n,), device=dev, generator=g)

@@ -123,7 +123,11 @@ class DiscriminatorTrainer:
     """c_model / d_model ``train_on_batch`` (sgan.py:525-532) with the reference's optimizers, fp16 autocast and,
     when torch.distributed is initialised, DistributedDataParallel gradient all-reduce."""
 
-    def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None):
+    def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None, use_graph=False):
+        """``use_graph``: capture forward + backward of each head in a HIP graph (torch.cuda.graphs) after three eager
+        warm-up steps and replay it afterwards; the optimizer and the loss scaler stay outside the graph.  Single GPU
+        only (ignored under DDP); inputs must keep their shapes.  With the fused layers the step is launch-bound on the
+        host side, which is what the graph removes."""
         import torch
         import torch.distributed as dist
         self.model = model
@@ -141,6 +145,52 @@ class DiscriminatorTrainer:
         self.opt_d = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7, fused=fused)
         self.amp_dtype = getattr(torch, amp_dtype) if (amp_dtype and self.device.type == "cuda") else None
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
+        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not use_ddp
+        self._graphs = {}           # head -> dict(graph, static inputs / targets, loss, logits, eager_calls)
+
+    def _graph_step(self, head, opt, make_loss, x, targets):
+        """One update of ``head`` ('c' or 'd') through a captured graph.  ``targets``: tuple of tensors the loss needs
+        (copied into static buffers); ``make_loss(logits, *static_targets)`` builds the loss."""
+        import torch
+        st = self._graphs.setdefault(head, {"eager": 0})
+        xs = self._inputs(x)
+        key = tuple(tuple(t.shape) for t in xs) + tuple(tuple(t.shape) for t in targets)
+        if st.get("key") not in (None, key):            # shapes changed: start over
+            st.clear(); st["eager"] = 0
+        st["key"] = key
+        self.net.train()
+        if "graph" not in st:
+            if st["eager"] < 3:                         # eager warm-up (MIOpen find, allocator, lazy initialisations)
+                st["eager"] += 1
+                opt.zero_grad(set_to_none=False)
+                with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
+                    logits = self.net(*xs)
+                loss = make_loss(logits, *targets)
+                self.scaler.scale(loss).backward()
+                self.scaler.step(opt)
+                self.scaler.update()
+                return loss.detach(), logits.detach()
+            st["xs"] = [t.clone() for t in xs]
+            st["targets"] = [t.clone() for t in targets]
+            opt.zero_grad(set_to_none=False)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
+                    logits = self.net(*st["xs"])
+                loss = make_loss(logits, *st["targets"])
+                self.scaler.scale(loss).backward()
+            st["graph"], st["loss"], st["logits"] = g, loss, logits
+            # the capture itself does not run the kernels: fall through to the first replay
+        for dst, src in zip(st["xs"], xs):
+            dst.copy_(src)
+        for dst, src in zip(st["targets"], targets):
+            dst.copy_(src)
+        opt.zero_grad(set_to_none=False)
+        st["graph"].replay()
+        self.scaler.step(opt)
+        self.scaler.update()
+        return st["loss"].detach(), st["logits"].detach()
 
     def _inputs(self, x):
         return [to_nchw(a, self.device) for a in x]
@@ -166,7 +216,10 @@ class DiscriminatorTrainer:
         with ``sync=False`` (no host synchronisation: the next step's launches overlap this step's kernels)."""
         import torch
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).long().reshape(-1)
-        loss, logits = self._step(self.opt_c, lambda lg: c_loss(lg, yt), x)
+        if self.use_graph:
+            loss, logits = self._graph_step("c", self.opt_c, lambda lg, t: c_loss(lg, t), x, (yt,))
+        else:
+            loss, logits = self._step(self.opt_c, lambda lg: c_loss(lg, yt), x)
         acc = (logits.argmax(dim=-1) == yt).float().mean()
         return (float(loss), float(acc)) if sync else (loss, acc)
 
@@ -175,7 +228,12 @@ class DiscriminatorTrainer:
         import torch
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).float()
         sw = None if sample_weight is None else torch.as_tensor(np.asarray(sample_weight)).to(self.device)
-        loss, _ = self._step(self.opt_d, lambda lg: d_loss(lg, yt, sw), x)
+        if self.use_graph:
+            tg = (yt,) if sw is None else (yt, sw.float())
+            loss, _ = self._graph_step("d" if sw is None else "dw", self.opt_d,
+                                       (lambda lg, t: d_loss(lg, t)) if sw is None else (lambda lg, t, w_: d_loss(lg, t, w_)), x, tg)
+        else:
+            loss, _ = self._step(self.opt_d, lambda lg: d_loss(lg, yt, sw), x)
         return float(loss) if sync else loss
 
     def predict(self, x, batch_size=4096):

@@ -140,12 +140,12 @@ def main():
         sgan = importlib.import_module("radar_ml_amd.sgan")
         n = a.batch or 256
         d = sgan.define_discriminator(device=dev)
-        tr = sgan.DiscriminatorTrainer(d, amp_dtype=a.dtype or "float16", ddp=False)
+        tr = sgan.DiscriminatorTrainer(d, amp_dtype=a.dtype or "float16", ddp=False, use_graph=bool(int(os.environ.get("RML_SGAN_GRAPH", "1"))))
         g = torch.Generator(device=dev).manual_seed(0)
         x = [torch.rand((n, 128, 128), device=dev, generator=g) * 2 - 1 for _ in range(3)]
         y = torch.randint(0, 3, (n,), device=dev, generator=g)
         yr = torch.full((n, 1), 0.9, device=dev)
-        for _ in range(3):
+        for _ in range(6):
             tr.train_on_batch_c(x, y); tr.train_on_batch_d(x, yr)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
