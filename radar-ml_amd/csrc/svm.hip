@@ -819,6 +819,8 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
         // linear: x.s = G' + 128 isum_x + [128 isum_s - 16384 D]
         term[r] = (kernel == RML_KERNEL_RBF) ? (double)(isq - 256 * isum + 32768 * D) : (double)(128 * isum - 16384 * D);
     }
+    // the int8 MFMA accumulates sum (a-128)(b-128) in int32: |.| <= 128^2 * K must stay below 2^31
+    if (m->Kq >= 131072) exact = false;
     m->exact = exact;
     int rc = RML_OK;
     do {
