@@ -272,6 +272,27 @@ def run_workload(a, env, grid, frames, primary):
                               "frac": round(alone / I8_MFMA_PEAK_TOPS, 4)}
         del q, isum, isq, flags
 
+    # ---- configs[1]: the projection kernel alone (HBM-roofline check; float32 feature rows written) ------------
+    proj_only = None
+    if primary:
+        proj_only = {}
+        for nb in (4096, 16384):
+            nb = int(min(nb, B))
+            feat_o = torch.empty((nb, D), dtype=torch.float32, device=dev)
+            for _ in range(3):
+                rml.process_volumes(V[:nb], mode="max", out=feat_o)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                rml.process_volumes(V[:nb], mode="max", out=feat_o)
+            e1.record()
+            e1.synchronize()
+            ms_p = e0.elapsed_time(e1) / 10
+            gbs = nb * (frame_bytes + 4 * D) / (ms_p * 1e-3) / 1e9
+            proj_only["batch_%d" % nb] = {"ms": round(ms_p, 4), "frames_per_s": round(nb / ms_p * 1e3), "achieved_GBs": round(gbs, 1),
+                                          "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": frame_bytes + 4 * D}
+            del feat_o
+
     # ---- parity gate on a slab of the very frames the GPU classified ----------------------
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as OC
@@ -321,7 +342,8 @@ def run_workload(a, env, grid, frames, primary):
                    "gamma": a.gamma, "parallelism": "frames sharded x%d, labels all-gathered (RCCL)" % world
                    if world > 1 else "single GPU"},
         "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": roofline, "gemm_roofline": groof, "cpu_baseline": cpu, "parity": parity, "uint8_ingest": u8,
+        "roofline": roofline, "gemm_roofline": groof, "projection_only": proj_only, "cpu_baseline": cpu, "parity": parity,
+        "uint8_ingest": u8,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
     del V, out, svc
@@ -468,7 +490,7 @@ def main():
             "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
             "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
             "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"], "cpu_baseline": res["cpu_baseline"],
-            "parity": res["parity"],
+            "parity": res["parity"], "projection_only_configs1": res["projection_only"],
             "uint8_ingest": res["uint8_ingest"], "model": res["model"],
         }
         if wal is not None:
