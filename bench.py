@@ -355,7 +355,8 @@ def run_dnn(a, env):
     """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection (csrc/project.hip) ->
     [-1,1] scaling + Pillow-exact bicubic resize to 80x80 (csrc/resize.hip) -> fused conv trunk (csrc/dnn.hip) -> dense
     tail (hipBLASLt through PyTorch), bf16, random-init weights of the reference's architecture (dnn.py:45-91).
-    Frames are sharded over the ranks, nothing is exchanged.  Returns the result dict on rank 0."""
+    Frames are sharded over the ranks; the predicted labels are all-gathered (RCCL) when N > 1.  Returns the result dict
+    on rank 0."""
     import importlib
     import torch
     import torch.distributed as dist
@@ -366,17 +367,25 @@ def run_dnn(a, env):
     torch.manual_seed(a.seed)
     model = dnn.define_classifier(device=dev).eval()
     V, _ = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 7, frame0=rank * B, device=dev)
+    from radar_ml_amd import dist as rdist
+
+    def step(vol):
+        p = model.predict_volumes(vol)
+        if world > 1:
+            rdist.gather_labels(p.argmax(dim=1).to(torch.int32))          # RCCL all-gather of the predictions, 4 B/frame
+        return p
+
     res = {}
     for tag, vol in (("f32", V), ("u8", V.to(torch.uint8))):
         for _ in range(max(1, a.warmup)):
-            p = model.predict_volumes(vol)
+            p = step(vol)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            p = model.predict_volumes(vol)
+            p = step(vol)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
