@@ -362,24 +362,39 @@ __global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ ima
         const int c = cg * 8 + i;
         mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c];
     }
-    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < M; p += (int64_t)gridDim.x * PL) {
-        const int64_t nh = p / W;
-        const int w = (int)(p - nh * W);
-        const int64_t n = nh / H;
-        const int h = (int)(nh - n * H);
-        float t[9], v[8], d[8];
-        cv.taps(n, h, w, t);
-        cv.z(t, v);
-        unpack8<BF>(*reinterpret_cast<const uint4*>(dy + ((n * Hp + h) * (int64_t)Wp + w) * C + cg * 8), d);
+    // one output row per iteration: its three image rows go through LDS (as float), so the nine taps of a pixel are LDS
+    // broadcasts instead of nine dependent global loads
+    float* rows_s = lds;                             // [3][IW], reused for the reductions afterwards
+    const int IW = 2 * W + 1, IH = 2 * H + 1;
+    (void)M;
+    for (int64_t row = blockIdx.x; row < N * H; row += gridDim.x) {
+        const int64_t n = row / H;
+        const int h = (int)(row - n * H);
+        __syncthreads();
+        for (int i = tid; i < 3 * IW; i += kT) {
+            const int ky = i / IW, xx = i - ky * IW;
+            rows_s[i] = h2f<BF>(image[(n * IH + 2 * h + ky) * (int64_t)IW + xx]);
+        }
+        __syncthreads();
+        const uint16_t* dyr = dy + ((n * Hp + h) * (int64_t)Wp) * C + cg * 8;
+        for (int w = pl; w < W; w += PL) {
+            float t[9], v[8], d[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xh = (v[i] - mu[i]) * rs[i];
-            const float zz = xh * ga[i] + be[i];
-            const float g = zz > 0.0f ? d[i] : d[i] * slope;
-            acc[9][i] += g;
-            acc[10][i] = fmaf(g, xh, acc[10][i]);
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(g, t[k], acc[k][i]);
+                for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = rows_s[ky * IW + 2 * w + kx];
+            cv.z(t, v);
+            unpack8<BF>(*reinterpret_cast<const uint4*>(dyr + (int64_t)w * C), d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[i] - mu[i]) * rs[i];
+                const float zz = xh * ga[i] + be[i];
+                const float g = zz > 0.0f ? d[i] : d[i] * slope;
+                acc[9][i] += g;
+                acc[10][i] = fmaf(g, xh, acc[10][i]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(g, t[k], acc[k][i]);
+            }
         }
     }
     for (int k = 0; k < 11; ++k) {
