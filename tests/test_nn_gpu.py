@@ -224,8 +224,9 @@ def test_fused_bn_lrelu_pad_matches_torch(rml, dtype, shape, pad):
     assert torch.equal(y2, ya.detach())
 
 
+@pytest.mark.parametrize("sparse", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_fused_conv1_bn_lrelu_pad_matches_torch(rml, dtype):
+def test_fused_conv1_bn_lrelu_pad_matches_torch(rml, dtype, sparse):
     """The first layer of an SGAN branch as one node (library convolution forward; weight gradient summed inside the
     batch-norm backward, csrc/bnact.hip) against conv -> BatchNorm -> LeakyReLU -> pad in float32 PyTorch."""
     import torch.nn.functional as F
@@ -233,6 +234,9 @@ def test_fused_conv1_bn_lrelu_pad_matches_torch(rml, dtype):
     torch.manual_seed(2)
     n, c, hw = 6, 128, 32
     img = torch.rand((n, 1, hw, hw), device="cuda") * 2 - 1
+    if sparse:      # radar-like: background at -1 (a zero return after the [-1,1] scaling), a few returns -- the batch
+        #             statistics come from sums of tap products, so a large mean with a small variance is the hard case
+        img = torch.where(torch.rand_like(img) < 0.04, img, torch.full_like(img, -1.0))
     xpad = F.pad(img, (0, 1, 0, 1))
     conv = torch.nn.Conv2d(1, c, 3, stride=2, padding=0).cuda()
     bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()
