@@ -23,7 +23,7 @@
 // free.  Barriers are
 // LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) so that they do not drain the plane prefetch.
 // Numerics: bf16 operands (conv1 bias included), float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
-// Measured (8192 samples of 3 x 80x80, MI355X): 0.69 ms = 11.8 M samples/s; the same layers through PyTorch/MIOpen
+// Measured (8192 samples of 3 x 80x80, MI355X): 0.68 ms = 12.1 M samples/s; the same layers through PyTorch/MIOpen
 // in bf16 channels_last take 13.9 ms.
 #include "rml_internal.h"
 
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
             };
             ldk(0, afrag[0]);
             ldk(1, afrag[1]);
+            __builtin_amdgcn_s_setprio(2);          // the MFMA phase goes first on its SIMD; the other workgroup's wave fills the gaps
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < 9; ++tt) {
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 #ifdef RML_DNN_TIMING
         t3_ = __builtin_readcyclecounter();
 #endif
