@@ -370,7 +370,9 @@ namespace {
 template <bool INBF>
 int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
     int rc = RML_ERR_UNSUPPORTED;
-    // (measured and dropped: 2-row strips at three workgroups per CU -- 148 VGPRs, 49 KB LDS -- 0.78 ms against 0.69:
+    // (measured and dropped: a wave-specialised variant -- one 8-wave workgroup per CU, 4 producer waves doing conv1 and 4
+    // consumer waves doing conv2 on a double-buffered conv1 image, one producer and one consumer per SIMD: 0.72 ms against
+    // 0.675, archived as tools/exp/dnn_trunk_wave_specialised_kernel.hip.txt; and 2-row strips at three workgroups per CU -- 148 VGPRs, 49 KB LDS -- 0.78 ms against 0.69:
     // the extra conv1 rows, tile padding and barriers cost more than the third wave per SIMD hides)
     // strips of 4 conv2 rows while 4 rows are at most 80 pixels and two workgroups fit a CU, else 2 rows, else 1
     if (rc == RML_ERR_UNSUPPORTED) rc = launch_trunk<4, INBF, 5, true, 2>(a, num_cu, st);
