@@ -68,3 +68,34 @@ def test_context_lifecycle_and_side_stream(rml):
     s.synchronize()
     for g, w in zip((xz, yz, xy), O.project_max(v)):
         np.testing.assert_array_equal(g.cpu().numpy(), w)
+
+
+def test_new_entry_points_reject_bad_arguments(rml):
+    """rml_resize_bicubic / rml_dnn_trunk / rml_bn_lrelu_pad_*: status codes and messages, no launch on bad input."""
+    import torch
+    from radar_ml_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.context()
+    st = _lib.stream_ptr()
+    x = torch.zeros((2, 8, 8), device="cuda")
+    out = torch.zeros((2, 4, 4), device="cuda")
+    assert lib.rml_resize_bicubic(ctx, None, 64, 2, 8, 8, 4, 4, 0.0, 0.0, _lib.ptr(out), 0, st) == -1
+    assert lib.rml_resize_bicubic(ctx, _lib.ptr(x), 10, 2, 8, 8, 4, 4, 0.0, 0.0, _lib.ptr(out), 0, st) == -1     # in_stride < H*W
+    assert b"in_stride" in lib.rml_last_error()
+    assert lib.rml_resize_bicubic(ctx, _lib.ptr(x), 64, 2, 8, 8, 0, 4, 0.0, 0.0, _lib.ptr(out), 0, st) == -1
+    assert lib.rml_resize_bicubic(ctx, None, 64, 0, 8, 8, 4, 4, 0.0, 0.0, None, 0, st) == 0                     # empty batch
+    feat = torch.zeros((2, 2 * 2 * 96), dtype=torch.bfloat16, device="cuda")
+    w1 = torch.zeros((3, 64, 9), device="cuda"); b1 = torch.zeros((3, 64), device="cuda")
+    w2 = torch.zeros((3, 32, 576), dtype=torch.bfloat16, device="cuda"); b2 = torch.zeros((3, 32), device="cuda")
+    p6 = torch.zeros((2, 6, 8), device="cuda")
+    assert lib.rml_dnn_trunk(ctx, _lib.ptr(p6), _lib.ptr(p6), _lib.ptr(p6), 0, 2, 6, 8, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+                             _lib.ptr(feat), st) == -2                                                            # H not a multiple of 4
+    assert b"multiple" in lib.rml_last_error()
+    assert lib.rml_dnn_trunk(ctx, None, None, None, 0, 2, 8, 8, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(feat), st) == -1
+    xh = torch.zeros((2, 4, 4, 12), dtype=torch.float16, device="cuda")
+    g = torch.ones(12, device="cuda"); z = torch.zeros(12, device="cuda")
+    ws = torch.zeros(int(lib.rml_bn_workspace_floats(ctx, 16)) + 64, device="cuda")
+    assert lib.rml_bn_lrelu_pad_forward(ctx, _lib.ptr(xh), 0, 2, 4, 4, 12, 1, 1, _lib.ptr(g), _lib.ptr(z), 1e-3, 0.01, 0.2, None, None,
+                                        _lib.ptr(z), _lib.ptr(z), _lib.ptr(ws), _lib.ptr(xh), st) == -2               # C = 12
+    assert lib.rml_bn_lrelu_pad_forward(ctx, _lib.ptr(xh), 7, 2, 4, 4, 16, 1, 1, _lib.ptr(g), _lib.ptr(z), 1e-3, 0.01, 0.2, None, None,
+                                        _lib.ptr(z), _lib.ptr(z), _lib.ptr(ws), _lib.ptr(xh), st) == -1               # dtype
