@@ -27,6 +27,7 @@
 #include "rml_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -127,6 +128,34 @@ struct Emitter {
                 uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
                 *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
             }
+        }
+    }
+    // next frame of a persistent kernel
+    __device__ __forceinline__ void reset(int64_t b_) { b = b_; isum = 0; isq = 0; ok = 1; nsq = 0.0; }
+    // the same as finish() for kernels in which ONE WAVE owns the frame: no LDS, no barrier
+    __device__ void finish_wave(int lane) {
+        if (a.o.qrow) {
+            for (int64_t c = a.o.qD + lane; c < a.o.qstride; c += 64) a.o.qrow[b * a.o.qstride + c] = 0;
+        }
+        if (a.o.prow) {
+            for (int64_t c = a.o.pD + lane; c < a.o.pstride; c += 64) a.o.prow[b * a.o.pstride + c] = 0.0f;
+        }
+        if (!(a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.row_nsq)) return;
+        int64_t s = isum, q = isq;
+        int g = ok;
+        double nn = nsq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+            g &= __shfl_xor(g, off);
+            nn += __shfl_xor(nn, off);
+        }
+        if (lane == 0) {
+            if (a.o.row_isum) a.o.row_isum[b] = (int32_t)s;
+            if (a.o.row_isq) a.o.row_isq[b] = q;
+            if (a.o.row_flags) a.o.row_flags[b] = (int32_t)g;
+            if (a.o.row_nsq) a.o.row_nsq[b] = nn;
         }
     }
     // block reduction of the statistics (up to 16 waves); red must hold >= 64 int64 slots; all threads call it
@@ -396,6 +425,215 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
         em.put4(2, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xy_lds + idx * 4));
     for (int idx = nxy4 * 4 + tid; idx < nxy; idx += T) em.put1(2, idx, xy_lds[idx]);
     em.finish(red);
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-per-frame path for small frames with long rows (Walabot arena 22 x 31 x 176: 32 < Z/4 <= 64, Y <= 32).
+// ONE WAVE owns a frame and streams it row by row: lane = float4 column kq of the row (lanes >= Z/4 re-read the
+// last column: a duplicate is harmless for max, sum zeroes it), so
+//   * xz[i,k] = op_j V is an IN-LANE reduction over the rows of plane i and leaves as one coalesced store per plane,
+//   * yz[j,k] = op_i V is an in-lane reduction over the planes (NY float4 accumulators per lane),
+//   * xy[i,j] = op_k V: the lane's float4 is folded to one value and parked in a private LDS image [row][lane];
+//     once per plane lane j folds row j with bank-conflict-free float4 reads (wave-private: no barrier).
+// No atomics, no barrier, no LDS initialisation.  The kernel is persistent (a wave walks frames gw, gw + #waves, ...): the rows of
+// the next group -- also across plane and frame boundaries -- are in flight in a second register buffer while the
+// current group is reduced, so a frame's epilogue (yz stores, code statistics) overlaps the next frame's loads.
+// G = rows per buffer: G == NY (a whole plane per buffer, ~400 VGPRs, one wave per SIMD, 22-44 KB in flight per
+// wave) or NY/4 (<= 256 VGPRs, two waves per SIMD).
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// reduction over the 64 lanes of a wave; the result is wave-uniform (an SGPR)
+template <int MODE> __device__ __forceinline__ float wave_reduce_uniform(float r) {
+    const float id = Op<MODE>::ident();
+    r = Op<MODE>::f(r, dpp_mov<0xB1, 0xF, true>(id, r));    // quad_perm [1,0,3,2]
+    r = Op<MODE>::f(r, dpp_mov<0x4E, 0xF, true>(id, r));    // quad_perm [2,3,0,1]
+    r = Op<MODE>::f(r, dpp_mov<0x141, 0xF, true>(id, r));   // row_half_mirror
+    r = Op<MODE>::f(r, dpp_mov<0x140, 0xF, true>(id, r));   // row_mirror: every lane of a 16-lane row holds the row's result
+    r = Op<MODE>::f(r, dpp_mov<0x142, 0xA, false>(id, r));  // row_bcast15 into rows 1 and 3
+    r = Op<MODE>::f(r, dpp_mov<0x143, 0xC, false>(id, r));  // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- register arrays indexed by the
+// constant stay in registers (a runtime-indexed array would go to scratch)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// acc[lane J] = uniform value (v_writelane_b32 with a constant lane select: one instruction, no compare mask)
+template <int J> __device__ __forceinline__ float park_lane(float acc, float uniform_val) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(uniform_val), "n"(J));
+    return acc;
+}
+
+template <typename VT, int MODE, int NY, int G, bool PRED>
+__global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_project_wave(ProjParams a) {
+    if constexpr (PRED) { if (*a.o.skip_if_set) return; }
+    constexpr int NG = (NY + G - 1) / G;                // row groups per plane
+    static_assert(NG == 1 || NG % 2 == 0, "the two row buffers must alternate statically");
+    constexpr int U = NG == 1 ? 2 : NG;                 // steps per trip of the main loop (buffer = step parity)
+    const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t cf = (int64_t)blockIdx.x * 4 + wave;        // frame being reduced
+    if (cf >= a.B) return;
+    typedef typename Quad<VT>::T QT;
+    const QT* __restrict__ Vall = reinterpret_cast<const QT*>(a.V);
+    const int64_t fq = (int64_t)X * Y * ZQ;             // quads per frame
+    const int pq = Y * ZQ;                              // quads per plane
+    const bool act = lane < ZQ;
+    const uint32_t kqc = (uint32_t)(act ? lane : ZQ - 1);      // unsigned: global_load saddr + 32-bit voffset form
+    const float id = Op<MODE>::ident();
+    const float4 id4 = make_float4(id, id, id, id);
+
+    // load cursor: one group ahead of the reduction
+    int64_t lf = cf;
+    int li = 0;
+    const QT* __restrict__ lV = Vall + lf * fq;
+    auto next_plane = [&]() {
+        ++li;
+        lV += pq;
+        if (li == X) {                                  // next frame of this wave; past the end: re-read (never consumed)
+            li = 0;
+            const int64_t nf = lf + stride;
+            lf = nf < a.B ? nf : lf;
+            lV = Vall + lf * fq;
+        }
+    };
+    float4 buf[2][G];
+    // xy staging: [row j][column lane] per wave, row stride 68 floats: lane j's float4 reads hit 64 distinct banks
+    constexpr int kXyStride = 68;
+    __shared__ __align__(16) float xy_stage[4][NY * kXyStride];
+    float* xyl = xy_stage[wave];
+    // row j of a plane starts at byte offset min(j, Y-1) * rowb (rows past Y re-read the last one)
+    const uint32_t rowb = (uint32_t)ZQ * sizeof(QT);
+    auto fetch = [&](float4 (&dst)[G], auto gc) {
+        constexpr int g = decltype(gc)::value;
+        const char* __restrict__ base = reinterpret_cast<const char*>(lV);
+        uint32_t rowb_t = rowb;                         // opaque per step: hipcc would otherwise keep NY hoisted row offsets
+        asm volatile("" : "+s"(rowb_t));                // alive across the loop (and spill them)
+        static_for<G>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int j = g * G + r;
+            if constexpr (j < NY) {
+                const uint32_t ro = (uint32_t)(NY == 31 || j < Y ? j : Y - 1) * rowb_t;   // NY == 31: exact (no clamp)
+                dst[r] = ld_stream(reinterpret_cast<const QT*>(base + ro) + kqc);
+            }
+        });
+    };
+    constexpr int PPT = NG == 1 ? 2 : 1;                // planes per trip; whole-plane buffers need an even X
+    Emitter em(a, cf);
+    fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
+    for (; cf < a.B; cf += stride) {
+        em.reset(cf);
+        float4 yz[NY];
+        static_for<NY>([&](auto jc) { yz[decltype(jc)::value] = id4; });
+        float4 xz = id4;
+        for (int ci = 0; ci < X; ci += PPT) {
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int g = NG == 1 ? 0 : u;                  // group reduced in this step
+                constexpr int gn = NG == 1 ? 0 : (u + 1) % NG;      // group fetched in this step
+                if constexpr (gn == 0) next_plane();
+                // unconditional prefetch (past the last frame it re-reads): a conditional one would make hipcc drain vmcnt
+                fetch(buf[(u + 1) & 1], std::integral_constant<int, gn>{});
+                // keep the software pipeline as written: left alone, hipcc hoists the loads of ALL later groups above this
+                // group's reduction (and spills the buffers it then needs)
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<G>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    constexpr int j = g * G + r;
+                    if constexpr (j < NY) {
+                        float4 v = buf[u & 1][r];
+                        if constexpr (MODE == RML_MODE_SUM) v = (act && j < Y) ? v : id4;
+                        yz[j] = op4<MODE>(yz[j], v);
+                        // pin the update here: yz is only "needed" at the loop back-edge, and instruction selection would
+                        // otherwise place all NY updates there and keep every loaded row alive for the whole trip
+                        asm volatile("" : "+v"(yz[j].x), "+v"(yz[j].y), "+v"(yz[j].z), "+v"(yz[j].w));
+                        xz = op4<MODE>(xz, v);
+                        xyl[j * kXyStride + lane] = Op<MODE>::f(Op<MODE>::f(v.x, v.y), Op<MODE>::f(v.z, v.w));
+                    }
+                });
+                // materialise xz here: its only use sits in a lane-conditional block and hipcc would sink the whole reduction
+                // there, keeping every row of the plane alive until then
+                asm volatile("" : "+v"(xz.x), "+v"(xz.y), "+v"(xz.z), "+v"(xz.w));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (g == NG - 1) {                        // plane i of frame cf is complete
+                    const int i = ci + (NG == 1 ? u : 0);
+                    int lane_e = lane;                  // opaque: keeps the store addresses out of loop-invariant hoisting
+                    asm volatile("" : "+v"(lane_e));    // (hipcc would hold NY pointer pairs across the streaming loop)
+#ifdef RML_EXP_NOPLANE
+                    if (i == 0)
+#endif
+                    if (lane_e < ZQ) em.put4(0, (int64_t)i * Z + 4 * lane_e, xz);
+#ifdef RML_EXP_NOPLANE
+                    if (i == 0)
+#endif
+                    {
+                    // xy[i, j]: lane j folds the ZQ per-column partials of row j (transposed, conflict-free b128 reads)
+                    const float* rowp = xyl + (lane_e < NY ? lane_e : NY - 1) * kXyStride;
+                    float m = id;
+                    for (int q = 0; q < ZQ; q += 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(rowp + q);
+                        m = Op<MODE>::f(m, Op<MODE>::f(Op<MODE>::f(t.x, t.y), Op<MODE>::f(t.z, t.w)));
+                    }
+                    if (lane_e < Y) em.put1(2, (int64_t)i * Y + lane_e, m);
+                    }
+                    xz = id4;
+                }
+            });
+        }
+        int lane_f = lane, Y_f = Y;
+        asm volatile("" : "+v"(lane_f), "+s"(Y_f));
+        const bool act_f = lane_f < ZQ;
+#ifdef RML_EXP_NOYZ      // experiment build: yz leaves through ONE store (what does the unrolled epilogue cost?)
+        float4 yzall = id4;
+        static_for<NY>([&](auto jc) { yzall = op4<MODE>(yzall, yz[decltype(jc)::value]); });
+        if (act_f) em.put4(1, 4 * lane_f, yzall);
+#else
+        static_for<NY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j]);
+        });
+#endif
+        em.finish_wave(lane_f);
+    }
+}
+
+template <typename VT, int MODE, int NY, int G>
+void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
+    constexpr int per_cu = (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2;
+    const int64_t want = (pp.B + 3) / 4;
+    const int64_t cap = (int64_t)num_cu * per_cu;
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
+    if (pp.o.skip_if_set) hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, 0, st, pp);
+    else hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, false>), grid, block, 0, st, pp);
+}
+
+// returns true when the wave-per-frame kernel took the launch
+template <typename VT, int MODE>
+bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
+    // RML_WAVEFRAME: 0 = off, 1 = whole-plane buffers (default), 2 = quarter-plane buffers (two waves per SIMD)
+    const char* env = getenv("RML_WAVEFRAME");          // read per call (tests flip it): a getenv is noise next to a launch
+    const int knob = env ? atoi(env) : 1;
+    if (knob == 0 || pp.ZQ <= 32 || pp.ZQ > 64 || pp.Y > 32) return false;
+    const int Y = pp.Y;
+    const bool quarter = knob == 2 || (pp.X & 1);       // whole-plane buffers need an even number of planes
+#define RML_WAVE_CASE(NYV)                                                                     \
+    { if (quarter) launch_wave<VT, MODE, NYV, (NYV + 3) / 4>(pp, num_cu, st);                 \
+      else launch_wave<VT, MODE, NYV, NYV>(pp, num_cu, st); return true; }
+    if (Y <= 8) RML_WAVE_CASE(8)
+    if (Y <= 16) RML_WAVE_CASE(16)
+    if (Y <= 24) RML_WAVE_CASE(24)
+    if (Y == 31) RML_WAVE_CASE(31)
+    RML_WAVE_CASE(32)
+#undef RML_WAVE_CASE
 }
 
 // ------------------------------------------------------------------------------------------
@@ -755,7 +993,7 @@ void launch_rowgroup(const ProjParams& pp, int R, size_t lds_bytes, hipStream_t 
 int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 template <typename VT, int MODE>
-int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
+int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fast) {
     const int X = pp.X, Y = pp.Y, Z = pp.Z;
     *used_fast = false;
     if constexpr (sizeof(VT) == 1 && MODE == RML_MODE_MAX) {
@@ -764,6 +1002,7 @@ int launch_mode(const ProjParams& pp, hipStream_t st, bool* used_fast) {
     bool fast_ok = (Z % 4 == 0) && (Z / 4 <= 64) && ((reinterpret_cast<uintptr_t>(pp.V) & (4 * sizeof(VT) - 1)) == 0);
     size_t lds_bytes = ((size_t)X * Z + (((size_t)X * Y + 3) & ~(size_t)3)) * 4 + 64 * 8;
     if (lds_bytes > 150 * 1024) fast_ok = false;
+    if (fast_ok && try_launch_wave<VT, MODE>(pp, num_cu, st)) { *used_fast = true; return 0; }
     static const bool allow_rowgroup = [] { const char* e = getenv("RML_ROWGROUP"); return !e || atoi(e) != 0; }();
     if (fast_ok && allow_rowgroup && (Z / 4) != next_pow2(Z / 4) && (Z / 4) >= 8) {
         // rows that are not a power-of-two number of float4: row groups with every lane busy
@@ -802,10 +1041,10 @@ void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, 
 
 namespace {
 template <typename VT>
-int launch_project_t(const ProjParams& pp, int mode, hipStream_t st) {
+int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st) {
     bool fast = false;
-    if (mode == RML_MODE_MAX) launch_mode<VT, RML_MODE_MAX>(pp, st, &fast);
-    else if (mode == RML_MODE_SUM) launch_mode<VT, RML_MODE_SUM>(pp, st, &fast);
+    if (mode == RML_MODE_MAX) launch_mode<VT, RML_MODE_MAX>(pp, num_cu, st, &fast);
+    else if (mode == RML_MODE_SUM) launch_mode<VT, RML_MODE_SUM>(pp, num_cu, st, &fast);
     else if (mode == RML_MODE_SLICE) {
         RML_REQUIRE(pp.ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
         hipLaunchKernelGGL(k_project_slice<VT>, dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
@@ -818,12 +1057,12 @@ int launch_project_t(const ProjParams& pp, int mode, hipStream_t st) {
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st) {
-    (void)ctx;
     if (B == 0) return RML_OK;
     RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project: unknown volume dtype %d", vdtype);
     ProjParams pp;
     fill_params(pp, V, B, X, Y, Z, ijk, o);
-    const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, st) : launch_project_t<float>(pp, mode, st);
+    const int num_cu = ctx ? ctx->num_cu : 256;
+    const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;
     RML_HIP(hipGetLastError());
     return RML_OK;

@@ -8,7 +8,8 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 9), (3, 70, 24), (2, 3, 260), (16, 16, 64), (9, 130, 32),
-          (7, 37, 160), (5, 33, 48), (4, 9, 48), (3, 100, 176)]      # row-group kernel shapes (Z/4 not a power of two)
+          (7, 37, 160), (5, 33, 48), (4, 9, 48), (3, 100, 176),      # row-group kernel shapes (Z/4 not a power of two)
+          (4, 8, 132), (6, 16, 256), (3, 20, 180), (2, 32, 176), (5, 31, 176), (1, 24, 200)]   # wave-per-frame kernel
 
 
 def _vol(seed, B, X, Y, Z, integer=True):
@@ -41,6 +42,41 @@ def test_sum_projection_exact_on_integer_data(rml, shape):
     got = rml.project(v, mode="sum")
     for g, w in zip(got, O.project_sum(v)):
         np.testing.assert_array_equal(g, w)      # integer data: float32 sums are exact in any order
+
+
+@pytest.mark.parametrize("knob", ["1", "2"])
+@pytest.mark.parametrize("shape", [(22, 31, 176), (4, 8, 132), (3, 20, 180), (6, 32, 256), (2, 13, 148)])
+def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
+    """The persistent wave-per-frame kernel (k_project_wave): more frames than resident waves, so every wave walks several
+    frames with the cross-frame prefetch, in both buffer configurations (RML_WAVEFRAME=1 whole plane / 2 quarter plane),
+    max and sum, float rows + codes + statistics."""
+    import torch
+    monkeypatch.setenv("RML_WAVEFRAME", knob)
+    X, Y, Z = shape
+    B = 2600 if X * Y * Z < 60000 else 1100
+    rng = np.random.default_rng(X * 1000 + Y)
+    v = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
+    v[rng.random((B, X, Y, Z)) < 0.7] = 0
+    got = rml.project(v, mode="max")
+    for g, w in zip(got, O.project_max(v)):
+        np.testing.assert_array_equal(g, w)
+    got = rml.project(v, mode="sum")
+    for g, w in zip(got, O.project_sum(v)):
+        np.testing.assert_array_equal(g, w)
+    feat, q, isum, isq, flags = rml.process_volumes(v, mode="max", scale=True, codes=True)
+    xz, yz, xy = O.project_max(v)
+    np.testing.assert_array_equal(feat.cpu().numpy(), O.features_from_projections(xz, yz, xy, (True, True, True), True))
+    raw = O.features_from_projections(xz, yz, xy, (True, True, True), False)
+    D = raw.shape[1]
+    qh = q.cpu().numpy()
+    np.testing.assert_array_equal(qh[:, :D] ^ 0x80, raw.astype(np.uint8))
+    assert not qh[:, D:].any()
+    np.testing.assert_array_equal(isum.cpu().numpy(), raw.astype(np.int64).sum(1))
+    np.testing.assert_array_equal(isq.cpu().numpy(), (raw.astype(np.int64) ** 2).sum(1))
+    assert flags.cpu().numpy().all()
+    vf = (rng.standard_normal((64, X, Y, Z)) * 50).astype(np.float32)      # non-integer, negative values
+    for g, w in zip(rml.project(vf, mode="max"), O.project_max(vf)):
+        np.testing.assert_array_equal(g, w)
 
 
 @pytest.mark.parametrize("shape", [(22, 31, 176), (64, 64, 128), (5, 7, 9)])

@@ -72,6 +72,18 @@ def main():
             res.append({"what": "project %s %s" % (a.mode, label), "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4),
                         "ms_min": round(mn, 4), "frames_per_s": round(B / med * 1e3), "alg_GBs": round(alg / med / 1e6, 1),
                         "frac_of_8TBs": round(alg / med / 1e6 / 8000, 4)})
+        # the fused pipeline's first pass: codes + row statistics only (no float rows), through the C ABI
+        lib = _lib.load(); ctx = _lib.context(dev)
+        isum = torch.empty(B, dtype=torch.int32, device=dev); isq = torch.empty(B, dtype=torch.int64, device=dev)
+        flags = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        def codes_only():
+            _lib.check(lib.rml_project(ctx, V.data_ptr(), 1 if a.u8 else 0, B, X, Y, Z, 0, None, 255.0, 7, None, 0, q.data_ptr(), qb,
+                                       isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st))
+        med, mn, mean = timeit(torch, codes_only, a.iters)
+        alg = B * (esz * X * Y * Z + 16)
+        res.append({"what": "project max codes+stats only", "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4), "ms_min": round(mn, 4),
+                    "frames_per_s": round(B / med * 1e3), "alg_GBs": round(alg / med / 1e6, 1), "frac_of_8TBs": round(alg / med / 1e6 / 8000, 4)})
         for r in res:
             print(json.dumps(r))
     else:
