@@ -17,6 +17,11 @@
  *     documented "host".  The library never frees caller memory.
  *   - launches are asynchronous on the caller's hipStream_t (passed as void*; NULL =
  *     the default stream).  A context is bound to one device.
+ *   - threads and streams: a context may be shared.  The entry points that use the context's workspace, second
+ *     stream or caches (rml_svm_decision, rml_svm_kernel_matrix, rml_project_svm, rml_derive_targets,
+ *     rml_resize_bicubic) serialise on it: they hold a per-context mutex for the duration of the (asynchronous) call and
+ *     make their stream wait for the device work the previous such call queued, whatever stream that was on.  Calls on
+ *     different streams are therefore correct but do not overlap on the device; use one context per stream for that.
  *   - layouts: volumes V[b][i][j][k], C-contiguous, (x=theta index i, y=phi index j,
  *     z=range index k); element type float32 (vdtype RML_VOL_F32) or uint8 (RML_VOL_U8: the
  *     radar's native 0..255 magnitudes as stored by the data sets -- a quarter of the HBM
@@ -119,6 +124,16 @@ int rml_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y
                 uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
                 void* stream);
 
+/* Mode SLICE with T targets per frame: the reference classifies every target of one raw image
+ * (`for target in targets:` over one `image`, predict.py:93-119; ground_truth_samples.py:366-440).  Row r = b*T + t of
+ * every output is sliced from frame b at ijk[r] -- the volume is read once per target but never duplicated.
+ *   ijk      B*T*3 int32;  feat / feat_q / row_* have B*T rows, otherwise as rml_project. */
+int rml_project_slices(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int T,
+                       const int32_t* ijk, float scale_div, uint32_t mask,
+                       float* feat, int64_t ld_feat,
+                       uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
+                       void* stream);
+
 /* The three planes as separate arrays (B,X,Z) (B,Y,Z) (B,X,Y); any may be NULL.
  * Same modes; no scaling.  (The tuple a reference caller packs at predict.py:113.) */
 int rml_project_planes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
@@ -195,11 +210,13 @@ int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
                      int32_t* label_vote, int32_t* label_calib, void* stream);
 
 /* SVC(probability=True).predict_proba (the estimator train.py:478 constructs): libsvm's Platt sigmoid on every
- * pair value followed by pairwise coupling (sk:svm/src/libsvm/svm.cpp:2032-2104, 2918-2952).  probA/probB: HOST,
- * P values each (SVC._probA / _probB); dec_ovo: DEVICE N*P libsvm pair values (dec_ovo of rml_svm_decision);
- * proba: DEVICE N*C.  Synchronises the stream before returning. */
-int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, const double* probB,
-                           const double* dec_ovo, int64_t N, double* proba, void* stream);
+ * pair value followed by pairwise coupling (sk:svm/src/libsvm/svm.cpp:2032-2104, 2918-2952).
+ * rml_svm_set_platt: probA/probB HOST, P values each (SVC._probA / _probB); copied to the device once, at load time
+ * (synchronous, like rml_svm_load).  rml_svm_pairwise_proba: dec_ovo DEVICE N*P libsvm pair values (dec_ovo of
+ * rml_svm_decision); proba DEVICE N*C; an ordinary asynchronous launch on `stream`; RML_ERR_STATE when the model has
+ * no Platt coefficients. */
+int rml_svm_set_platt(rml_ctx* ctx, rml_svm* m, const double* probA, const double* probB);
+int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* dec_ovo, int64_t N, double* proba, void* stream);
 
 /* Kernel values against the model's support vectors, K[n][m] = k(x_n, sv_m) for m < M, float64, exact to the
  * same arithmetic as rml_svm_decision (path AUTO / I8 / F64).  With the training rows loaded as the "support vectors"

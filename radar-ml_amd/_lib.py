@@ -18,7 +18,7 @@ class RadarMLError(RuntimeError):
 
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()      # re-entrant: check() -> load() may run while context() holds it
 _ctx = {}
 
 c_void_p, c_int, c_int64, c_uint32, c_uint64, c_float, c_double = (
@@ -37,6 +37,8 @@ SIGNATURES = {
     "rml_feature_len": (c_int64, [c_int, c_int, c_int, c_uint32]),
     "rml_project": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_project_slices": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_uint32,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_project_planes": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -54,7 +56,8 @@ SIGNATURES = {
     "rml_svm_dim": (c_int64, [c_void_p]),
     "rml_svm_decision": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rml_svm_pairwise_proba": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rml_svm_set_platt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_svm_pairwise_proba": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "rml_svm_kernel_matrix": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                 c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -138,11 +141,27 @@ def context(device=None):
         device = device.index if device.index is not None else torch.cuda.current_device()
     lib = load()
     with _lock:
-        if device not in _ctx:
-            h = c_void_p()
-            check(lib.rml_ctx_create(int(device), C.byref(h)), "rml_ctx_create")
-            _ctx[device] = h
-        return _ctx[device]
+        h = _ctx.get(device)
+    if h is None:
+        # create outside the lock (a failing rml_ctx_create must raise, not dead-lock: check() calls load())
+        new = c_void_p()
+        check(lib.rml_ctx_create(int(device), C.byref(new)), "rml_ctx_create")
+        with _lock:
+            h = _ctx.setdefault(device, new)
+        if h is not new:                    # another thread won the race
+            lib.rml_ctx_destroy(new)
+    return h
+
+
+def device_of(device=None):
+    """torch.device of a 'cuda:N' / int / None (current) argument."""
+    import torch
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    if d.type != "cuda":
+        raise RadarMLError("the radar-ml HIP path runs on a HIP device, not %r" % (device,))
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def ptr(t):

@@ -108,6 +108,30 @@ def _as_device_volumes(a, device=None):
     return t.to(device=device, non_blocking=True).contiguous(), _lib.VOL_U8
 
 
+def _slice_indices(ijk, B, X, Y, Z, dev):
+    """ijk as (B,3) or (B,T,3) (numpy / torch, any integer dtype) -> (contiguous int32 CUDA tensor (B*T,3), T).
+    Raises like the reference's NumPy indexing would: one (i,j,k) (or T of them) per frame, every index within
+    [-size, size) (Python negative-index wrap) -- the kernel never sees an index it would have to clamp."""
+    torch = _torch()
+    t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk)
+    if t.ndim == 1 and B == 1:
+        t = t.reshape(1, 3)
+    if t.ndim not in (2, 3) or t.shape[-1] != 3:
+        raise ValueError("ijk must be (B,3) or (B,T,3)")
+    if t.shape[0] != B:
+        raise ValueError("ijk must have one (i,j,k) row (or T rows) per frame: got %d for %d frames" % (t.shape[0], B))
+    T = 1 if t.ndim == 2 else int(t.shape[1])
+    if T < 1:
+        raise ValueError("ijk holds no target")
+    t = t.to(device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
+    size = torch.tensor([X, Y, Z], dtype=torch.int32, device=dev)
+    bad = ((t >= size) | (t < -size)).any(dim=0).cpu().numpy()
+    for ax in range(3):
+        if bad[ax]:
+            raise IndexError("index out of bounds for axis %d with size %d" % (ax, (X, Y, Z)[ax]))
+    return t, T
+
+
 def project(volumes, mode="max", ijk=None, return_numpy=None):
     """Batched 3-D -> 2-D projections: returns the reference's tuple ``(xz, yz, xy)``.
 
@@ -136,14 +160,9 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
     if m == _lib.MODE_SLICE:
         if ijk is None:
             raise ValueError("mode='slice' needs ijk")
-        ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
-            device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
-        if ijk_t.shape[0] != B:
-            raise ValueError("ijk must have one (i,j,k) per frame")
-        chk = ijk_t.cpu().numpy()
-        for ax, size in enumerate((X, Y, Z)):
-            if (chk[:, ax] >= size).any() or (chk[:, ax] < -size).any():
-                raise IndexError("index out of bounds for axis %d with size %d" % (ax, size))
+        ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev)
+        if T != 1:
+            raise ValueError("project(): one (i,j,k) per frame; use process_volumes for several targets per frame")
     xz = torch.empty((B, X, Z), dtype=torch.float32, device=dev)
     yz = torch.empty((B, Y, Z), dtype=torch.float32, device=dev)
     xy = torch.empty((B, X, Y), dtype=torch.float32, device=dev)
@@ -159,14 +178,18 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
 
 
 def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, yz=True, xy=True), scale=False,
-                    out=None, codes=False):
+                    out=None, codes=False, num_targets=1, device=None):
     """Fused batched front door: (B,X,Y,Z) volumes -> (B,D) float32 feature rows in one pass over
     the volumes (projection + ``process_samples`` at zoom 1).  Returns a CUDA tensor; with
     ``codes=True`` returns ``(feat, codes_u8, row_isum, row_isq, row_flags)`` for the exact SVM path.
+
+    mode='slice' takes ``ijk`` as (B,3) or -- several targets per frame, the reference's ``for target in targets`` over one
+    image (predict.py:93-119) -- (B,T,3): the result then has B*T rows, frame-major (row b*T+t), and no volume is
+    duplicated.  Without ``ijk`` the ``num_targets`` strongest derived targets of every frame are used (common.py:49-80).
     """
     torch = _torch()
     lib = _lib.load()
-    v, vdt = _as_device_volumes(volumes)
+    v, vdt = _as_device_volumes(volumes, device)
     if v.ndim == 3:
         v = v.unsqueeze(0)
     B, X, Y, Z = v.shape
@@ -176,25 +199,33 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
     D = int(lib.rml_feature_len(X, Y, Z, bits))
     m = _lib.MODES[mode]
     ijk_t = None
+    T = 1
     if m == _lib.MODE_SLICE:
         if ijk is None:
-            # no SDK targets: derive the strongest return per frame on the GPU (common.py:49-80), then slice there
-            ijk = derive_targets(v, 1)[:, 0, :]
-        ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
-            device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
-    feat = out if out is not None else torch.empty((B, D), dtype=torch.float32, device=dev)
+            # no SDK targets: derive the strongest return(s) per frame on the GPU (common.py:49-80), then slice there
+            ijk = derive_targets(v, num_targets)
+        ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev)
+    R = B * T                           # output rows
+    feat = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=dev)
+    if feat.shape[0] != R or feat.shape[1] < D or feat.device != dev:
+        raise ValueError("out must be a (%d, >=%d) float32 tensor on %s" % (R, D, dev))
     q = isum = isq = flags = None
     ldq = 0
     if codes:
         ldq = (D + 127) // 128 * 128
-        q = torch.empty((B, ldq), dtype=torch.uint8, device=dev)
-        isum = torch.empty((B,), dtype=torch.int32, device=dev)
-        isq = torch.empty((B,), dtype=torch.int64, device=dev)
-        flags = torch.empty((B,), dtype=torch.int32, device=dev)
+        q = torch.empty((R, ldq), dtype=torch.uint8, device=dev)
+        isum = torch.empty((R,), dtype=torch.int32, device=dev)
+        isq = torch.empty((R,), dtype=torch.int64, device=dev)
+        flags = torch.empty((R,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.rml_project(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
-                                   bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
-                                   _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
+        if T > 1:
+            _lib.check(lib.rml_project_slices(ctx, _lib.ptr(v), vdt, B, X, Y, Z, T, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
+                                              bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                              _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project_slices")
+        else:
+            _lib.check(lib.rml_project(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
+                                       bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                       _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
     if codes:
         return feat, q, isum, isq, flags
     return feat

@@ -38,6 +38,7 @@ struct ProjParams {
     int64_t B;
     int X, Y, Z, ZQ;
     const int32_t* ijk;
+    int tpf;            // mode SLICE: targets (output rows) per frame; output row b reads frame b / tpf
     ProjOut o;
     int vec_ok[3];   // float4 stores allowed for plane pl (16-B aligned base and stride)
 };
@@ -867,8 +868,8 @@ __global__ __launch_bounds__(kThreads) void k_project_slice(ProjParams a) {
     __shared__ int64_t red[64];
     if (a.o.skip_if_set && *a.o.skip_if_set) return;
     const int X = a.X, Y = a.Y, Z = a.Z;
-    const int64_t b = blockIdx.x;
-    const VT* __restrict__ Vb = static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z;
+    const int64_t b = blockIdx.x;       // output row; several rows (targets) may share one frame
+    const VT* __restrict__ Vb = static_cast<const VT*>(a.V) + (b / a.tpf) * (int64_t)X * Y * Z;
     int i = a.ijk[b * 3 + 0], j = a.ijk[b * 3 + 1], k = a.ijk[b * 3 + 2];
     i = i < 0 ? i + X : i; j = j < 0 ? j + Y : j; k = k < 0 ? k + Z : k;
     // out-of-range after wrapping would raise IndexError in the reference; clamp defensively
@@ -1032,7 +1033,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
 }
 
 void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
-    pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.o = o;
+    pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.o = o;
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
 }
@@ -1056,11 +1057,13 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
 }  // namespace
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
-                       const int32_t* ijk, const ProjOut& o, hipStream_t st) {
+                       const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame) {
     if (B == 0) return RML_OK;
     RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project: unknown volume dtype %d", vdtype);
+    RML_REQUIRE(targets_per_frame == 1 || mode == RML_MODE_SLICE, RML_ERR_INVALID, "rml_project: several targets per frame only in mode SLICE");
     ProjParams pp;
-    fill_params(pp, V, B, X, Y, Z, ijk, o);
+    fill_params(pp, V, B, X, Y, Z, ijk, o);       // B counts output rows
+    pp.tpf = targets_per_frame;
     const int num_cu = ctx ? ctx->num_cu : 256;
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;
@@ -1077,10 +1080,33 @@ extern "C" int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask) {
     return d;
 }
 
+static int project_rows(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode, int tpf,
+                        const int32_t* ijk, float scale_div, uint32_t mask,
+                        float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
+                        int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream);
+
 extern "C" int rml_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                            const int32_t* ijk, float scale_div, uint32_t mask,
                            float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
                            int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
+    return project_rows(ctx, V, vdtype, B, X, Y, Z, mode, 1, ijk, scale_div, mask, feat, ld_feat, feat_q, ld_q, row_isum, row_isq,
+                        row_flags, stream);
+}
+
+extern "C" int rml_project_slices(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int T,
+                                  const int32_t* ijk, float scale_div, uint32_t mask,
+                                  float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
+                                  int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
+    RML_REQUIRE(T >= 1 && B >= 0 && B * (int64_t)T < (int64_t)1 << 31, RML_ERR_INVALID, "rml_project_slices: bad target count");
+    RML_REQUIRE(B == 0 || ijk != nullptr, RML_ERR_INVALID, "rml_project_slices: ijk is NULL");
+    return project_rows(ctx, V, vdtype, B * T, X, Y, Z, RML_MODE_SLICE, T, ijk, scale_div, mask, feat, ld_feat, feat_q, ld_q, row_isum,
+                        row_isq, row_flags, stream);
+}
+
+static int project_rows(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode, int tpf,
+                        const int32_t* ijk, float scale_div, uint32_t mask,
+                        float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
+                        int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
     RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_project: bad arguments");
     if (B == 0) return RML_OK;
     RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project: V is NULL");
@@ -1106,7 +1132,7 @@ extern "C" int rml_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, i
     o.qrow = feat_q; o.qD = D;
     o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
     o.scale_div = scale_div;
-    return rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream));
+    return rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, static_cast<hipStream_t>(stream), tpf);
 }
 
 extern "C" int rml_project_planes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
@@ -1135,6 +1161,7 @@ extern "C" int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64
     RML_HIP(hipSetDevice(ctx->device));
     if (B == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rml_ctx_guard guard(ctx, st);           // shared workspace
     // workspace: sum planes xz (B,X,Z) and yz (B,Y,Z)
     size_t need = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
     void* ws = nullptr;

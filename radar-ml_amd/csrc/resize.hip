@@ -267,6 +267,7 @@ void launch_resize(const ResizeArgs& a, size_t lds, int num_cu, hipStream_t st) 
 
 // device copy of an axis table, cached in the context (a handful of (in, out) pairs per process)
 int axis_table(rml_ctx* ctx, int in_size, int out_size, const int** bounds, const double** kk, int* ksize) {
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);    // the table cache is shared by every thread using the context
     for (const auto& e : ctx->resize_tabs)
         if (e.in == in_size && e.out == out_size) { *bounds = e.bounds; *kk = e.kk; *ksize = e.ksize; return RML_OK; }
     AxisTable t;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/radarml.h"
@@ -35,6 +36,29 @@ struct rml_ctx {
     size_t prof_used_g = 0;
     double prof_ops_g = 0.0;
     std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
+    // Entry points that use the shared workspace / events / caches take `mu` for the duration of the call and order
+    // their stream behind the previous user's work (ev_last), so calls from several host threads or on several
+    // streams cannot interleave on the workspace (rml_ctx_guard below).
+    std::recursive_mutex mu;
+    hipEvent_t ev_last = nullptr;
+    bool ev_last_valid = false;
+};
+
+// RAII serialisation of one entry point on a context: locks ctx->mu, makes `stream` wait for the work the previous
+// guarded call queued (on whatever stream), and on destruction records the new "last use" point on `stream`.
+struct rml_ctx_guard {
+    rml_ctx* ctx;
+    hipStream_t st;
+    explicit rml_ctx_guard(rml_ctx* c, hipStream_t stream) : ctx(c), st(stream) {
+        ctx->mu.lock();
+        if (ctx->ev_last_valid) (void)hipStreamWaitEvent(st, ctx->ev_last, 0);
+    }
+    ~rml_ctx_guard() {
+        if (ctx->ev_last && hipEventRecord(ctx->ev_last, st) == hipSuccess) ctx->ev_last_valid = true;
+        ctx->mu.unlock();
+    }
+    rml_ctx_guard(const rml_ctx_guard&) = delete;
+    rml_ctx_guard& operator=(const rml_ctx_guard&) = delete;
 };
 
 // records an event on st when profiling is on (no-op otherwise)
@@ -85,7 +109,7 @@ struct ProjOut {
 };
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
-                       const int32_t* ijk, const ProjOut& o, hipStream_t st);
+                       const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);
 
 // ---- SVM (svm.hip) ------------------------------------------------------------------------
 struct rml_svm {
@@ -108,6 +132,7 @@ struct rml_svm {
     double* W = nullptr;          // PT x Mpad per-pair SV weights (zero padded)
     double* intercept = nullptr;  // P
     double* calib = nullptr;      // 2*C (a then b)
+    double* platt = nullptr;      // libsvm probA | probB (2 x kMaxP), set by rml_svm_set_platt
     uint32_t mask_hint = 0;
 };
 

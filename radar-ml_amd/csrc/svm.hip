@@ -468,7 +468,8 @@ __device__ __forceinline__ double expit_d(double x) {
     return e / (1.0 + e);
 }
 
-constexpr int kMaxC = 4, kMaxP = 6;
+// up to 6 classes (15 one-vs-one pairs): person / dog / cat plus the aliases of train.py:656-663 fit with room to spare
+constexpr int kMaxC = 6, kMaxP = 15;
 
 __global__ __launch_bounds__(256) void k_svm_finish(FinishArgs a) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -656,6 +657,8 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
         RML_GEMM_CASE(1)
         RML_GEMM_CASE(3)
         RML_GEMM_CASE(6)
+        RML_GEMM_CASE(10)
+        RML_GEMM_CASE(15)
         default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count");
     }
 #undef RML_GEMM_CASE
@@ -768,7 +771,7 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
     rml_svm* m = new (std::nothrow) rml_svm();
     RML_REQUIRE(m != nullptr, RML_ERR_NOMEM, "rml_svm_load: out of host memory");
     m->M = M; m->D = D; m->C = n_classes; m->P = n_classes * (n_classes - 1) / 2;
-    m->PT = m->P <= 1 ? 1 : (m->P <= 3 ? 3 : 6);
+    m->PT = m->P <= 1 ? 1 : (m->P <= 3 ? 3 : (m->P <= 6 ? 6 : (m->P <= 10 ? 10 : 15)));
     m->kernel = kernel; m->gamma = gamma; m->code_scale = code_scale > 1.0 ? code_scale : 1.0;
     m->Mpad = round_up(M, kTile);
     m->Kq = round_up(D, kStepBytes); m->Kf = round_up(D, 32);
@@ -849,7 +852,7 @@ extern "C" int rml_svm_free(rml_ctx* ctx, rml_svm* m) {
     if (!m) return RML_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {m->sv_f32, m->sv_nsq, m->sv_q, m->sv_term_q, m->W, m->intercept, m->calib};
+    void* bufs[] = {m->sv_f32, m->sv_nsq, m->sv_q, m->sv_term_q, m->W, m->intercept, m->calib, m->platt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete m;
     return RML_OK;
@@ -883,6 +886,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     RML_HIP(hipSetDevice(ctx->device));
     if (N == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rml_ctx_guard guard(ctx, st);           // shared workspace
     const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
     const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
@@ -921,6 +925,7 @@ extern "C" int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, c
     RML_REQUIRE(path != RML_PATH_I8 || m->exact, RML_ERR_STATE, "rml_svm_kernel_matrix: exact path requested but the model is not on the code grid");
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rml_ctx_guard guard(ctx, st);           // shared workspace
     const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
     const bool need_q = m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     ChunkWs probe = carve(m, CH, nullptr, need_q, true);
@@ -960,6 +965,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     RML_HIP(hipSetDevice(ctx->device));
     if (B == 0) return RML_OK;
     hipStream_t caller = static_cast<hipStream_t>(stream);
+    rml_ctx_guard guard(ctx, caller);       // shared workspaces, aux stream and chunk events (the caller's stream joins at the end)
     // with a CU partition the projections run on the context's masked stream, forked from the caller's
     hipStream_t st = ctx->proj_stream ? ctx->proj_stream : caller;
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
@@ -1068,24 +1074,27 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     return RML_OK;
 }
 
-extern "C" int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* probA, const double* probB,
-                                      const double* dec_ovo, int64_t N, double* proba, void* stream) {
-    RML_REQUIRE(ctx && m && probA && probB && N >= 0, RML_ERR_INVALID, "rml_svm_pairwise_proba: bad arguments");
+// libsvm's own Platt coefficients (SVC(probability=True): sk:svm/_base.py _probA / _probB, one pair per class pair):
+// uploaded once, at load time, so that rml_svm_pairwise_proba is an ordinary asynchronous launch
+extern "C" int rml_svm_set_platt(rml_ctx* ctx, rml_svm* m, const double* probA, const double* probB) {
+    RML_REQUIRE(ctx && m && probA && probB, RML_ERR_INVALID, "rml_svm_set_platt: NULL argument");
+    RML_HIP(hipSetDevice(ctx->device));
+    std::vector<double> ab(2 * kMaxP, 0.0);
+    for (int p = 0; p < m->P; ++p) { ab[p] = probA[p]; ab[kMaxP + p] = probB[p]; }
+    if (!m->platt) RML_HIP(hipMalloc(reinterpret_cast<void**>(&m->platt), ab.size() * sizeof(double)));
+    RML_HIP(hipMemcpy(m->platt, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice));
+    return RML_OK;
+}
+
+extern "C" int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* dec_ovo, int64_t N, double* proba, void* stream) {
+    RML_REQUIRE(ctx && m && N >= 0, RML_ERR_INVALID, "rml_svm_pairwise_proba: bad arguments");
     if (N == 0) return RML_OK;
     RML_REQUIRE(dec_ovo && proba, RML_ERR_INVALID, "rml_svm_pairwise_proba: NULL array");
+    RML_REQUIRE(m->platt != nullptr, RML_ERR_STATE, "rml_svm_pairwise_proba: the model has no Platt coefficients (rml_svm_set_platt)");
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the 2 x P Platt coefficients travel through the workspace (host pointers in, like rml_svm_load)
-    void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, 2 * kMaxP * sizeof(double) + 256, &ws);
-    if (rc) return rc;
-    double* dA = static_cast<double*>(ws);
-    double* dB = dA + kMaxP;
-    RML_HIP(hipMemcpyAsync(dA, probA, m->P * sizeof(double), hipMemcpyHostToDevice, st));
-    RML_HIP(hipMemcpyAsync(dB, probB, m->P * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pairwise_proba, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dec_ovo, N, m->C, dA, dB, proba);
+    hipLaunchKernelGGL(k_pairwise_proba, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dec_ovo, N, m->C, m->platt, m->platt + kMaxP, proba);
     RML_HIP(hipGetLastError());
-    RML_HIP(hipStreamSynchronize(st));      // probA/probB are caller-owned host memory
     return RML_OK;
 }
 

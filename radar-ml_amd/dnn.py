@@ -93,10 +93,13 @@ class Classifier(_module_base()):
 
     # ---- fused HIP trunk -------------------------------------------------------------------------------
     def _packed_trunk_weights(self):
-        """conv weights in the layout of rml_dnn_trunk (cached; invalidate by deleting ``_trunk_pack``)."""
+        """conv weights in the layout of rml_dnn_trunk, cached and re-packed whenever a convolution parameter was written
+        (optimizer step, load_state_dict, .to(): the tensors' version counters / storage change)."""
         import torch
+        key = tuple((p._version, p.data_ptr()) for br in self.branches for cv in (br[0].conv, br[1].conv) for p in (cv.weight, cv.bias))
         pk = getattr(self, "_trunk_pack", None)
-        if pk is None:
+        if pk is None or getattr(self, "_trunk_pack_key", None) != key:
+            self._trunk_pack_key = key
             w1 = torch.stack([br[0].conv.weight.detach().float().reshape(64, 9) for br in self.branches]).contiguous()
             b1 = torch.stack([br[0].conv.bias.detach().float() for br in self.branches]).contiguous()
             # (32, 64, 3, 3) -> (32, ky, kx, cin) -> (32, 576): k = (ky*3+kx)*64 + cin

@@ -15,11 +15,6 @@ def tf_same_pad(size, kernel, stride):
     return total // 2, total - total // 2
 
 
-class SamePadConv2d:
-    """Factory: Conv2d with TF 'same' padding resolved at call time (nn.Module defined lazily to keep torch
-    imports out of module import)."""
-
-
 def make_same_conv(in_ch, out_ch, kernel, stride):
     import torch
     import torch.nn as nn
@@ -199,6 +194,10 @@ def bn_lrelu_pad(x, bn, slope=0.2, pad=0, conv_bias=None):
                                        conv_bias)
     with torch.no_grad():
         bn.num_batches_tracked += 1
+        if conv_bias is not None:
+            # the kernel tracked the mean of the bias-free activations; eval mode (and the unfused layers) normalise
+            # conv(x) + bias, whose mean is larger by exactly the bias: running_mean += momentum * bias keeps both in step
+            bn.running_mean.add_(conv_bias.detach().to(bn.running_mean.dtype), alpha=float(bn.momentum))
     return y
 
 
@@ -278,4 +277,6 @@ def conv1_bn_lrelu_pad(x_padded, conv, bn, slope, pad, dtype):
                                              bn.eps, bn.momentum, slope, pad, dtype)
     with torch.no_grad():
         bn.num_batches_tracked += 1
+        if conv.bias is not None:       # see bn_lrelu_pad: running statistics of conv(x) + bias
+            bn.running_mean.add_(conv.bias.detach().to(bn.running_mean.dtype), alpha=float(bn.momentum))
     return y

@@ -50,7 +50,17 @@ class _Base:
         if X.shape[1] != self.n_features_in_:
             raise ValueError("X has %d features, but %s is expecting %d features as input."
                              % (X.shape[1], type(self).__name__, self.n_features_in_))
-        return _as_device_f32(X)
+        # rows go to the model's device (its buffers and its context live there), whatever the current device is
+        return _as_device_f32(X, getattr(self, "_dev", None))
+
+
+MAX_CLASSES = 6         # kMaxC of csrc/svm.hip (15 one-vs-one pairs)
+
+
+def _check_classes(n):
+    if not 2 <= n <= MAX_CLASSES:
+        raise NotImplementedError("%d classes: the HIP SVM / linear kernels are built for 2..%d classes "
+                                  "(csrc/svm.hip kMaxC)" % (n, MAX_CLASSES))
 
 
 class GpuSVC(_Base):
@@ -69,12 +79,13 @@ class GpuSVC(_Base):
         self.gamma = float(gamma)
         self.path = path
         C_ = len(self.classes_)
+        _check_classes(C_)
         dc, ic, ns = _f64(dual_coef), _f64(intercept), np.ascontiguousarray(n_support, dtype=np.int32)
         if dc.shape != (C_ - 1, sv.shape[0]):
             raise ValueError("dual_coef must be (n_classes-1, n_SV) in libsvm order (SVC._dual_coef_)")
         if not torch.cuda.is_available():
             raise _lib.RadarMLError("no HIP device is visible: the radar-ml HIP path needs an MI355X (no CPU fallback)")
-        self._dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._dev = _lib.device_of(device)
         self._ctx = _lib.context(self._dev)
         self.code_scale = _detect_code_scale(sv)
         ca = cb = None
@@ -93,6 +104,12 @@ class GpuSVC(_Base):
         # libsvm's own Platt coefficients (SVC(probability=True)): used by predict_proba of the bare SVC
         self._probA = None if probA is None or len(np.ravel(probA)) == 0 else _f64(np.ravel(probA))
         self._probB = None if probB is None or len(np.ravel(probB)) == 0 else _f64(np.ravel(probB))
+        if self._probA is not None:
+            P = C_ * (C_ - 1) // 2
+            if len(self._probA) != P or self._probB is None or len(self._probB) != P:
+                raise ValueError("probA / probB must hold one value per class pair (%d)" % P)
+            with torch.cuda.device(self._dev):      # uploaded once: predict_proba is then an asynchronous launch
+                _lib.check(lib.rml_svm_set_platt(self._ctx, h, self._probA.ctypes.data, self._probB.ctypes.data), "rml_svm_set_platt")
         self.exact = bool(lib.rml_svm_is_exact(h)) and self.code_scale > 0
         self.n_sv = sv.shape[0]
 
@@ -106,8 +123,20 @@ class GpuSVC(_Base):
         a = b = None
         if calib is not None:
             a, b = calib
-        return cls(clf.support_vectors_, clf._dual_coef_, clf._intercept_, clf._n_support, clf._gamma, clf.classes_,
-                   kernel=kernel, calib_a=a, calib_b=b, probA=getattr(clf, "_probA", None), probB=getattr(clf, "_probB", None),
+        # private libsvm-order arrays; the fall-backs are the names older pickles carry (the reference pins scikit-learn
+        # 0.24, requirements.txt:57: probA_ / probB_ are plain attributes there, n_support_ a property of _n_support)
+        def pick(*names):
+            for nm in names:
+                v = clf.__dict__.get(nm, None) if nm.startswith("_") else getattr(clf, nm, None)
+                if v is not None:
+                    return v
+            return None
+        dual = pick("_dual_coef_", "dual_coef_")
+        icpt = pick("_intercept_", "intercept_")
+        if "_dual_coef_" not in clf.__dict__ and len(clf.classes_) == 2:
+            dual, icpt = -np.asarray(dual), -np.asarray(icpt)       # sk:svm/_base.py:266-270: the public pair is negated
+        return cls(clf.support_vectors_, dual, icpt, pick("_n_support", "n_support_"), pick("_gamma", "gamma"), clf.classes_,
+                   kernel=kernel, calib_a=a, calib_b=b, probA=pick("_probA", "probA_"), probB=pick("_probB", "probB_"),
                    decision_function_shape=getattr(clf, "decision_function_shape", "ovr"), **kw)
 
     def __del__(self):
@@ -169,7 +198,8 @@ class GpuSVC(_Base):
         Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib])."""
         torch = _torch()
         lib = _lib.load()
-        v, vdt = _as_device_volumes(volumes)
+        from .common import derive_targets, _slice_indices, process_volumes
+        v, vdt = _as_device_volumes(volumes, self._dev)
         if v.ndim == 3:
             v = v.unsqueeze(0)
         B, X, Y, Z = v.shape
@@ -179,12 +209,19 @@ class GpuSVC(_Base):
         if want_proba is None:
             want_proba = self.has_calibration
         ijk_t = None
-        if mode == "slice" and ijk is None:
-            from .common import derive_targets
-            ijk = derive_targets(v, 1)[:, 0, :]          # DerivedTarget.get_derived_targets on the GPU (common.py:49-80)
-        if ijk is not None:
-            ijk_t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk).to(
-                device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
+        if mode == "slice":
+            if ijk is None:
+                ijk = derive_targets(v, 1)[:, 0, :]      # DerivedTarget.get_derived_targets on the GPU (common.py:49-80)
+            ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev)
+            if T > 1:
+                # several targets per frame (predict.py:93-119 classifies every target of one image): slice rows first,
+                # then the SVM on the B*T rows; outputs are (B*T, ...) in frame-major order
+                feat = process_volumes(v, mode="slice", ijk=ijk_t.reshape(B, T, 3), proj_mask=proj_mask, scale=scale)
+                ovo, ovr, vote, proba, lab = self._decide(feat, want_proba=want_proba)
+                out = {"dec_ovo": ovo, "dec_ovr": ovr, "label_vote": vote}
+                if want_proba:
+                    out["proba"], out["label_calib"] = proba, lab
+                return out
         out = {
             "dec_ovo": torch.empty((B, P), dtype=torch.float64, device=dev),
             "dec_ovr": torch.empty((B,) if C_ == 2 else (B, C_), dtype=torch.float64, device=dev),
@@ -236,9 +273,8 @@ class GpuSVC(_Base):
         N, C_ = Xd.shape[0], len(self.classes_)
         proba = torch.empty((N, C_), dtype=torch.float64, device=Xd.device)
         with torch.cuda.device(Xd.device):
-            _lib.check(lib.rml_svm_pairwise_proba(self._ctx, self._h, self._probA.ctypes.data, self._probB.ctypes.data,
-                                                  _lib.ptr(ovo), N, _lib.ptr(proba), _lib.stream_ptr(Xd.device)),
-                       "rml_svm_pairwise_proba")
+            _lib.check(lib.rml_svm_pairwise_proba(self._ctx, self._h, _lib.ptr(ovo), N, _lib.ptr(proba),
+                                                  _lib.stream_ptr(Xd.device)), "rml_svm_pairwise_proba")
         return proba.cpu().numpy()
 
     def predict(self, X):
@@ -255,6 +291,7 @@ class GpuCalibratedClassifier(_Base):
         self.estimator = estimator
         self.classes_ = estimator.classes_
         self.n_features_in_ = estimator.n_features_in_
+        self._dev = estimator._dev
 
     def predict_proba(self, X):
         """sk:calibration.py:492-518,727-784."""
@@ -290,7 +327,8 @@ class GpuLinearClassifier(_Base):
         self.classes_ = np.asarray(classes)
         self.n_features_in_ = cf.shape[1]
         C_ = len(self.classes_)
-        self._dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _check_classes(C_)
+        self._dev = _lib.device_of(device)
         self._ctx = _lib.context(self._dev)
         ca = cb = None
         if calib_a is not None:
@@ -339,7 +377,7 @@ class GpuLinearClassifier(_Base):
         """Batched path for the reference's default (SGD) model: (B,X,Y,Z) volumes -> projection + feature rows
         (one pass over the volumes) -> linear scores, labels and calibrated probabilities, all on the GPU."""
         from .common import process_volumes
-        feat = process_volumes(volumes, mode=mode, ijk=ijk, proj_mask=proj_mask, scale=scale)
+        feat = process_volumes(volumes, mode=mode, ijk=ijk, proj_mask=proj_mask, scale=scale, device=self._dev)
         dec, lab, proba, labc = self._run(feat, want_proba=self.has_calibration)
         out = {"dec": dec, "label": lab}
         if proba is not None:
@@ -374,6 +412,27 @@ class KernelMatrix:
         return self._svc.kernel_matrix(X)
 
 
+def unwrap_calibrated(cc):
+    """(estimator, a, b) of one ``_CalibratedClassifier``.  scikit-learn >= 1.2 names the parts ``estimator`` /
+    ``calibrators``; the release the reference pins (0.24.0, requirements.txt:57 -- what its own pickles were written
+    with, train.py:722-731) names them ``base_estimator`` / ``calibrators_``.  Pure attribute access: no GPU needed."""
+    if getattr(cc, "method", "sigmoid") != "sigmoid":
+        raise NotImplementedError("only sigmoid calibration (the sklearn default the reference uses)")
+    est = getattr(cc, "estimator", None)
+    if est is None:
+        est = getattr(cc, "base_estimator", None)
+    cals = getattr(cc, "calibrators", None)
+    if cals is None:
+        cals = getattr(cc, "calibrators_", None)
+    if est is None or cals is None:
+        raise NotImplementedError("unrecognised _CalibratedClassifier layout: %s" % sorted(vars(cc)))
+    if type(est).__name__ == "FrozenEstimator":
+        est = est.estimator
+    a = np.array([c.a_ for c in cals], dtype=np.float64)
+    b = np.array([c.b_ for c in cals], dtype=np.float64)
+    return est, a, b
+
+
 def from_sklearn(obj, **kw):
     """Ingest the fitted object the reference pickles (train.py:729-731) or a bare estimator.
 
@@ -384,14 +443,7 @@ def from_sklearn(obj, **kw):
         ccs = obj.calibrated_classifiers_
         if len(ccs) != 1:
             raise NotImplementedError("only cv='prefit' calibration (one calibrated classifier) is used by the reference")
-        cc = ccs[0]
-        if getattr(cc, "method", "sigmoid") != "sigmoid":
-            raise NotImplementedError("only sigmoid calibration (the sklearn default the reference uses)")
-        a = np.array([c.a_ for c in cc.calibrators])
-        b = np.array([c.b_ for c in cc.calibrators])
-        est = cc.estimator
-        if type(est).__name__ == "FrozenEstimator":
-            est = est.estimator
+        est, a, b = unwrap_calibrated(ccs[0])
         if type(est).__name__ == "SVC":
             return GpuCalibratedClassifier(GpuSVC.from_sklearn(est, calib=(a, b), **kw))
         if type(est).__name__ == "SGDClassifier":

@@ -140,3 +140,53 @@ def test_dataset_pickle_roundtrip(rml, tmp_path):
     assert labels == ["person", "dog", "cat", "dog", "person"]
     a, b, c, labels = ds.load_dataset([p, p], desired_labels={"person"})
     assert a.shape == (4, 22, 176) and labels == ["person"] * 4
+
+
+def test_unwrap_calibrated_accepts_sklearn_024_attribute_names():
+    """The reference pins scikit-learn 0.24 (requirements.txt:57): its pickled _CalibratedClassifier carries
+    ``base_estimator`` / ``calibrators_`` where 1.x has ``estimator`` / ``calibrators``."""
+    import types
+    import importlib
+    svm = importlib.import_module("radar_ml_amd.svm")
+    cals = [types.SimpleNamespace(a_=-1.5 - i, b_=0.25 * i) for i in range(3)]
+    est = types.SimpleNamespace(name="est")
+    new = types.SimpleNamespace(estimator=est, calibrators=cals, method="sigmoid")
+    old = types.SimpleNamespace(base_estimator=est, calibrators_=cals, method="sigmoid")
+    for cc in (new, old):
+        e, a, b = svm.unwrap_calibrated(cc)
+        assert e is est
+        np.testing.assert_array_equal(a, [-1.5, -2.5, -3.5])
+        np.testing.assert_array_equal(b, [0.0, 0.25, 0.5])
+    with pytest.raises(NotImplementedError):
+        svm.unwrap_calibrated(types.SimpleNamespace(estimator=est, calibrators=cals, method="isotonic"))
+    with pytest.raises(NotImplementedError):
+        svm.unwrap_calibrated(types.SimpleNamespace(foo=1))
+    with pytest.raises(NotImplementedError):
+        svm._check_classes(svm.MAX_CLASSES + 1)
+
+
+def test_context_creation_failure_raises_instead_of_deadlocking(monkeypatch):
+    """_lib.context() used to call check() -> load() while holding a non-reentrant lock: a failing rml_ctx_create hung the
+    process.  Without a GPU rml_ctx_create fails, which is exactly the case to exercise."""
+    import threading
+    import importlib
+    import torch
+    _lib = importlib.import_module("radar_ml_amd._lib")
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a HIP device")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    res = {}
+
+    def run():
+        try:
+            _lib.context(0)
+            res["r"] = "no error"
+        except _lib.RadarMLError as e:
+            res["r"] = str(e)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "context() dead-locked on a failing rml_ctx_create"
+    assert "rml_ctx_create failed" in res["r"]

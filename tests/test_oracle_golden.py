@@ -186,3 +186,28 @@ def test_reference_generated_data_fixture():
         for i, nm in enumerate(("xz", "yz", "xy")):
             got = O.pil_resize_bicubic(O.scale_unit_range(g[nm][b]), (80, 80))
             np.testing.assert_array_equal(got, g["dnn_inputs_80"][b, i])
+
+
+def test_multiclass_oracle_matches_sklearn():
+    """More classes than the reference's three (its label set is open, train.py:656-663): 5-class SVC and 6-class SGD
+    golden vectors of tests/golden/make_golden_multiclass.py."""
+    g = load_golden("svm_multiclass.npz")
+    C = len(g["svc_classes"])
+    sv = (g["svc_sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    X = g["svc_test_u8"].astype(np.float32) / np.float32(255.0)
+    dec = O.svm_decision_ovo(X, sv, g["svc_dual_coef"], g["svc_intercept"], g["svc_n_support"], float(g["svc_gamma"]), "rbf")
+    np.testing.assert_allclose(dec, g["svc_dec_ovo"], rtol=0, atol=1e-10)
+    ovr = O.ovr_decision_function(dec, C)
+    np.testing.assert_allclose(ovr, g["svc_dec_ovr"], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(g["svc_classes"][O.svm_vote_labels(dec, C)], g["svc_label_vote"])
+    proba = O.calibrated_proba(ovr, g["svc_calib_a"], g["svc_calib_b"])
+    np.testing.assert_allclose(proba, g["svc_proba"], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(g["svc_classes"][O.calibrated_labels(proba)], g["svc_label_calib"])
+    p = O.libsvm_pairwise_proba(dec, g["svc_probA"], g["svc_probB"], C)
+    np.testing.assert_allclose(p, g["svc_platt_proba"], rtol=0, atol=1e-12)
+    Xs = g["sgd_test_u8"].astype(np.float32) / np.float32(255.0)
+    d = O.linear_decision(Xs, g["sgd_coef"], g["sgd_intercept"])
+    np.testing.assert_allclose(d, g["sgd_dec"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(g["sgd_classes"][np.argmax(d, axis=1)], g["sgd_label"])
+    pr = O.calibrated_proba(d, g["sgd_calib_a"], g["sgd_calib_b"])
+    np.testing.assert_allclose(pr, g["sgd_proba"], rtol=0, atol=1e-13)

@@ -372,3 +372,35 @@ def test_misaligned_and_strided_volume_views(rml):
     got = rml.project(view, mode="max")
     for g, w in zip(got, O.project_max(view.float().cpu().numpy())):
         np.testing.assert_array_equal(g.cpu().numpy(), w)
+
+
+def test_slices_for_several_targets_per_frame(rml):
+    """The reference classifies EVERY target of one raw image (`for target in targets`, predict.py:93-119;
+    ground_truth_samples.py:366-440): ijk (B,T,3) gives B*T rows sliced from B volumes, none duplicated."""
+    import torch
+    B, T, X, Y, Z = 9, 3, 22, 31, 176
+    v, _ = O.synth_volumes(11, B, X, Y, Z)
+    rng = np.random.default_rng(3)
+    ijk = np.stack([rng.integers(-X, X, (B, T)), rng.integers(-Y, Y, (B, T)), rng.integers(-Z, Z, (B, T))], -1).astype(np.int32)
+    feat, q, isum, isq, flags = rml.process_volumes(v, mode="slice", ijk=ijk, scale=True, codes=True)
+    assert tuple(feat.shape) == (B * T, rml.feature_len(X, Y, Z))
+    fh = feat.cpu().numpy()
+    for b in range(B):
+        for t in range(T):
+            xz, yz, xy = O.project_slice(v[b], *ijk[b, t])
+            want = O.features_from_projections(xz[None], yz[None], xy[None], (True, True, True), True)[0]
+            np.testing.assert_array_equal(fh[b * T + t], want)
+    assert flags.cpu().numpy().all()
+    raw = rml.process_volumes(v, mode="slice", ijk=ijk).cpu().numpy()
+    np.testing.assert_array_equal(isum.cpu().numpy(), raw.astype(np.int64).sum(1))
+    # the derived targets of every frame (common.py:49-80), three per frame, through the same door
+    d3 = rml.derive_targets(v, 3)
+    auto = rml.process_volumes(v, mode="slice", num_targets=3).cpu().numpy()
+    np.testing.assert_array_equal(auto, rml.process_volumes(v, mode="slice", ijk=d3).cpu().numpy())
+    for bad in (np.array([[[X, 0, 0]] * T] * B), np.array([[[0, 0, -Z - 1]] * T] * B)):
+        with pytest.raises(IndexError):
+            rml.process_volumes(v, mode="slice", ijk=bad)
+    with pytest.raises(ValueError):
+        rml.process_volumes(v, mode="slice", ijk=ijk[:-1])                 # a short ijk used to be read out of bounds
+    with pytest.raises(IndexError):
+        rml.process_volumes(v, mode="slice", ijk=np.array([[0, Y, 0]] * B))

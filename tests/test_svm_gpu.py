@@ -346,3 +346,82 @@ def test_kernel_matrix_service(rml):
     Kt = km.against(X[:64]).cpu().numpy()
     np.testing.assert_array_equal(pre.predict(Kt), direct.predict(X[:64].astype(np.float64)))
     assert np.abs(pre.decision_function(Kt) - direct.decision_function(X[:64].astype(np.float64))).max() < 1e-3
+
+
+def test_more_than_four_classes_match_sklearn(rml):
+    """5-class SVC (ovo / ovr / vote / calibrated proba / libsvm Platt coupling) and 6-class SGD against scikit-learn
+    golden vectors (tests/golden/make_golden_multiclass.py); the reference's label set is open (train.py:656-663)."""
+    g = load_golden("svm_multiclass.npz")
+    sv = (g["svc_sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    X = g["svc_test_u8"].astype(np.float32) / np.float32(255.0)
+    for path in ("auto", "f64"):
+        svc = rml.GpuSVC(sv, g["svc_dual_coef"], g["svc_intercept"], g["svc_n_support"], float(g["svc_gamma"]), g["svc_classes"],
+                         calib_a=g["svc_calib_a"], calib_b=g["svc_calib_b"], probA=g["svc_probA"], probB=g["svc_probB"], path=path)
+        svc.decision_function_shape = "ovo"
+        assert np.abs(svc.decision_function(X) - g["svc_dec_ovo"]).max() <= TOL
+        svc.decision_function_shape = "ovr"
+        assert np.abs(svc.decision_function(X) - g["svc_dec_ovr"]).max() <= TOL
+        np.testing.assert_array_equal(svc.predict(X), g["svc_label_vote"])
+        cal = rml.GpuCalibratedClassifier(svc)
+        assert np.abs(cal.predict_proba(X) - g["svc_proba"]).max() <= TOL
+        np.testing.assert_array_equal(cal.predict(X), g["svc_label_calib"])
+        assert np.abs(svc.predict_proba(X) - g["svc_platt_proba"]).max() <= TOL
+    Xs = g["sgd_test_u8"].astype(np.float32) / np.float32(255.0)
+    lin = rml.GpuLinearClassifier(g["sgd_coef"], g["sgd_intercept"], g["sgd_classes"], g["sgd_calib_a"], g["sgd_calib_b"])
+    assert np.abs(lin.decision_function(Xs) - g["sgd_dec"]).max() <= 1e-9
+    np.testing.assert_array_equal(lin.predict(Xs), g["sgd_label"])
+    cal = rml.GpuCalibratedClassifier(lin)
+    assert np.abs(cal.predict_proba(Xs) - g["sgd_proba"]).max() <= 1e-9
+    np.testing.assert_array_equal(cal.predict(Xs), g["sgd_label_calib"])
+    with pytest.raises(NotImplementedError):
+        rml.GpuLinearClassifier(np.zeros((7, 4)), np.zeros(7), np.arange(7))
+
+
+def test_from_sklearn_reads_objects_pickled_by_sklearn_024(rml):
+    """A model written by the reference's own environment (scikit-learn 0.24, requirements.txt:57) carries
+    base_estimator / calibrators_ on the calibrated classifier and probA_ / probB_ on the SVC: from_sklearn must load it
+    through the documented drop-in edit.  The 0.24 layout is emulated by renaming the attributes of
+    objects fitted here."""
+    import types
+    import warnings
+    from sklearn import svm
+    from sklearn.calibration import CalibratedClassifierCV
+    g = load_golden("svm_small.npz")
+    m = svm_model_arrays(g)
+    rng = np.random.default_rng(5)
+    Xtr = rng.integers(0, 256, (240, 40)).astype(np.float32) / np.float32(255.0)
+    ytr = rng.integers(0, 3, 240)
+    clf = svm.SVC(kernel="rbf", C=10.0, gamma=0.05, probability=True, random_state=1).fit(Xtr, ytr)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cal = CalibratedClassifierCV(estimator=clf, cv="prefit").fit(Xtr[:90], ytr[:90])
+    want_p, want_l = cal.predict_proba(Xtr), cal.predict(Xtr)
+    # emulate the 0.24 pickle: private Platt arrays under their old public names, old calibrated-classifier layout
+    SVC = type("SVC", (), {})                                       # from_sklearn dispatches on the class NAME
+    CalibratedClassifierCV_ = type("CalibratedClassifierCV", (), {})
+    old_svc = SVC()
+    old_svc.__dict__.update({k: v for k, v in clf.__dict__.items() if k not in ("_probA", "_probB")})
+    old_svc.probA_, old_svc.probB_ = clf._probA, clf._probB
+    cc = cal.calibrated_classifiers_[0]
+    old_cc = types.SimpleNamespace(base_estimator=old_svc, calibrators_=cc.calibrators, classes=cc.classes, method="sigmoid")
+    old_cal = CalibratedClassifierCV_()
+    old_cal.calibrated_classifiers_, old_cal.classes_ = [old_cc], cal.classes_
+    gpu = rml.from_sklearn(old_cal)
+    assert np.abs(gpu.predict_proba(Xtr) - want_p).max() <= TOL
+    np.testing.assert_array_equal(gpu.predict(Xtr), want_l)
+    assert np.abs(gpu.estimator.predict_proba(Xtr) - clf.predict_proba(Xtr)).max() <= TOL      # libsvm Platt from probA_/probB_
+
+
+def test_pairwise_proba_is_asynchronous_and_needs_platt_coefficients(rml):
+    import ctypes as C
+    from radar_ml_amd import _lib
+    g = load_golden("svm_platt.npz")
+    sv = (g["c3_sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    bare = rml.GpuSVC(sv, g["c3_dual_coef"], g["c3_intercept"], g["c3_n_support"], float(g["gamma"]), g["c3_classes"])
+    lib = _lib.load()
+    dec = torch.zeros((4, 3), dtype=torch.float64, device="cuda")
+    out = torch.empty((4, 3), dtype=torch.float64, device="cuda")
+    rc = lib.rml_svm_pairwise_proba(bare._ctx, bare._h, _lib.ptr(dec), 4, _lib.ptr(out), _lib.stream_ptr())
+    assert rc == -5 and b"Platt" in lib.rml_last_error()            # RML_ERR_STATE
+    with pytest.raises(AttributeError):
+        bare.predict_proba(np.zeros((2, sv.shape[1]), np.float32))

@@ -1,0 +1,212 @@
+"""Measurement helpers of bench.py that are NOT part of the product path:
+
+* ``reference_libs_baseline``: the reference's own CPU path with the reference's own libraries -- NumPy ``max`` per axis
+  -> ``common.process_samples`` (``scipy.ndimage.zoom(p, 1.0)`` + concatenate + ``/255``: common.py:141-148, restated in
+  oracle/oracle_np.py) -> scikit-learn ``CalibratedClassifierCV(SVC(kernel='rbf')).predict`` (train.py:217,723-724;
+  predict.py:60) -- timed single-process as the reference runs it and on all host cores through a thread pool
+  (libsvm's predict releases the GIL).  SURVEY.md §8d.
+* ``measure_traffic``: HBM bytes per projection launch from this run's own PMC counters (``rocprofv3 --pmc FETCH_SIZE`` and
+  ``--pmc WRITE_SIZE`` in two separate kernel-trace-only passes over tools/pmc_child.py, 2x FETCH correction for gfx950 --
+  /opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Returns None when rocprofv3 is not usable.
+
+Only bench.py imports this module; it may use oracle/ (the product may not).
+"""
+import concurrent.futures
+import glob
+import json
+import os
+import shutil
+import sqlite3
+import statistics
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reference-library CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
+def build_sklearn_rbf_model(model, D):
+    """The object the reference pickles -- CalibratedClassifierCV(prefit, sigmoid) around SVC(kernel='rbf') -- carrying the
+    bench model's arrays.  (bench.py fits with kernel='precomputed' on the GPU Gram matrix; libsvm's predict needs an RBF
+    estimator, so a tiny RBF SVC is fitted for its private state and the fitted arrays are then replaced.)"""
+    import copy
+    import warnings
+    from sklearn import svm
+    from sklearn.calibration import CalibratedClassifierCV
+    classes = np.asarray(model["classes"])
+    C = len(classes)
+    sv = (model["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)     # train.py:667
+    M = sv.shape[0]
+    rng = np.random.default_rng(0)
+    Xd = rng.random((4 * C, D))
+    yd = np.repeat(classes, 4)
+    svc = svm.SVC(kernel="rbf", C=10.0, gamma=float(model["gamma"]), class_weight="balanced")
+    svc.fit(Xd, yd)
+    svc.support_vectors_ = np.ascontiguousarray(sv)
+    svc.support_ = np.arange(M, dtype=np.int32)
+    svc._n_support = np.asarray(model["n_support"], dtype=np.int32)
+    svc._dual_coef_ = np.ascontiguousarray(model["dual_coef"], dtype=np.float64)
+    svc.dual_coef_ = svc._dual_coef_
+    svc._intercept_ = np.ascontiguousarray(model["intercept"], dtype=np.float64)
+    svc.intercept_ = svc._intercept_
+    svc._gamma = float(model["gamma"])
+    svc._probA = np.empty(0, dtype=np.float64)
+    svc._probB = np.empty(0, dtype=np.float64)
+    svc.shape_fit_ = (M, D)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cal = CalibratedClassifierCV(estimator=svc, cv="prefit").fit(Xd, yd)
+    cc = cal.calibrated_classifiers_[0]
+    for c, (a, b) in enumerate(zip(model["calib_a"], model["calib_b"])):
+        cc.calibrators[c].a_ = float(a)
+        cc.calibrators[c].b_ = float(b)
+    return cal
+
+
+def _reference_path(frames, cal, O):
+    """frames (n,X,Y,Z) float32 -> labels, exactly the reference's sequence of library calls"""
+    samples = [(v.max(axis=1), v.max(axis=0), v.max(axis=2)) for v in frames]          # (xz, yz, xy), common.py:40
+    feats = O.process_samples(samples, scale=True)                                      # ndimage.zoom(p, 1.0) + concatenate + /255
+    return cal.predict(feats)
+
+
+def reference_libs_baseline(vh, model, gpu_label_idx, threads, budget_s=25.0, want_all=2048):
+    """Time the reference path on the host cores.  vh: host frames the GPU also classified; gpu_label_idx: their calibrated
+    label indices from the GPU.  Returns the ``cpu_baseline`` object of the bench line."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_np as O
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+    except Exception:                               # pragma: no cover
+        threadpool_limits = None
+    D = int(sum(a * b for a, b in ((vh.shape[1], vh.shape[3]), (vh.shape[2], vh.shape[3]), (vh.shape[1], vh.shape[2]))))
+    cal = build_sklearn_rbf_model(model, D)
+    classes = np.asarray(model["classes"])
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None       # BLAS/OpenMP pools pinned to 1: libsvm itself is serial
+    try:
+        # (i) single process, as the reference runs it
+        t0 = time.perf_counter()
+        lab = [_reference_path(vh[:4], cal, O)]
+        probe = (time.perf_counter() - t0) / 4
+        n1 = int(max(8, min(len(vh), (budget_s * 0.4) / max(probe, 1e-6))))
+        t0 = time.perf_counter()
+        lab1 = _reference_path(vh[:n1], cal, O)
+        dt1 = time.perf_counter() - t0
+        mism1 = int((lab1 != classes[gpu_label_idx[:n1]]).sum())
+        # (ii) all host cores: frames chunked over a thread pool (libsvm releases the GIL; NumPy max and SciPy zoom mostly hold it)
+        nall = int(min(len(vh), want_all))
+        chunk = 4
+        jobs = [(s, min(s + chunk, nall)) for s in range(0, nall, chunk)]
+        done = 0
+        mism2 = 0
+        t0 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as ex:
+            futs = {}
+            it = iter(jobs)
+            # keep the pool full, stop feeding it once the time budget is spent
+            for _ in range(threads * 2):
+                j = next(it, None)
+                if j is None:
+                    break
+                futs[ex.submit(_reference_path, vh[j[0]:j[1]], cal, O)] = j
+            while futs:
+                fin, _ = concurrent.futures.wait(futs, return_when=concurrent.futures.FIRST_COMPLETED)
+                for f in fin:
+                    s, e = futs.pop(f)
+                    mism2 += int((f.result() != classes[gpu_label_idx[s:e]]).sum())
+                    done += e - s
+                    if time.perf_counter() - t0 < budget_s * 0.6:
+                        j = next(it, None)
+                        if j is not None:
+                            futs[ex.submit(_reference_path, vh[j[0]:j[1]], cal, O)] = j
+        dt2 = time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    import sklearn, scipy
+    return {
+        "value": round(done / dt2, 2), "unit": "frames/s", "cores": int(threads), "kind": "reference-libs",
+        "sample": "%d of the same synthetic frames on %d threads in %.1f s (thread pool over 4-frame chunks): numpy max -> "
+                  "scipy.ndimage.zoom(p, 1.0) + concatenate + /255 (common.process_samples) -> sklearn %s "
+                  "CalibratedClassifierCV(SVC(rbf)).predict; scipy %s; BLAS/OpenMP pools limited to 1 thread (threadpoolctl)"
+                  % (done, threads, dt2, sklearn.__version__, scipy.__version__),
+        "single_process": {"value": round(n1 / dt1, 2), "unit": "frames/s", "cores": 1, "frames": n1, "seconds": round(dt1, 1),
+                           "label_mismatch_vs_gpu": mism1},
+        "label_mismatch_vs_gpu": mism2,
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the projection launches from this run's own counters
+# ------------------------------------------------------------------------------------------------------------------
+def _find_db(d):
+    hits = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True) + glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return hits[0] if hits else None
+
+
+def _read_counter(db, counter):
+    """[(kernel_name, value, duration_ns)] in dispatch order"""
+    c = sqlite3.connect(db)
+    cur = c.execute("select * from counters_collection limit 1")
+    cols = [d[0] for d in cur.description]
+    order = next((k for k in ("dispatch_id", "start", "start_timestamp", "timestamp", "id") if k in cols), None)
+    q = "select kernel_name, value, duration from counters_collection where counter_name=?" + (" order by %s" % order if order else "")
+    return c.execute(q, (counter,)).fetchall()
+
+
+def measure_traffic(configs, timeout_s=240):
+    """configs: [{"tag", "grid": [X,Y,Z], "frames", "u8": bool}].  Returns {tag: {"hbm_bytes", "fetch_bytes",
+    "write_bytes", "kernel", "dispatches"}} or None.  One child process per counter runs every configuration."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = os.path.join(ROOT, "tools", "pmc_child.py")
+    spec = json.dumps(configs)
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="rml_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "k", "--", sys.executable, child, spec]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except Exception:
+                return None
+            if r.returncode != 0:
+                return None
+            order = None
+            for line in r.stdout.decode(errors="replace").splitlines():
+                if line.startswith("PMC_CHILD_ORDER "):
+                    order = json.loads(line[len("PMC_CHILD_ORDER "):])
+            db = _find_db(out)
+            if db is None or order is None:
+                return None
+            rows = [x for x in _read_counter(db, counter) if "k_project" in x[0]]
+            # the child launches every configuration `reps` times in order and nothing else that is called k_project*
+            reps = order["reps"]
+            if len(rows) != reps * len(order["tags"]):
+                return None
+            for i, tag in enumerate(order["tags"]):
+                mine = rows[i * reps:(i + 1) * reps][1:]          # first launch of a configuration = warm-up
+                got.setdefault(tag, {})[counter] = statistics.mean(v for _, v, _ in mine)
+                got[tag]["kernel"] = mine[0][0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
+                got[tag]["dispatches"] = len(mine)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for tag, g in got.items():
+        if "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
+            return None
+        fetch = 2.0 * g["FETCH_SIZE"] * 1024.0      # KB as reported; gfx950 tallies 128-B requests at 64 B (guide, HBM section)
+        write = g["WRITE_SIZE"] * 1024.0
+        res[tag] = {"hbm_bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "kernel": g["kernel"],
+                    "dispatches": g["dispatches"],
+                    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, this run), 2x FETCH correction"}
+    return res
