@@ -39,6 +39,12 @@ def gemm_roofline(lib, ctx):
             "avg_chunk_ms": round(ms.value / nl.value, 4), "note": "algorithmic 2*D*M ops per frame; runs concurrently with the projection of the next chunk"}
 
 
+def _bench_support():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_support
+    return bench_support
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +62,11 @@ def parse():
     ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
     ap.add_argument("--no-dnn", action="store_true", help="skip the multi-view CNN inference row (BASELINE configs[3])")
     ap.add_argument("--dnn-frames", type=int, default=65536, help="frames per GPU of the CNN inference row")
-    ap.add_argument("--no-sgan", action="store_true", help="skip the SGAN discriminator train-step row (configs[4]; N = 1 only)")
+    ap.add_argument("--no-sgan", action="store_true", help="skip the SGAN discriminator train-step row (configs[4])")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that measure roofline.traffic (it is null then)")
+    ap.add_argument("--no-general", action="store_true", help="skip the general_rows row (non-integer data, float64 MFMA path)")
+    ap.add_argument("--general-frames", type=int, default=16384, help="frames per GPU of the general_rows row")
+    ap.add_argument("--dnn-parity", type=int, default=1024, help="frames of the CNN row checked against the NumPy restatement")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -206,13 +216,7 @@ def run_workload(a, env, grid, frames, primary):
         l8 = max(1, nl8.value)
         a8 = ms8.value / l8
         ach8 = (X * Y * Z + 16) * (nf8.value / l8) / (a8 * 1e-3) / 1e9 if a8 > 0 else 0.0
-        tr8 = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pj.get("grid") == [X, Y, Z] and abs(pj.get("u8_project_frames_per_launch", 0) - nf8.value / l8) < 1:
-                tr8 = pj.get("u8_project_hbm_bytes_per_launch")
-        except Exception:
-            tr8 = None
+        tr8 = None          # filled in by main() from this run's own PMC passes (tools/bench_support.measure_traffic)
         u8 = {"value": round(world * B * a.steps / dt8, 1), "unit": "frames/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3),
               "workload": "the same %d frames/GPU as uint8 volumes (1 byte per voxel)" % B,
               "identical_to_f32_ingest": same,
@@ -238,16 +242,9 @@ def run_workload(a, env, grid, frames, primary):
     avg_ms = ms.value / launches
     frames_per_launch = nf.value / launches
     achieved = alg_bytes_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            pj = json.load(open(pmc))
-            if pj.get("grid") == [X, Y, Z] and abs(pj.get("frames_per_launch", 0) - frames_per_launch) < 1:
-                traffic = pj.get("project_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    kname = "k_project_fast" if (Z // 4) & ((Z // 4) - 1) == 0 else "k_project_rowgroup"
+    traffic = None          # filled in by main() from this run's own PMC passes (tools/bench_support.measure_traffic)
+    zq = Z // 4
+    kname = "k_project_fast" if zq & (zq - 1) == 0 else ("k_project_wave" if 32 < zq <= 64 and Y <= 32 else "k_project_rowgroup")
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
@@ -314,14 +311,22 @@ def run_workload(a, env, grid, frames, primary):
                                           np.searchsorted(model["classes"], cls[:npar].cpu().numpy())).mean()),
     }
 
-    # ---- CPU baseline: the C port of the reference path on the host cores (rank 0, N = 1 only) ---
+    # ---- CPU baseline (rank 0, N = 1 only): the reference's own path with the reference's own libraries -- numpy max ->
+    #      scipy.ndimage.zoom(.,1.0) + concatenate (common.process_samples) -> sklearn CalibratedClassifierCV(SVC(rbf)).predict
+    #      (SURVEY.md §8d), single-process and on all host cores; the C port of the oracle is kept as a second figure ---
     cpu = None
     if not a.no_cpu and world == 1:
+        BS = _bench_support()
+        gl = out["label_calib"][:npar].cpu().numpy()
+        try:
+            cpu = BS.reference_libs_baseline(vh, model, gl, threads, budget_s=25.0 if primary else 12.0,
+                                             want_all=2048 if primary else 1024)
+        except Exception as e:                                  # sklearn internals moved: say so, keep the port
+            cpu = {"value": None, "unit": "frames/s", "cores": threads, "kind": "reference-libs", "error": repr(e)[:200]}
         ncpu = a.cpu_frames
         if ncpu <= 0:
-            # 2*D*M*3 flop/frame direct-difference; ~1.2 GFLOP/s/core scalar float64 -> aim at ~20 s (10 s secondary)
             est = 3.0 * D * M / (1.2e9 * threads)
-            ncpu = int(max(threads * 4, min(npar, (20.0 if primary else 10.0) / max(est, 1e-6))))
+            ncpu = int(max(threads * 4, min(npar, (6.0 if primary else 3.0) / max(est, 1e-6))))
         ncpu = min(ncpu, npar)
         t1 = time.perf_counter()
         cxz, cyz, cxy = OC.project_max(vh[:ncpu], threads=threads)
@@ -329,9 +334,9 @@ def run_workload(a, env, grid, frames, primary):
         OC.svm(cf, sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
                model["calib_a"], model["calib_b"], threads=threads)
         cdt = time.perf_counter() - t1
-        cpu = {"value": round(ncpu / cdt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": "%d of the same synthetic frames, oracle/oracle.c (max-projection + float64 libsvm loops, "
-                         "OpenMP over frames), %.1f s" % (ncpu, cdt)}
+        cpu["port"] = {"value": round(ncpu / cdt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+                       "sample": "%d of the same frames, oracle/oracle.c (max-projection + float64 libsvm loops, OpenMP over frames), "
+                                 "%.1f s" % (ncpu, cdt)}
 
     value = world * B * a.steps / dt
     res = {
@@ -349,6 +354,93 @@ def run_workload(a, env, grid, frames, primary):
     del V, out, svc
     torch.cuda.empty_cache()
     return res
+
+
+def run_general(a, env, grid, frames):
+    """The same step on data that is NOT on the integer code grid (what train.py:496-517 augmentation and a non-unit
+    proj_zoom, predict.py:109-116, produce, and what the reference's shipped generated_data pickles hold): volumes and
+    support vectors scaled off the grid, so RML_PATH_AUTO takes the float64-MFMA GEMM (v_mfma_f64_16x16x4_f64) on float32
+    rows.  MFMA-bound: 2*D*M flop per frame against the 78.6 TFLOP/s f64 matrix peak.  Parity vs the float64 C oracle."""
+    import torch
+    import torch.distributed as dist
+    rml, _lib, dev, rank, world = env["rml"], env["lib_mod"], env["dev"], env["rank"], env["world"]
+    X, Y, Z = grid
+    D = rml.feature_len(X, Y, Z)
+    obj = [None]
+    if rank == 0:
+        obj[0] = fit_model(rml, torch, X, Y, Z, a.train, a.gamma, a.seed, dev)
+    if world > 1:
+        dist.broadcast_object_list(obj, src=0)
+    model = obj[0]
+    off = np.float64(0.9990234375)                                  # 1 - 2^-10: every non-zero value leaves the code grid
+    sv = sv_f64(model) * off
+    svc = rml.GpuSVC(sv, model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], model["classes"],
+                     calib_a=model["calib_a"], calib_b=model["calib_b"])
+    assert not svc.exact
+    M = int(sv.shape[0])
+    B = int(frames)
+    V, _ = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 3, frame0=rank * B, device=dev)
+    V.mul_(float(off))
+    lib = _lib.load()
+    ctx = _lib.context(dev)
+    from radar_ml_amd import dist as rdist
+
+    def step():
+        o = svc.decide_volumes(V, mode="max", scale=True, want_proba=True)
+        if world > 1:
+            o["all_labels"] = rdist.gather_labels(o["label_calib"])
+        return o
+
+    for _ in range(max(1, a.warmup)):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    lib.rml_profile_enable(ctx, 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    nl, ms, ops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    lib.rml_profile_read_gemm(ctx, ctypes.byref(nl), ctypes.byref(ms), ctypes.byref(ops))
+    lib.rml_profile_enable(ctx, 0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as OC
+    npar = min(1024, B)
+    vh = V[:npar].cpu().numpy()
+    threads = len(os.sched_getaffinity(0))
+    xz, yz, xy = OC.project_max(vh, threads=threads)
+    fh = OC.features(xz, yz, xy, scale=True)
+    ref = OC.svm(fh, sv, model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
+                 model["calib_a"], model["calib_b"], threads=threads)
+    F64_PEAK = 78.6                                                 # MI355X f64 matrix peak, TFLOP/s (DESIGN.md §3.2)
+    ach = ops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    value = world * B * a.steps / dt
+    return {
+        "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 3), "dtype": "f32 rows, f64 MFMA + f64 epilogue",
+        "workload": "%d frames/GPU of %dx%dx%d f32, every value scaled by 1 - 2^-10 (off the integer grid), %d SVs off the grid "
+                    "as well: RML_PATH_AUTO -> float64 MFMA" % (B, X, Y, Z, M),
+        "roofline": {"bound": "mfma", "kernel": "k_svm_gemm<F64> + k_svm_finish", "achieved": round(ach, 2), "peak": F64_PEAK,
+                     "unit": "TFLOP/s", "frac": round(ach / F64_PEAK, 4), "launches": int(nl.value),
+                     "note": "in situ: 2*D*M flop per frame over the summed GEMM+finish time of every chunk"},
+        "mfma_frac_end_to_end": round(value / world * 2.0 * D * M / 1e12 / F64_PEAK, 4),
+        "parity": {"frames": int(npar),
+                   "label_vote_mismatch": int((out["label_vote"][:npar].cpu().numpy() != ref["label_vote"]).sum()),
+                   "label_calib_mismatch": int((out["label_calib"][:npar].cpu().numpy() != ref["label_calib"]).sum()),
+                   "dec_ovo_max_abs_err": float(np.abs(out["dec_ovo"][:npar].cpu().numpy() - ref["dec_ovo"]).max()),
+                   "proba_max_abs_err": float(np.abs(out["proba"][:npar].cpu().numpy() - ref["proba"]).max())},
+    }
 
 
 def run_dnn(a, env):
@@ -399,7 +491,7 @@ def run_dnn(a, env):
     # parity on a few frames: NumPy restatement of the whole chain (oracle projections, Pillow restatement, Keras layers)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_np as O
-    npar = 8
+    npar = int(min(max(8, a.dnn_parity), B))
     vh = V[:npar].cpu().numpy()
     planes = [[], [], []]
     for v in vh:
@@ -408,44 +500,98 @@ def run_dnn(a, env):
     convs, dense = model.keras_weights()
     want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
     got = res["f32"][1][:npar].float().cpu().numpy()
+    # roofline of the dominant kernel of this row, k_dnn_trunk (bf16 MFMA): timed with events on the stream it runs on
+    from radar_ml_amd import nn_common
+    nb = int(min(8192, B))
+    feat = rml.process_volumes(V[:nb], mode="max", scale=False)
+    xs = nn_common.preprocess_features(feat, (X, Y, Z), (80, 80), out_dtype="bfloat16")
+    for _ in range(3):
+        model.features_fused(*xs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        model.features_fused(*xs)
+    e1.record()
+    e1.synchronize()
+    trunk_ms = e0.elapsed_time(e1) / 10
+    conv_flop = 3 * 2.0 * (40 * 40 * 64 * 9 + 20 * 20 * 32 * 576)            # per frame: 3 branches x (conv1 + conv2), dnn.py:45-52
+    trunk_tf = conv_flop * nb / (trunk_ms * 1e-3) / 1e12
+    BF16_PEAK = 2500.0                                                         # MI355X_MICROARCH.md: dense bf16 MFMA
     out = {"metric": "radar frames/s (3D-proj->resize->CNN forward)", "unit": "frames/s", "dtype": "bf16 operands, f32 accumulate",
            "value": round(world * B * a.steps / res["f32"][0], 1), "ms_per_step": round(res["f32"][0] / a.steps * 1e3, 3),
            "value_uint8_volumes": round(world * B * a.steps / res["u8"][0], 1),
            "uint8_identical_labels": bool(torch.equal(res["u8"][1].argmax(1), res["f32"][1].argmax(1))),
            "config": {"workload": "configs[3]: %d frames/GPU of %dx%dx%d -> 3 x 80x80 -> multi-view CNN (2.52 M parameters, "
                                   "54.7 MFLOP/frame), random-init weights" % (B, X, Y, Z), "frames_per_gpu": B},
+           "roofline": {"bound": "mfma", "kernel": "k_dnn_trunk", "achieved": round(trunk_tf, 1), "peak": BF16_PEAK, "unit": "TFLOP/s",
+                        "frac": round(trunk_tf / BF16_PEAK, 4), "avg_launch_ms": round(trunk_ms, 4), "frames_per_launch": nb,
+                        "algorithmic_flop_per_frame": conv_flop, "traffic": None},
            "parity": {"frames": npar, "proba_max_abs_err_vs_float64_oracle": float(np.abs(got - want).max()),
-                      "label_mismatch": int((got.argmax(1) != want.argmax(1)).sum())}}
+                      "label_mismatch": int((got.argmax(1) != want.argmax(1)).sum()),
+                      "note": "parity unpinned by the reference (no weights, no TensorFlow here): random-init weights, "
+                              "bf16 GPU chain vs the float64 NumPy restatement of the same chain"}}
     return out
 
 
-def run_sgan(a, env):
-    """BASELINE configs[4] on one GPU: the SGAN discriminator/classifier train step (c_model + d_model(real) updates,
-    sgan.py:525-532) on 128x128 projections, PyTorch-ROCm (MIOpen convolutions), fp16 autocast with loss scaling."""
+def run_sgan(a, env, n=256, hw=128, steps=None):
+    """BASELINE configs[4]: the SGAN discriminator/classifier train step (c_model + d_model(real) updates, sgan.py:525-532) on
+    128x128 projections, fp16 autocast with loss scaling, MIOpen convolutions for layers 2-3 + csrc/bnact.hip for the rest.
+    Data parallel when N > 1: every rank trains on its own batch of ``n`` samples (weak scaling) and the gradients are
+    all-reduced once per update on one flat 7.4 MB bucket (RCCL over xGMI) between the HIP-graph replay of forward + backward
+    and the optimizer step.  Runs on the CPU too (gloo, no autocast, no graph): that is what tests/test_dist_cpu.py drives
+    with two ranks.  Returns the row on rank 0."""
     import importlib
     import torch
-    dev = env["dev"]
+    import torch.distributed as dist
+    dev, rank, world = env["dev"], env["rank"], env["world"]
+    on_gpu = torch.device(dev).type == "cuda"
     sgan = importlib.import_module("radar_ml_amd.sgan")
-    n = 256
-    d = sgan.define_discriminator(device=dev)
-    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16", ddp=False, use_graph=True)      # fwd+bwd replayed from HIP graphs
-    g = torch.Generator(device=dev).manual_seed(a.seed)
-    x = [torch.rand((n, 128, 128), device=dev, generator=g) * 2 - 1 for _ in range(3)]
+    torch.manual_seed(a.seed)                                                   # the same initial weights on every rank
+    d = sgan.define_discriminator((hw, hw, 1), (hw, hw, 1), (hw, hw, 1), device=dev)
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16" if on_gpu else None, use_graph=on_gpu)    # ddp: on when world > 1
+    g = torch.Generator(device=dev).manual_seed(a.seed + 17 * rank)             # every rank its own shard of the global batch
+    x = [torch.rand((n, hw, hw), device=dev, generator=g) * 2 - 1 for _ in range(3)]
     y = torch.randint(0, 3, (n,), device=dev, generator=g)
     yr = torch.full((n, 1), 0.9, device=dev)
-    for _ in range(6):
+    for _ in range(6 if on_gpu else 1):
         tr.train_on_batch_c(x, y)
         tr.train_on_batch_d(x, yr)
-    torch.cuda.synchronize(dev)
-    steps = max(30, a.steps)
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    steps = steps if steps is not None else max(30, a.steps)
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         lc, acc = tr.train_on_batch_c(x, y, sync=False)
         ld = tr.train_on_batch_d(x, yr, sync=False)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(2 * n / dt, 1), "unit": "samples/s",
-            "ms_per_step": round(dt * 1e3, 2), "batch": n, "dtype": "fp16 autocast (MIOpen convolutions, csrc/bnact.hip batch-norm/activation/pad), fp32 master weights",
+    fence()
+    dt = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    # replicas must still be identical after the timed updates (sum of |parameters| agrees to the last bit)
+    chk = torch.stack([p.detach().double().abs().sum() for p in d.parameters()]).sum().reshape(1)
+    same = True
+    if world > 1:
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        same = all(bool(torch.equal(b, both[0])) for b in both)
+    if rank != 0:
+        return None
+    return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(world * 2 * n / dt, 1), "unit": "samples/s",
+            "ms_per_step": round(dt * 1e3, 2), "batch_per_gpu": n, "global_batch": world * n, "n_gpus": world,
+            "parallelism": "data parallel x%d: one flat-bucket gradient all-reduce (%d parameters) per update"
+                           % (world, sum(p.numel() for p in d.parameters())) if world > 1 else "single GPU",
+            "replicas_identical": same, "hip_graph": bool(tr.use_graph),
+            "dtype": "fp16 autocast (MIOpen convolutions, csrc/bnact.hip batch-norm/activation/pad), fp32 master weights"
+                     if on_gpu else "float32 (CPU)",
             "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4)}
 
 
@@ -480,12 +626,55 @@ def main():
     if not a.no_walabot and grid != (22, 31, 176):
         wal = run_workload(a, env, (22, 31, 176), a.walabot_frames, primary=False)
 
+    # roofline.traffic: HBM bytes per projection launch from THIS run's counters (two rocprofv3 PMC passes over a child
+    # process that launches the same kernels on the same grids and frames per launch); null when that is not possible
+    if rank == 0 and world == 1 and not a.no_pmc:
+        cfgs = []
+        for tag, r in (("primary", res), ("walabot", wal)):
+            if r is None:
+                continue
+            g = r["config"]["grid"]
+            cfgs.append({"tag": tag + "_f32", "grid": g, "frames": int(r["roofline"]["frames_per_launch"]), "u8": False})
+            if r.get("uint8_ingest"):
+                cfgs.append({"tag": tag + "_u8", "grid": g, "frames": int(r["uint8_ingest"]["roofline"]["frames_per_launch"]), "u8": True})
+        tr = None
+        try:
+            torch.cuda.empty_cache()
+            tr = _bench_support().measure_traffic(cfgs)
+        except Exception:
+            tr = None
+        if tr:
+            for tag, r in (("primary", res), ("walabot", wal)):
+                if r is None:
+                    continue
+                t = tr.get(tag + "_f32")
+                if t:
+                    r["roofline"]["traffic"] = t["hbm_bytes"]
+                    r["roofline"]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "kernel", "source")}
+                t = tr.get(tag + "_u8")
+                if t and r.get("uint8_ingest"):
+                    r["uint8_ingest"]["roofline"]["traffic"] = t["hbm_bytes"]
+                    r["uint8_ingest"]["roofline"]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "kernel", "source")}
+
+    gen_row = None
+    if not a.no_general:
+        gen_row = {}
+        g1 = run_general(a, env, grid, a.general_frames)
+        if not a.no_walabot and grid != (22, 31, 176):
+            g2 = run_general(a, env, (22, 31, 176), a.general_frames * 2)
+        else:
+            g2 = None
+        if rank == 0:
+            gen_row = dict(g1)
+            if g2 is not None:
+                gen_row["walabot_grid"] = g2
+
     dnn_row = None
     if not a.no_dnn:
         dnn_row = run_dnn(a, env)
 
     sgan_row = None
-    if not a.no_sgan and world == 1:
+    if not a.no_sgan:
         try:
             sgan_row = run_sgan(a, env)
         except Exception as e:          # a library-side failure must not cost the headline line
@@ -504,6 +693,8 @@ def main():
         }
         if wal is not None:
             line["walabot_grid"] = wal
+        if gen_row:
+            line["general_rows"] = gen_row
         if dnn_row is not None:
             line["dnn_forward"] = dnn_row
         if sgan_row is not None:

@@ -125,19 +125,51 @@ class DiscriminatorTrainer:
 
     def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None, use_graph=False):
         """``use_graph``: capture forward + backward of each head in a HIP graph (torch.cuda.graphs) after three eager
-        warm-up steps and replay it afterwards; the optimizer and the loss scaler stay outside the graph.  Single GPU
-        only (ignored under DDP); inputs must keep their shapes.  With the fused layers the step is launch-bound on the
-        host side, which is what the graph removes."""
+        warm-up steps and replay it afterwards; the optimizer, the loss scaler and the gradient all-reduce stay outside
+        the graph.  Inputs must keep their shapes.  With the fused layers the step is launch-bound on the host side,
+        which is what the graph removes.
+
+        ``ddp``: data parallelism when torch.distributed is initialised with more than one rank (None = on).  The
+        replicas are kept in step the MI355X way: every parameter's ``.grad`` is a view into ONE flat float32 bucket
+        (1.86 M elements = 7.4 MB) that is all-reduced (RCCL over xGMI; gloo on CPU) once per update, after the
+        backward pass and before the loss-scaled optimizer step -- a single collective of a few tens of microseconds
+        instead of per-bucket hooks inside the backward, so forward + backward can still be replayed from a HIP graph.
+        ``ddp="torch"`` wraps the model in torch's DistributedDataParallel instead (no graph replay then).
+        BatchNorm statistics stay per replica (what Keras does per replica)."""
         import torch
         import torch.distributed as dist
         self.model = model
         self.device = next(model.parameters()).device
         self.net = model
-        use_ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 if ddp is None else ddp
-        if use_ddp:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if multi else 1
+        mode = ddp
+        if mode is None or mode is True:
+            mode = "flat" if multi else None
+        elif mode is False:
+            mode = None
+        if mode is not None and not multi:
+            mode = None
+        self.ddp_mode = mode
+        self._flat = None
+        if mode == "torch":
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.net = DDP(model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                            gradient_as_bucket_view=True)
+        elif mode == "flat":
+            with torch.no_grad():                       # identical replicas to start from (what DDP's constructor does)
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=0)
+            params = [p for p in model.parameters() if p.requires_grad]
+            self._flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
+            off = 0
+            for p in params:
+                if p.dtype != torch.float32:
+                    raise TypeError("flat gradient bucket: float32 master parameters expected")
+                p.grad = self._flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        elif mode is not None:
+            raise ValueError("ddp must be None, False, 'flat' or 'torch'")
         # Adam(lr=0.0002, beta_1=0.5), Keras epsilon 1e-7 (sgan.py:206,214); one fused update kernel on the GPU
         # (the per-parameter kernels of the default implementation were 8 % of the step)
         fused = self.device.type == "cuda"
@@ -145,8 +177,23 @@ class DiscriminatorTrainer:
         self.opt_d = torch.optim.Adam(model.parameters(), lr=lr, betas=(beta1, 0.999), eps=1e-7, fused=fused)
         self.amp_dtype = getattr(torch, amp_dtype) if (amp_dtype and self.device.type == "cuda") else None
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
-        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not use_ddp
+        self.use_graph = bool(use_graph) and self.device.type == "cuda" and mode != "torch"
         self._graphs = {}           # head -> dict(graph, static inputs / targets, loss, logits, eager_calls)
+
+    def _zero_grad(self, opt):
+        if self._flat is not None:
+            self._flat.zero_()          # the grads are views of the bucket: keep them, clear them in one kernel
+        else:
+            opt.zero_grad(set_to_none=not self.use_graph)
+
+    def _allreduce_grads(self):
+        """mean of the (loss-scaled) gradients over the replicas: one collective on the flat bucket.  An overflow on any
+        rank reaches every rank through the sum, so the loss scaler skips the step everywhere."""
+        if self._flat is None:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        self._flat.mul_(1.0 / self.world)
 
     def _graph_step(self, head, opt, make_loss, x, targets):
         """One update of ``head`` ('c' or 'd') through a captured graph.  ``targets``: tuple of tensors the loss needs
@@ -162,17 +209,18 @@ class DiscriminatorTrainer:
         if "graph" not in st:
             if st["eager"] < 3:                         # eager warm-up (MIOpen find, allocator, lazy initialisations)
                 st["eager"] += 1
-                opt.zero_grad(set_to_none=False)
+                self._zero_grad(opt)
                 with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
                     logits = self.net(*xs)
                 loss = make_loss(logits, *targets)
                 self.scaler.scale(loss).backward()
+                self._allreduce_grads()
                 self.scaler.step(opt)
                 self.scaler.update()
                 return loss.detach(), logits.detach()
             st["xs"] = [t.clone() for t in xs]
             st["targets"] = [t.clone() for t in targets]
-            opt.zero_grad(set_to_none=False)
+            self._zero_grad(opt)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -186,8 +234,9 @@ class DiscriminatorTrainer:
             dst.copy_(src)
         for dst, src in zip(st["targets"], targets):
             dst.copy_(src)
-        opt.zero_grad(set_to_none=False)
+        self._zero_grad(opt)
         st["graph"].replay()
+        self._allreduce_grads()
         self.scaler.step(opt)
         self.scaler.update()
         return st["loss"].detach(), st["logits"].detach()
@@ -198,7 +247,10 @@ class DiscriminatorTrainer:
     def _step(self, opt, loss_fn, x):
         import torch
         self.net.train()
-        opt.zero_grad(set_to_none=True)
+        if self._flat is not None:
+            self._zero_grad(opt)
+        else:
+            opt.zero_grad(set_to_none=True)
         xs = self._inputs(x)
         if self.amp_dtype is not None:
             with torch.autocast("cuda", dtype=self.amp_dtype):
@@ -207,6 +259,7 @@ class DiscriminatorTrainer:
             logits = self.net(*xs)
         loss = loss_fn(logits)
         self.scaler.scale(loss).backward()
+        self._allreduce_grads()
         self.scaler.step(opt)
         self.scaler.update()
         return loss.detach(), logits.detach()

@@ -71,3 +71,40 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     t = torch.arange(5)
     assert rd.gather_labels(t) is t                       # no process group: identity
+
+
+def _bench_sgan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import radar_ml_amd  # noqa: F401
+    import bench
+    a = types.SimpleNamespace(seed=1234, steps=2, warmup=1)
+    env = {"dev": torch.device("cpu"), "rank": rank, "world": world}
+    row = bench.run_sgan(a, env, n=6, hw=16, steps=2)          # bench.py's own multi-rank leg of configs[4], small and on CPU
+    q.put((rank, row))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_sgan_leg_runs_data_parallel_on_two_gloo_ranks():
+    """bench.py's run_sgan -- the N > 1 leg of BASELINE configs[4] -- under world size 2: rank 0 reports the whole-job rate,
+    the replicas end bit-identical after the all-reduced updates."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_sgan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    row = res[0]
+    assert row["n_gpus"] == 2 and row["global_batch"] == 12 and row["replicas_identical"] is True
+    assert row["value"] > 0 and "all-reduce" in row["parallelism"]

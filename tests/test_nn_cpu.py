@@ -82,7 +82,7 @@ def test_sgan_train_steps_reduce_loss(mods):
     assert p.shape == (48, 3) and abs(p.sum(1) - 1).max() < 1e-5
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, mode=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -90,9 +90,9 @@ def _ddp_worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import radar_ml_amd  # noqa
     sgan = importlib.import_module("radar_ml_amd.sgan")
-    torch.manual_seed(0)
+    torch.manual_seed(rank)                                    # DIFFERENT initial weights: the trainer must broadcast rank 0's
     d = sgan.Discriminator(((16, 16, 1),) * 3, 3)
-    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None)          # picks up DDP from the process group
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None, ddp=mode)     # None: picks the flat-bucket all-reduce up from the process group
     rng = np.random.default_rng(100 + rank)                    # each rank its own shard of the batch
     x = [rng.uniform(-1, 1, (8, 16, 16, 1)).astype(np.float32) for _ in range(3)]
     tr.train_on_batch_c(x, rng.integers(0, 3, 8))
@@ -103,19 +103,29 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sgan_ddp_gloo_two_ranks_keep_replicas_in_sync():
+def _run_two_ranks(mode):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    np.testing.assert_array_equal(res[0], res[1])      # all-reduced gradients -> identical replicas
+    return res
+
+
+def test_sgan_data_parallel_gloo_two_ranks_keep_replicas_in_sync():
+    """configs[4] with N > 1 on CPU (gloo, world size 2): the flat-bucket gradient all-reduce (the default) keeps the replicas
+    bit-identical from different initial weights, and lands where torch's DistributedDataParallel lands."""
+    flat = _run_two_ranks(None)
+    np.testing.assert_array_equal(flat[0], flat[1])     # all-reduced gradients -> identical replicas
+    ddp = _run_two_ranks("torch")
+    np.testing.assert_array_equal(ddp[0], ddp[1])
+    assert np.abs(flat[0] - ddp[0]).max() < 1e-6        # the same mean gradient, summed in a different order
 
 
 def test_dnn_module_matches_numpy_oracle(mods):
