@@ -250,9 +250,9 @@ def run_workload(a, env, grid, frames, primary):
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_frame": alg_bytes_frame}
 
-    # ---- the GEMM alone (one 8 192-frame chunk of code rows, nothing else on the GPU) ------------------------
+    # ---- the GEMM alone (one pipeline chunk of code rows, nothing else on the GPU) ------------------------
     if groof is not None:
-        nb = int(min(8192, B))
+        nb = int(min(frames_per_launch, B))
         _, q, isum, isq, flags = rml.process_volumes(V[:nb], mode="max", scale=True, codes=True)
         if q.stride(0) % 16 == 0:
             for _ in range(2):

@@ -77,6 +77,7 @@ struct GemmArgs {
     int kernel;
     double* partial; int64_t Npart;        // ST x Npart x PT
     double* kmat; int64_t ld_k; int64_t M; // KM instantiations: kernel values K[n][m] for m < M (rml_svm_kernel_matrix)
+    int64_t sv_rows;                       // SV rows that exist in memory (Mpad); the 256-row kernel clamps to it
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -385,6 +386,192 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// I8 hot path, large batches: 256 SVs x 256 samples per workgroup (512 threads, 8 waves as 2 x 4, wave tile 128 x 64 =
+// 4 x 2 MFMA tiles of 32x32, 128 accumulator registers), K-step 128 B per row, two 64 KiB stages.
+//
+// Why: what a CU can pull from L2 into LDS is ~28 B/clk (measured: exp_l2bw, and the per-K-step cycle counters of the
+// 128x128 kernel), and an i8 MFMA eats operand bytes twice as fast as bf16.  A 128x128 tile needs 64 B/clk per CU at full
+// matrix rate (ceiling 44 %: measured 40-43 %); 256x256 needs 32 B/clk (ceiling ~87 %).  Round 1 measured this tile at
+// 574 us vs 501 us on 8192 x 2560: that was the GRID, not the tile -- 32 x 10 = 320 workgroups on 256 CUs are two rounds
+// with the second one a quarter full.  It is therefore only used when the launch has enough tiles for >= ~2.5 rounds
+// (rml_project_svm sizes its chunks for it), and the 128x128 kernel keeps the small batches.
+// Sample tiles are paired: tile_exact[] is evaluated per 256 samples (k_tile_flags group = 2), partial slot 2*stile carries the
+// sum over the 256 SV rows and slot 2*stile+1 is zeroed.
+// ------------------------------------------------------------------------------------------
+constexpr int kBig = 256;
+constexpr int kBigStageBytes = 2 * kBig * kStepBytes;     // 64 KiB: [SV 256 x 128 B][samples 256 x 128 B]
+
+template <int PT>
+__global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves; wave tile = 128 SVs x 64 samples
+    // XCD-aware mapping, sample tiles fastest (see k_svm_gemm)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int FT2 = (a.FT + 1) >> 1;                   // 256-sample tiles (a.FT counts 128-sample tiles)
+    const int XPX = (FT2 + 7) >> 3;
+    const int ftile = (slot % XPX) * 8 + xcd;
+    const int stile = slot / XPX;
+    if (ftile >= FT2) return;
+    if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kBig;
+    const int64_t m0 = (int64_t)stile * kBig;
+
+    double* svw = reinterpret_cast<double*>(smem + 2 * kBigStageBytes);    // [256][1+PT]; rows past Mpad carry W = 0
+    for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        const bool in = m0 + m < a.Mpad;
+        svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
+    }
+
+    // staging: each operand image is 2048 16-byte slots = 32 wave-instructions of 1 KiB, 4 per wave
+    const uint8_t* gsv[4];
+    const uint8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        int64_t mr = m0 + r; mr = mr < a.sv_rows ? mr : a.sv_rows - 1;
+        gsv[q] = a.sv + mr * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * kBigStageBytes;
+        const int64_t ko = (int64_t)kt * kStepBytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gsv[q] + ko, base + (wave * 4 + q) * 1024);
+            glds16(gx[q] + ko, base + kBig * kStepBytes + (wave * 4 + q) * 1024);
+        }
+    };
+
+    int aoff[4], asw[4], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int ra = wr * 128 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        boff[t] = kBig * kStepBytes + rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    // Measured on this kernel (16 384 x 2 562 x 20 480, tools/kbench.py gemm): 0.96 ms as written; MFMAs removed 0.82 ms;
+    // staging removed 0.75 ms -- the L2 -> LDS delivery of a stage (~1.7 us per 64 KiB) and the matrix work of a step
+    // (~1.1 us) overlap only partly with ONE stage of look-ahead, and a third 64 KiB stage does not fit the 160 KiB of LDS.
+    // Tried and measured slower: issuing the stage in four slices between the MFMA groups (1.11 ms: it lands later), touching
+    // the lines of stage kt+3 with one dword load per lane to make the later DMA an L2 hit (0.99 ms).
+    stage(0, 0);
+    for (int kt = 0; kt < a.KT; ++kt) {
+        __syncthreads();                               // DMA of step kt landed and visible; other buffer free
+        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* sb = smem + (kt & 1) * kBigStageBytes;
+        // two fragment register sets: reads of sub-step kk+1 are in flight under the MFMAs of kk
+        v4i af[2][4], bf[2][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(sb + aoff[t] + ((chalf ^ asw[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(sb + boff[t] + ((chalf ^ bsw[t]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int ch = 2 * (kk + 1) + chalf;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(sb + aoff[t] + ((ch ^ asw[t]) << 4));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(sb + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#if RML_GEMM_ABL == 3
+                    acc[i][j][0] += af[kk & 1][i][0] ^ bf[kk & 1][j][1];
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+#endif
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- fused float64 epilogue: G[256 SVs][128 samples] int32 through LDS, one 128-sample half at a time ----
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    int* gl = reinterpret_cast<int*>(smem);
+    const int nl = tid & 127, h = tid >> 7;            // sample column of the half, SV quarter (64 rows)
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                               // tile images / previous exchange consumed
+        if ((wc >> 1) == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                        const int nn = (wc & 1) * 64 + j * 32 + (lane & 31);
+                        gl[ml * kTile + nn] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        const int64_t n = f0 + pass * kTile + nl;
+        const int64_t nc = n < a.N ? n : a.N - 1;
+        const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+        double S[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = 0.0;
+        const int* gcol = gl + nl;
+#pragma unroll 2
+        for (int mm = 0; mm < 64; ++mm) {
+            const int ml = h * 64 + mm;
+            const double* e = svw + ml * (1 + PT);
+            const double g = (double)gcol[ml * kTile];
+            double kv;
+            if (rbf) {
+                double d2 = xt + e[0] - 2.0 * g;
+                d2 = d2 > 0.0 ? d2 : 0.0;
+                kv = exp(-a.gs * d2);
+            } else {
+                kv = (g + xt + e[0]) * a.gs;
+            }
+#pragma unroll
+            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+        }
+        __syncthreads();                               // G half consumed: reuse its LDS for the exchange
+        double* x4 = reinterpret_cast<double*>(smem);  // [4][128][PT]
+#pragma unroll
+        for (int p = 0; p < PT; ++p) x4[(h * kTile + nl) * PT + p] = S[p];
+        __syncthreads();
+        if (h == 0 && n < a.N) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                double t = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
+                t += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
+                // two 128-row SV tiles per block: slot 2*stile carries the sum, 2*stile+1 (when it exists) is zero
+                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
+                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+            }
+        }
+    }
+}
+
 // ---- row preparation for callers that bring float32 feature rows -------------------------
 // One workgroup per row: zero-padded float copy (ld = Df), float64 norm, codes + statistics.
 __global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t ld, int64_t D, float code_scale,
@@ -433,21 +620,33 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t
 
 // tile_exact[ft] = policy(flags of the 128 rows of tile ft); *all_exact = AND over tiles.
 // One 128-thread block per tile, one row flag per thread.
-__global__ __launch_bounds__(128) void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force general,2 force i8*/,
-                                                    int model_exact, int32_t* tile_exact, int32_t* all_exact) {
-    const int ft = blockIdx.x;
+// group = sample tiles decided together (2 when the 256-sample GEMM kernel takes the exact tiles): blockDim = group * 128.
+__global__ __launch_bounds__(256) void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force general,2 force i8*/,
+                                                    int model_exact, int32_t* tile_exact, int32_t* all_exact, int group) {
+    const int ft0 = blockIdx.x * group;
     int e;
     if (policy == 1) e = 0;
     else if (policy == 2) e = 1;
     else {
-        const int64_t r = (int64_t)ft * kTile + threadIdx.x;
+        const int64_t r = (int64_t)ft0 * kTile + threadIdx.x;
         int mine = (model_exact && flags != nullptr) ? ((r < N) ? (flags[r] != 0) : 1) : 0;
         e = __syncthreads_and(mine);
     }
     if (threadIdx.x == 0) {
-        tile_exact[ft] = e;
+        for (int g = 0; g < group; ++g) if (ft0 + g < FT) tile_exact[ft0 + g] = e;
         if (!e && all_exact) atomicAnd(all_exact, 0);
     }
+}
+
+// does the 256x256 kernel take the exact tiles of a chunk of n rows against this model?  (enough tiles for ~2.5 rounds of
+// one workgroup per CU; RML_GEMM_BIG=0 turns it off, =1 forces it for every n >= 256)
+inline bool use_big_gemm(const rml_svm* m, int64_t n, int num_cu) {
+    const char* env = getenv("RML_GEMM_BIG");          // read per call: tests flip it
+    const int knob = env ? atoi(env) : -1;
+    if (knob == 0 || m->PT > 6) return false;
+    if (knob == 1) return n >= 256;
+    const int64_t wgs = ((n + kBig - 1) / kBig) * ((m->Mpad + kBig - 1) / kBig);
+    return wgs * 2 >= (int64_t)num_cu * 5;
 }
 
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
@@ -666,6 +865,51 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
+int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double);
+    const int FT2 = (ga.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
+    dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
+#define RML_BIG_CASE(PTV)                                                                                          \
+    case PTV: {                                                                                                    \
+        static bool attr_done = false;                                                                             \
+        if (!attr_done) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<PTV>),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            attr_done = true;                                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_svm_gemm_i8_256<PTV>), grid, block, lds, st, ga);                                    \
+    } break;
+    switch (m->PT) {
+        RML_BIG_CASE(1)
+        RML_BIG_CASE(3)
+        RML_BIG_CASE(6)
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 256x256 kernel");
+    }
+#undef RML_BIG_CASE
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// Rows per chunk of the chunked front doors.  With an exact model the chunk is sized for the 256x256 kernel: among
+// 8192..32768 rows the size whose tile count fills whole rounds of one workgroup per CU best (>= 2.5 rounds); otherwise
+// `fallback` (the round-1 choice for the 128x128 kernel).  RML_CHUNK overrides.
+int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu) {
+    static const int64_t env = [] { const char* e = getenv("RML_CHUNK"); int64_t v = e ? atoll(e) : 0; return v >= 128 ? round_up(v, kTile) : (int64_t)0; }();
+    int64_t ch = fallback;
+    if (env) ch = env;
+    else if (m->exact && use_big_gemm(m, 32768, num_cu)) {
+        const int64_t st2 = (m->Mpad + kBig - 1) / kBig;
+        double best = 0.0;
+        for (int64_t c = 8192; c <= 32768; c += 2048) {
+            const int64_t wgs = (c / kBig) * st2, rounds = (wgs + num_cu - 1) / num_cu;
+            if (wgs * 2 < (int64_t)num_cu * 5) continue;
+            const double eff = (double)wgs / (double)(rounds * num_cu);
+            if (eff > best + 0.02) { best = eff; ch = c; }       // a larger chunk has to earn its longer pipeline fill
+        }
+    }
+    return std::min<int64_t>(round_up(rows, kTile), ch);
+}
+
 // Workspace carved from the ctx block for one chunk of CH rows.
 struct ChunkWs {
     uint8_t* q; float* f32; int32_t* isum; int64_t* isq; double* nsq; int32_t* flags;
@@ -704,7 +948,7 @@ struct DecisionOut {
 };
 
 // GEMM(s) + finish for one chunk whose operands are already in place.
-int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
+int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
               bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
@@ -714,20 +958,24 @@ int run_chunk(const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t
     const bool run_gen = f32 && policy != RML_PATH_I8;
     const bool gen_f32 = (policy == RML_PATH_F32);
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
-    if (!tiles_done)
-        hipLaunchKernelGGL(k_tile_flags, dim3(FT), dim3(128), 0, st, flags, n, FT,
-                           run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr);
+    // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
+    const bool big = run_i8 && !kmat && use_big_gemm(m, n, ctx->num_cu);
+    if (!tiles_done) {
+        const int group = big ? 2 : 1;
+        hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, flags, n, FT,
+                           run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr, group);
+    }
     GemmArgs ga{};
     // all_exact_known: every row is on the code grid by construction (uint8 volumes): no tile predicate at all
     ga.N = n; ga.ST = ST; ga.FT = FT; ga.tile_exact = all_exact_known ? nullptr : w.tile_exact;
     ga.W = m->W; ga.Mpad = m->Mpad; ga.kernel = m->kernel; ga.partial = w.partial; ga.Npart = n;
-    ga.kmat = kmat; ga.ld_k = ld_k; ga.M = m->M;
+    ga.kmat = kmat; ga.ld_k = ld_k; ga.M = m->M; ga.sv_rows = m->Mpad;
     if (run_i8) {
         ga.sv = m->sv_q; ga.ld_sv = m->Dq; ga.x = q; ga.ld_x = ld_q; ga.KT = (int)(m->Kq / kStepBytes);
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
-        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st);
+        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st));
         if (rc) return rc;
     }
     if (run_gen) {
@@ -887,7 +1135,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (N == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rml_ctx_guard guard(ctx, st);           // shared workspace
-    const int64_t CH = std::min<int64_t>(round_up(N, kTile), 8192);
+    const int64_t CH = feat ? std::min<int64_t>(round_up(N, kTile), 8192) : pick_chunk(m, N, 8192, ctx->num_cu);
     const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
     ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32);
@@ -903,9 +1151,9 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
             hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)n), dim3(256), 0, st, feat + r0 * ld_feat, ld_feat, m->D,
                                (float)m->code_scale, w.f32, m->Df, w.nsq, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags);
             RML_HIP(hipGetLastError());
-            rc = run_chunk(m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st);
+            rc = run_chunk(ctx, m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st);
         } else {
-            rc = run_chunk(m, RML_PATH_I8, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
+            rc = run_chunk(ctx, m, RML_PATH_I8, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
                            nullptr, nullptr, w, out.at(r0, m->C, m->P), st);
         }
         if (rc) return rc;
@@ -939,7 +1187,7 @@ extern "C" int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, c
         hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)n), dim3(256), 0, st, feat + r0 * ld_feat, ld_feat, m->D,
                            (float)m->code_scale, w.f32, m->Df, w.nsq, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags);
         RML_HIP(hipGetLastError());
-        rc = run_chunk(m, path, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, none, st,
+        rc = run_chunk(ctx, m, path, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, none, st,
                        /*tiles_done=*/false, kmat + r0 * ld_k, ld_k);
         if (rc) return rc;
     }
@@ -971,9 +1219,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
     // frames per chunk: 8192, or 16384 for small frames (measured: 22x31x176 +2.5 % at 16384, 64x64x128 -2 % (f32) / -10 %
     // (uint8); 32768 is slower everywhere); RML_CHUNK overrides
-    static const int64_t kChunkEnv = [] { const char* e = getenv("RML_CHUNK"); int64_t v = e ? atoll(e) : 0; return v >= 128 ? round_up(v, kTile) : (int64_t)0; }();
-    const int64_t kChunk = kChunkEnv ? kChunkEnv : ((int64_t)X * Y * Z <= 200000 ? 16384 : 8192);
-    const int64_t CH = std::min<int64_t>(round_up(B, kTile), kChunk);
+    const int64_t CH = grid_ok ? pick_chunk(m, B, (int64_t)X * Y * Z <= 200000 ? 16384 : 8192, ctx->num_cu)
+                               : std::min<int64_t>(round_up(B, kTile), 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
@@ -1020,7 +1267,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             RML_HIP(hipEventRecord(ev_proj[c & 1], st));
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
             rml_prof_mark_gemm(ctx, aux);
-            rc = run_chunk(m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
+            rc = run_chunk(ctx, m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
                            /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true);
             rml_prof_mark_gemm(ctx, aux);
             if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
@@ -1036,7 +1283,9 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            hipLaunchKernelGGL(k_tile_flags, dim3(FT), dim3(128), 0, st, w.flags, n, FT, 0, 1, w.tile_exact, w.all_exact);
+            const int group = use_big_gemm(m, n, ctx->num_cu) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
+                               w.all_exact, group);
         }
         // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
         ProjOut of{};
@@ -1057,7 +1306,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
         rml_prof_mark_gemm(ctx, aux);
-        rc = run_chunk(m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
+        rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;

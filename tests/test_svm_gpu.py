@@ -425,3 +425,44 @@ def test_pairwise_proba_is_asynchronous_and_needs_platt_coefficients(rml):
     assert rc == -5 and b"Platt" in lib.rml_last_error()            # RML_ERR_STATE
     with pytest.raises(AttributeError):
         bare.predict_proba(np.zeros((2, sv.shape[1]), np.float32))
+
+
+@pytest.mark.parametrize("name", ["svm_small.npz", "svm_walabot.npz", "svm_small_linear.npz", "svm_small_binary.npz"])
+def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
+    """k_svm_gemm_i8_256 (256 SVs x 256 samples per workgroup, L2 touch-prefetch) is what large batches run on; forced
+    here (RML_GEMM_BIG=1) on ragged batches: a row count that is no multiple of 256, an SV count that is no multiple of
+    256, and -- through the float rows -- sample tiles that are NOT on the code grid, which must fall to the float64
+    kernel pair-wise (tile flags are decided per 256 samples then)."""
+    g = load_golden(name)
+    svc, m = _model(rml, g)
+    X0 = _test_rows(g, name)
+    rng = np.random.default_rng(7)
+    X = X0[rng.integers(0, len(X0), 1100)]
+    X[300:420] *= np.float32(0.9990234375)             # rows 300..419 leave the code grid: tiles 2,3 (128-row units) -> pair 1
+    C = len(m["classes"])
+    want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
+    outs = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("RML_GEMM_BIG", big)
+        svc.decision_function_shape = "ovo"
+        got = svc.decision_function(X)
+        got = got.reshape(len(X), -1)
+        ref = want if C > 2 else -want
+        assert np.abs(got - ref).max() <= _tol(m, ref), big
+        outs[big] = (got, svc.predict(X), rml.GpuCalibratedClassifier(svc).predict_proba(X))
+    np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
+    # exact tiles give the same integers on both kernels; only the order of the float64 sums over SV tiles differs
+    assert np.abs(outs["0"][0] - outs["1"][0]).max() <= 1e-9 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(outs["0"][2] - outs["1"][2]).max() <= 1e-9
+    # and on code rows straight from volumes (the fused pipeline's operand), labels identical between the kernels
+    if name == "svm_walabot.npz":
+        import torch
+        vol = torch.from_numpy(np.tile(g["test_vol_u8"], (12, 1, 1, 1))[:700].astype(np.float32)).cuda()
+        res = {}
+        for big in ("0", "1"):
+            monkeypatch.setenv("RML_GEMM_BIG", big)
+            o = svc.decide_volumes(vol, mode="max", scale=True, want_proba=True)
+            res[big] = {k: v.cpu().numpy() for k, v in o.items()}
+        for k in ("label_vote", "label_calib"):
+            np.testing.assert_array_equal(res["0"][k], res["1"][k])
+        assert np.abs(res["0"]["dec_ovo"] - res["1"]["dec_ovo"]).max() <= 1e-9

@@ -30,7 +30,7 @@ def timeit(torch, fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["proj", "svm", "copy"])
+    ap.add_argument("what", choices=["proj", "svm", "copy", "gemm"])
     ap.add_argument("--grid", default="64x64x128")
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
@@ -60,6 +60,31 @@ def main():
     if a.u8:
         V = V.to(torch.uint8)
         esz = 1
+    if a.what == "gemm":
+        # the exact-integer GEMM + finish alone, on code rows (the operand the fused pipeline hands it)
+        M = a.svs
+        Bm = max(B, M)
+        Vm, _ = rml.synth_volumes(Bm, X, Y, Z, seed=1)
+        _, q, isum, isq, flags = rml.process_volumes(Vm, mode="max", scale=True, codes=True)
+        del Vm
+        svq = (q[:M, :D] ^ 0x80).cpu().numpy()
+        sv = (svq.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+        ns = np.array([M // 3, M // 3, M - 2 * (M // 3)], dtype=np.int32)
+        rng = np.random.default_rng(0)
+        svc = rml.GpuSVC(sv, rng.uniform(-10, 10, (2, M)), np.array([0.1, -0.2, 0.3]), ns, 0.01, np.arange(3), calib_a=-np.ones(3), calib_b=np.zeros(3))
+        ld = svc_ld = None
+        # the model's code-row stride (odd multiple of 128 B)
+        kq = (D + 127) // 128 * 128
+        ldq = kq if (kq // 128) % 2 else kq + 128
+        qq = torch.zeros((B, ldq), dtype=torch.uint8, device=dev)
+        qq[:, :q.shape[1]] = q[:B]
+        qq[:, D:] = 0
+        fn = lambda: svc.decide_codes(qq, isum[:B], isq[:B], flags[:B], want_proba=True)
+        med, mn, mean = timeit(torch, fn, a.iters)
+        ops = 2.0 * B * M * D
+        print(json.dumps({"what": "exact GEMM + finish on code rows", "N": B, "M": M, "D": D, "ms_med": round(med, 4), "ms_min": round(mn, 4),
+                          "T_op_s": round(ops / med / 1e9, 1), "frac_of_3944": round(ops / med / 1e9 / 3944, 4)}))
+        return
     if a.what == "proj":
         feat = torch.empty((B, D), dtype=torch.float32, device=dev)
         res = []
