@@ -69,7 +69,7 @@ struct Emitter {
     const ProjParams& a;
     int64_t b;
     int32_t isum = 0;
-    int64_t isq = 0;
+    uint32_t isq = 0;       // per THREAD: < 66 000 codes of <= 255^2 each (the launchers keep a thread's share far below that)
     int ok = 1;
     double nsq = 0.0;
     bool want_stats;
@@ -87,7 +87,7 @@ struct Emitter {
         ok &= good ? 1 : 0;
         c = good ? c : 0;
         isum += c;
-        isq += (int64_t)(c * c);
+        isq += (uint32_t)(c * c);
         return (uint32_t)(c ^ 0x80);
     }
     // already-decided code (rml_quantize_rows)
@@ -95,7 +95,7 @@ struct Emitter {
         ok &= good ? 1 : 0;
         c = good ? c : 0;
         isum += c;
-        isq += (int64_t)(c * c);
+        isq += (uint32_t)(c * c);
         if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)(c ^ 0x80);
     }
     __device__ __forceinline__ void put1(int pl, int64_t idx, float v) {
@@ -472,6 +472,25 @@ template <int J> __device__ __forceinline__ float park_lane(float acc, float uni
     return acc;
 }
 
+// max without the v_max_f32 x,x "canonicalise" copy hipcc puts in front of every fmaxf of a loaded value (IEEE mode: it
+// would quiet a signalling NaN; v_max_f32 itself already returns the other operand for ANY NaN, which is the documented NaN
+// policy of the max-projection).  4 VALU less per row of the streaming loop.
+template <int MODE> __device__ __forceinline__ float op_raw(float a, float b) {
+#ifndef RML_NO_RAWMAX
+    if constexpr (MODE == RML_MODE_MAX) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    } else
+#endif
+    {
+        return Op<MODE>::f(a, b);
+    }
+}
+template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b) {
+    return make_float4(op_raw<MODE>(a.x, b.x), op_raw<MODE>(a.y, b.y), op_raw<MODE>(a.z, b.z), op_raw<MODE>(a.w, b.w));
+}
+
 template <typename VT, int MODE, int NY, int G, bool PRED>
 __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_project_wave(ProjParams a) {
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
@@ -493,7 +512,11 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
     const float id = Op<MODE>::ident();
     const float4 id4 = make_float4(id, id, id, id);
 
-    // load cursor: one group ahead of the reduction
+    // load cursor: one group ahead of the reduction.  Frames are assigned statically (wave w: frames w, w + #waves, ...).
+    // Dynamic assignment through an atomic ticket per frame was tried for the co-running case (a workgroup that starts late
+    // behind a GEMM workgroup delays the whole persistent grid): reading the ticket back costs a full drain of the loads in
+    // flight once per frame when the compiler schedules it (s_waitcnt vmcnt(0) behind the atomic), and an asynchronous
+    // inline-asm ticket cannot be made safe against register copies -- dropped.
     int64_t lf = cf;
     int li = 0;
     const QT* __restrict__ lV = Vall + lf * fq;
@@ -553,12 +576,12 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
                     if constexpr (j < NY) {
                         float4 v = buf[u & 1][r];
                         if constexpr (MODE == RML_MODE_SUM) v = (act && j < Y) ? v : id4;
-                        yz[j] = op4<MODE>(yz[j], v);
+                        yz[j] = op4_raw<MODE>(yz[j], v);
                         // pin the update here: yz is only "needed" at the loop back-edge, and instruction selection would
                         // otherwise place all NY updates there and keep every loaded row alive for the whole trip
                         asm volatile("" : "+v"(yz[j].x), "+v"(yz[j].y), "+v"(yz[j].z), "+v"(yz[j].w));
-                        xz = op4<MODE>(xz, v);
-                        xyl[j * kXyStride + lane] = Op<MODE>::f(Op<MODE>::f(v.x, v.y), Op<MODE>::f(v.z, v.w));
+                        xz = op4_raw<MODE>(xz, v);
+                        xyl[j * kXyStride + lane] = op_raw<MODE>(op_raw<MODE>(v.x, v.y), op_raw<MODE>(v.z, v.w));
                     }
                 });
                 // materialise xz here: its only use sits in a lane-conditional block and hipcc would sink the whole reduction
@@ -609,12 +632,28 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
 
 template <typename VT, int MODE, int NY, int G>
 void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
-    constexpr int per_cu = (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2;
+    constexpr int per_cu_max = (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2;
+    const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
+    const int per_cu = env && atoi(env) >= 1 && atoi(env) <= per_cu_max ? atoi(env) : (pp.o.share_cu ? 1 : per_cu_max);
     const int64_t want = (pp.B + 3) / 4;
     const int64_t cap = (int64_t)num_cu * per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
-    if (pp.o.skip_if_set) hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, 0, st, pp);
-    else hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, false>), grid, block, 0, st, pp);
+    // beside a GEMM: the request is padded past half of the CU's LDS, so that the dispatcher cannot put two of these
+    // persistent workgroups on one CU (and none on another) while GEMM workgroups (72.7 KB) still fit next to one
+    size_t pad = 0;
+    if (pp.o.share_cu && per_cu == 1) {
+        const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
+        pad = mine < 82 * 1024 ? 82 * 1024 - mine : 0;
+    }
+    if (pp.o.skip_if_set) {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_wave<VT, MODE, NY, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, pad, st, pp);
+    } else {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_wave<VT, MODE, NY, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+        hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, false>), grid, block, pad, st, pp);
+    }
 }
 
 // returns true when the wave-per-frame kernel took the launch
@@ -625,7 +664,8 @@ bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
     const int knob = env ? atoi(env) : 1;
     if (knob == 0 || pp.ZQ <= 32 || pp.ZQ > 64 || pp.Y > 32) return false;
     const int Y = pp.Y;
-    const bool quarter = knob == 2 || (pp.X & 1);       // whole-plane buffers need an even number of planes
+    // whole-plane buffers need an even number of planes; beside a GEMM the quarter-plane variant (206 VGPRs) leaves it room
+    const bool quarter = knob == 2 || (pp.X & 1) || pp.o.share_cu;
 #define RML_WAVE_CASE(NYV)                                                                     \
     { if (quarter) launch_wave<VT, MODE, NYV, (NYV + 3) / 4>(pp, num_cu, st);                 \
       else launch_wave<VT, MODE, NYV, NYV>(pp, num_cu, st); return true; }
@@ -949,6 +989,11 @@ __global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const fl
     }
 }
 
+bool wave_kernel_shape(int ZQ, int Y) {
+    const char* env = getenv("RML_WAVEFRAME");
+    return !(env && atoi(env) == 0) && ZQ > 32 && ZQ <= 64 && Y <= 32;
+}
+
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 template <typename VT, int MODE, int LPR, int NM, bool FULL>
@@ -1055,6 +1100,13 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
     return RML_OK;
 }
 }  // namespace
+
+bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z) {
+    (void)X;
+    if (mode != RML_MODE_MAX && mode != RML_MODE_SUM) return false;
+    if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX && Z % 16 == 0) return false;      // the byte-native kernel takes those
+    return Z % 4 == 0 && wave_kernel_shape(Z / 4, Y);
+}
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame) {

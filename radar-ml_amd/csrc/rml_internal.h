@@ -106,7 +106,15 @@ struct ProjOut {
     double* row_nsq;
     // predication: the whole launch is a no-op when *skip_if_set != 0 (device flag)
     const int32_t* skip_if_set;
+    // set by the fused pipeline: an SVM GEMM runs concurrently on another stream, so a persistent projection kernel
+    // should leave every CU the registers / LDS for one of its workgroups (k_project_wave: quarter-plane buffers, one
+    // workgroup per CU) -- measured +5 % end to end on the Walabot grid against filling the CUs with projection waves
+    int share_cu;
 };
+
+// true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then
+// pairs it with the 128x128 GEMM, whose workgroups fit beside it on a CU)
+bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z);
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);

@@ -893,8 +893,14 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
 // Rows per chunk of the chunked front doors.  With an exact model the chunk is sized for the 256x256 kernel: among
 // 8192..32768 rows the size whose tile count fills whole rounds of one workgroup per CU best (>= 2.5 rounds); otherwise
 // `fallback` (the round-1 choice for the 128x128 kernel).  RML_CHUNK overrides.
+int64_t pick_chunk_env(int64_t fallback) {
+    const char* e = getenv("RML_CHUNK");
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 128 ? round_up(v, kTile) : fallback;
+}
+
 int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu) {
-    static const int64_t env = [] { const char* e = getenv("RML_CHUNK"); int64_t v = e ? atoll(e) : 0; return v >= 128 ? round_up(v, kTile) : (int64_t)0; }();
+    const int64_t env = pick_chunk_env(0);
     int64_t ch = fallback;
     if (env) ch = env;
     else if (m->exact && use_big_gemm(m, 32768, num_cu)) {
@@ -950,7 +956,7 @@ struct DecisionOut {
 // GEMM(s) + finish for one chunk whose operands are already in place.
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
-              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false) {
+              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -959,7 +965,7 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
     const bool gen_f32 = (policy == RML_PATH_F32);
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
-    const bool big = run_i8 && !kmat && use_big_gemm(m, n, ctx->num_cu);
+    const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, ctx->num_cu);
     if (!tiles_done) {
         const int group = big ? 2 : 1;
         hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, flags, n, FT,
@@ -1219,8 +1225,13 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
     // frames per chunk: 8192, or 16384 for small frames (measured: 22x31x176 +2.5 % at 16384, 64x64x128 -2 % (f32) / -10 %
     // (uint8); 32768 is slower everywhere); RML_CHUNK overrides
-    const int64_t CH = grid_ok ? pick_chunk(m, B, (int64_t)X * Y * Z <= 200000 ? 16384 : 8192, ctx->num_cu)
-                               : std::min<int64_t>(round_up(B, kTile), 8192);
+    // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups
+    // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
+    // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
+    const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z);
+    const int64_t small_chunk = (int64_t)X * Y * Z <= 200000 ? 16384 : 8192;
+    const int64_t CH = (grid_ok && !wave_proj) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
+                                               : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
@@ -1252,6 +1263,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
+        o.share_cu = 1;
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // uint8 volumes are on the code grid by construction: one projection pass (codes + statistics), the exact GEMM on
@@ -1268,7 +1280,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
             rml_prof_mark_gemm(ctx, aux);
             rc = run_chunk(ctx, m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
-                           /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true);
+                           /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true, /*allow_big=*/!wave_proj);
             rml_prof_mark_gemm(ctx, aux);
             if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
             if (rc) return rc;
@@ -1283,7 +1295,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            const int group = use_big_gemm(m, n, ctx->num_cu) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            const int group = (!wave_proj && use_big_gemm(m, n, ctx->num_cu)) ? 2 : 1;      // the same decision run_chunk takes for this chunk
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
@@ -1297,6 +1309,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             }
         of.sel = mask & RML_MASK_ALL;
         of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
+        of.share_cu = 1;
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
         if (!grid_ok) rml_prof_mark(ctx, st);
@@ -1307,7 +1320,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
-                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok);
+                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!wave_proj);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
