@@ -191,3 +191,75 @@ def test_gpu_only_entry_points_fail_loudly_without_a_gpu(mods):
         rml.KernelMatrix(np.zeros((4, 8)), gamma=0.1)
     with pytest.raises(rml.RadarMLError):
         rml.process_volumes(np.zeros((1, 4, 4, 8), np.uint8))
+
+
+def test_keras_semantics_known_answers_derived_by_hand(mods):
+    """Known answers that need no TensorFlow: derived by hand from the TF/Keras definitions cited in SURVEY.md §7.
+
+    TF padding='same', stride s, kernel k on size n: out = ceil(n/s); total pad = max((out-1)*s + k - n, 0);
+    pad_before = total // 2, pad_after = total - pad_before.  For n = 4, k = 3, s = 2: out = 2, total = 1 -> (0, 1): the zero
+    row/column goes to the BOTTOM/RIGHT.  An all-ones 4x4 image through an all-ones 3x3 kernel then gives
+        [[9, 6], [6, 4]]        (window rows/cols {0,1,2} and {2,3,pad})
+    whereas symmetric padding 1 (PyTorch's padding=1) would give [[4, 6], [6, 9]].  For n = 5: out = 3, total = 2 -> (1, 1):
+        [[4, 6, 4], [6, 9, 6], [4, 6, 4]].
+    Keras Flatten on channels_last (N,H,W,C) enumerates (h, w, c) with c fastest."""
+    _, sgan, nc = mods
+    conv = nc.make_same_conv(1, 1, 3, 2)
+    with torch.no_grad():
+        conv.conv.weight.fill_(1.0); conv.conv.bias.zero_()
+        np.testing.assert_array_equal(conv(torch.ones(1, 1, 4, 4))[0, 0].numpy(), [[9, 6], [6, 4]])
+        np.testing.assert_array_equal(conv(torch.ones(1, 1, 5, 5))[0, 0].numpy(), [[4, 6, 4], [6, 9, 6], [4, 6, 4]])
+        # a one-hot image: tap (ky, kx) of output (r, c) reads input (2r + ky, 2c + kx) -- no shift from a top/left pad
+        w = torch.arange(9, dtype=torch.float32).reshape(1, 1, 3, 3)
+        conv.conv.weight.copy_(w)
+        x = torch.zeros(1, 1, 6, 6); x[0, 0, 3, 4] = 1.0
+        y = conv(x)[0, 0]
+        want = torch.zeros(3, 3)
+        for r in range(3):
+            for c in range(3):
+                ky, kx = 3 - 2 * r, 4 - 2 * c
+                if 0 <= ky < 3 and 0 <= kx < 3:
+                    want[r, c] = w[0, 0, ky, kx]
+        np.testing.assert_array_equal(y.numpy(), want.numpy())
+    t = torch.zeros(1, 2, 2, 2)
+    for c in range(2):
+        for h in range(2):
+            for w_ in range(2):
+                t[0, c, h, w_] = 100 * h + 10 * w_ + c
+    np.testing.assert_array_equal(nc.flatten_nhwc(t)[0].numpy(), [0, 1, 10, 11, 100, 101, 110, 111])
+    # LeakyReLU(0.2), BatchNorm(momentum 0.99 -> torch 0.01, eps 1e-3), Adam(2e-4, beta1 0.5, eps 1e-7): sgan.py:137-158, 206
+    d = sgan.Discriminator(((16, 16, 1),) * 3, 3)
+    bns = [m for m in d.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d))]
+    assert len(bns) == 11 and all(abs(b.momentum - 0.01) < 1e-12 and abs(b.eps - 1e-3) < 1e-12 for b in bns)
+    assert all(abs(m.negative_slope - 0.2) < 1e-12 for m in d.modules() if isinstance(m, torch.nn.LeakyReLU))
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None, ddp=False)
+    for opt in (tr.opt_c, tr.opt_d):
+        g = opt.param_groups[0]
+        assert g["lr"] == 2e-4 and g["betas"] == (0.5, 0.999) and g["eps"] == 1e-7
+
+
+def test_parameter_counts_match_the_model_summaries_exactly(mods):
+    """images/dnn_model.png, images/sgan_d_model.png / sgan_c_model.png (layer shapes) -> Keras parameter counts, derived in
+    SURVEY.md §8 a-9 / a-10.  Keras counts BatchNorm's moving mean / variance as (non-trainable) parameters: in PyTorch they
+    are buffers."""
+    dnn, sgan, _ = mods
+    m = dnn.define_classifier(device="cpu")
+    per_branch = (3 * 3 * 1 * 64 + 64) + (3 * 3 * 64 * 32 + 32)
+    assert per_branch == 640 + 18464
+    assert sum(p.numel() for p in m.parameters()) == 3 * per_branch + (38400 * 64 + 64) + (64 * 64 + 64) + (64 * 3 + 3) == 2519331
+    shapes = [tuple(p.shape) for p in m.branches[0].parameters()]
+    assert shapes == [(64, 1, 3, 3), (64,), (32, 64, 3, 3), (32,)]
+    d = sgan.define_discriminator(device="cpu")
+    conv_bn = lambda cin, cout: (9 * cin * cout + cout) + 4 * cout          # kernel + bias + (gamma, beta, mean, var)
+    branch = conv_bn(1, 128) + conv_bn(128, 64) + conv_bn(64, 32)
+    assert branch == 94432
+    keras_total = 3 * branch + (24576 * 64 + 64) + 4 * 64 + (64 * 64 + 64) + 4 * 64 + (64 * 3 + 3)
+    assert keras_total == 1861091
+    n_param = sum(p.numel() for p in d.parameters())
+    n_stat = sum(b.numel() for n, b in d.named_buffers() if not n.endswith("num_batches_tracked"))
+    assert n_param + n_stat == keras_total and n_stat == 2 * (3 * (128 + 64 + 32) + 64 + 64)
+    x = [torch.zeros(2, 1, 128, 128) for _ in range(3)]
+    d.eval()
+    with torch.no_grad():
+        h = d.branches[0](x[0])
+    assert tuple(h.shape) == (2, 32, 16, 16) and d(*x).shape == (2, 3)          # 128 -> 64 -> 32 -> 16 per branch

@@ -291,3 +291,71 @@ def test_sgan_trainer_hip_graph_matches_eager(rml):
     assert "graph" in trs[1]._graphs["c"] and "graph" in trs[1]._graphs["d"]
     a, b = np.array(hist[0]), np.array(hist[1])
     assert np.abs(a - b).max() < 2e-2, (a, b)
+
+
+@pytest.mark.parametrize("amp", ["float16", "bfloat16"])
+def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
+    """BASELINE configs[4] at its real size -- 128x128 projections, batch 256 -- not on two loss scalars but on the
+    gradient of EVERY parameter: the half-precision step with the fused HIP layers (csrc/bnact.hip: folded first
+    convolution, batch norm + LeakyReLU + pad, bias-free convolutions) against the float32 step of the plain PyTorch
+    layers on the same GPU with the same weights and data.  Parity stays "unpinned" by the reference (no Keras here):
+    this pins the fused path to the layer-by-layer restatement."""
+    sgan = importlib.import_module("radar_ml_amd.sgan")
+    torch.manual_seed(5)
+    ref = sgan.define_discriminator(device="cuda")
+    fus = copy.deepcopy(ref)
+    for m in (ref, fus):
+        m.drop.p = 0.0
+        m.train()
+    with torch.no_grad():                                   # non-trivial biases: the fused path must handle them too
+        for mod in list(ref.modules()):
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.bias.normal_(0.0, 0.05)
+        fus.load_state_dict(ref.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(6)
+    n = 256
+    x = [(torch.rand((n, 1, 128, 128), device="cuda", generator=g) * 2 - 1) for _ in range(3)]
+    x = [t.contiguous(memory_format=torch.channels_last) for t in x]
+    y = torch.randint(0, 3, (n,), device="cuda", generator=g)
+    yr = torch.full((n,), 0.9, device="cuda")
+
+    def grads(model, dtype, head):
+        model.zero_grad(set_to_none=True)
+        if dtype is None:
+            logits = model(*x)
+        else:
+            with torch.autocast("cuda", dtype=dtype):
+                logits = model(*x)
+        loss = sgan.c_loss(logits, y) if head == "c" else sgan.d_loss(logits, yr)
+        (loss * 256.0).backward()                           # a fixed loss scale keeps the fp16 gradients out of the subnormals
+        return float(loss), {k: (p.grad.detach().float() / 256.0) for k, p in model.named_parameters()}
+
+    dt = getattr(torch, amp)
+    tol_rel, tol_cos = (0.12, 0.992) if amp == "float16" else (0.5, 0.85)        # about twice the measured worst (printed below)
+    for head in ("c", "d"):
+        l32, g32 = grads(ref, None, head)
+        l16, g16 = grads(fus, dt, head)
+        assert abs(l32 - l16) < (5e-3 if amp == "float16" else 3e-2), (head, l32, l16)
+        worst = []
+        for k in g32:
+            a, b = g32[k].reshape(-1), g16[k].reshape(-1)
+            if k.endswith(".conv.bias") or k in ("fc1.bias", "fc2.bias"):
+                # a bias in front of a batch norm: its gradient is exactly zero in exact arithmetic (round-off in both runs;
+                # the fused convolutions hand back exact zeros)
+                assert float(a.abs().max()) < 1e-3 and float(b.abs().max()) < 1e-3, (head, k)
+                if k.endswith(".conv.bias"):
+                    assert float(b.abs().max()) == 0.0
+                continue
+            na = float(a.norm())
+            if na < 1e-12:
+                continue
+            rel = float((a - b).norm()) / na
+            cos = float(torch.dot(a, b) / (na * float(b.norm()) + 1e-30))
+            worst.append((rel, cos, k))
+            assert rel < tol_rel and cos > tol_cos, (head, k, rel, cos)
+        assert len(worst) >= 30
+        print("sgan %s head %s: worst relative gradient error %.4f (%s), worst cosine %.5f" % (amp, head, max(worst)[0], max(worst)[2], min(w[1] for w in worst)))
+    # running statistics after the same number of forward passes agree as well (incl. the bias the fused path adds back)
+    for (k, a), (_, b) in zip(ref.named_buffers(), fus.named_buffers()):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((a - b).abs().max()) < (2e-3 if amp == "float16" else 1e-2) * max(1.0, float(a.abs().max())), k

@@ -404,3 +404,24 @@ def test_slices_for_several_targets_per_frame(rml):
         rml.process_volumes(v, mode="slice", ijk=ijk[:-1])                 # a short ijk used to be read out of bounds
     with pytest.raises(IndexError):
         rml.process_volumes(v, mode="slice", ijk=np.array([[0, Y, 0]] * B))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 9), (7, 37, 160)])
+def test_nan_policy_of_the_max_projection_is_pinned(rml, shape):
+    """Documented deviation: NumPy's max PROPAGATES NaN, the hardware maximum (v_max_f32 / ds_max_f32, IEEE
+    maxNum) IGNORES it -- the result is np.fmax.reduce, and a line that holds nothing but NaN gives -inf (the identity).
+    Radar magnitudes are integers 0..255 (common.py:30-31), so the reference path never meets one; the policy is pinned here
+    for every kernel family (fast / wave-per-frame / generic / row-group)."""
+    X, Y, Z = shape
+    rng = np.random.default_rng(9)
+    v = (rng.standard_normal((3, X, Y, Z)) * 20).astype(np.float32)
+    v[rng.random(v.shape) < 0.05] = np.nan
+    v[1, :, 0, 0] = np.nan                     # a whole line of the yz plane of frame 1
+    got = rml.project(v, mode="max")
+    with np.errstate(invalid="ignore"):
+        want = [np.fmax.reduce(v, axis=2), np.fmax.reduce(v, axis=1), np.fmax.reduce(v, axis=3)]
+    want = [np.where(np.isnan(w), -np.inf, w) for w in want]
+    for g, w in zip(got, want):
+        assert not np.isnan(g).any()
+        np.testing.assert_array_equal(g, w)
+    assert got[1][1, 0, 0] == -np.inf
