@@ -218,6 +218,21 @@ int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
 int rml_svm_set_platt(rml_ctx* ctx, rml_svm* m, const double* probA, const double* probB);
 int rml_svm_pairwise_proba(rml_ctx* ctx, const rml_svm* m, const double* dec_ovo, int64_t N, double* proba, void* stream);
 
+/* ---- training-time augmentation ---------------------------------------------------------------
+ * train.DataGenerator (train.py:84-185) on the GPU, one batch of equally shaped projection planes per call:
+ *   RML_AUG_ROTATE  scipy.ndimage.rotate(p, angle, reshape=False) + clamp to [0,1] (train.py:87-94); params: 6 doubles per
+ *                   plane, the affine map of ndimage.rotate: m00 m01 m10 m11 off0 off1 with
+ *                   [[c, s], [-s, c]], offset = centre - M centre, c/s = cos/sin of the angle in degrees
+ *   RML_AUG_ZOOM    clipped_zoom(p, f) + clamp (train.py:96-144); params: 1 double per plane, the zoom factor
+ *   RML_AUG_NOISE   sparse_noise: ONE draw per plane added to its non-zero entries + clamp (train.py:146-154); params:
+ *                   1 double per plane, the draw
+ * src, dst: DEVICE B*H*W float32 (may not alias); params: DEVICE.  The random draws are the caller's (the Python mirror
+ * makes them in the reference's order from the reference's generators). */
+#define RML_AUG_ROTATE 0
+#define RML_AUG_ZOOM   1
+#define RML_AUG_NOISE  2
+int rml_augment(rml_ctx* ctx, int op, const float* src, int64_t B, int H, int W, const double* params, float* dst, void* stream);
+
 /* Kernel values against the model's support vectors, K[n][m] = k(x_n, sv_m) for m < M, float64, exact to the
  * same arithmetic as rml_svm_decision (path AUTO / I8 / F64).  With the training rows loaded as the "support vectors"
  * of a model (any coefficients) this is the Gram matrix sklearn's SVC(kernel='precomputed') is fitted on and

@@ -600,3 +600,58 @@ def dnn_forward(xz, yz, xy, conv_weights, dense_weights):
     z = z - z.max(axis=1, keepdims=True)
     e = np.exp(z)
     return e / e.sum(axis=1, keepdims=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training-time augmentation: train.DataGenerator.flow -> augment, train.py:84-185, restated with the
+# reference's own library calls (scipy.ndimage); the random draws are arguments
+# ------------------------------------------------------------------------------------------------------------------
+def aug_rotate(p, angle):
+    """train.py:87-94: ndimage.rotate(p, angle, reshape=False), clamp to [0,1]."""
+    from scipy import ndimage
+    out = ndimage.rotate(np.asarray(p), angle, reshape=False)
+    out[out > 1.0] = 1.0
+    out[out < 0.0] = 0.0
+    return out
+
+
+def aug_clipped_zoom(img, zoom_factor):
+    """train.py:96-144: zoom out = ndimage.zoom pasted into the centre of a zero plane; zoom in = ndimage.zoom of the centre
+    crop trimmed to the input size; clamp to [0,1]."""
+    from scipy import ndimage
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    if zoom_factor < 1:
+        zh, zw = int(np.round(h * zoom_factor)), int(np.round(w * zoom_factor))
+        top, left = (h - zh) // 2, (w - zw) // 2
+        out = np.zeros_like(img)
+        out[top:top + zh, left:left + zw] = ndimage.zoom(img, (zoom_factor, zoom_factor))
+    elif zoom_factor > 1:
+        zh, zw = int(np.ceil(h / zoom_factor)), int(np.ceil(w / zoom_factor))
+        top, left = (h - zh) // 2, (w - zw) // 2
+        out = ndimage.zoom(img[top:top + zh, left:left + zw], (zoom_factor, zoom_factor))
+        tt, tl = (out.shape[0] - h) // 2, (out.shape[1] - w) // 2
+        out = out[tt:tt + h, tl:tl + w]
+    else:
+        out = img.copy()
+    out[out > 1.0] = 1.0
+    out[out < 0.0] = 0.0
+    return out
+
+
+def aug_sparse_noise(q, draw):
+    """train.py:146-154: ONE Gaussian draw added to the non-zero entries (sparsity kept), clamp to [0,1]."""
+    qc = np.asarray(q).copy()
+    qc[qc != 0] += float(draw)      # a Python float, as Generator.normal() returns: the float32 array stays float32 (added in float32)
+    qc[qc > 1.0] = 1.0
+    qc[qc < 0.0] = 0.0
+    return qc
+
+
+def aug_repetitions(labels, balance=True):
+    """train.py:187-196 + 158: class weight = count of the most common class / count (1 without balancing);
+    a sample is augmented int(np.round(weight)) times."""
+    import collections
+    mc = collections.Counter(labels).most_common()
+    cw = {c: (mc[0][1] / cnt if balance else 1) for c, cnt in mc}
+    return [int(np.round(cw[y])) for y in labels]

@@ -14,6 +14,7 @@ from .common import (ProjMask, ProjZoom, DerivedTarget, RADAR_MAX, RADAR_MIN,
 from .svm import GpuSVC, GpuCalibratedClassifier, GpuLinearClassifier, KernelMatrix, from_sklearn
 from .predict import classifier, classify_batch, calc_proj_zoom
 from .synth import synth_volumes
+from .augment import DataGenerator, augment_planes, rotation_params
 
 __all__ = [
     "RadarMLError", "ProjMask", "ProjZoom", "DerivedTarget", "RADAR_MAX", "RADAR_MIN",
@@ -21,4 +22,5 @@ __all__ = [
     "process_samples", "process_volumes", "project", "derive_targets", "feature_len",
     "GpuSVC", "GpuCalibratedClassifier", "GpuLinearClassifier", "KernelMatrix", "from_sklearn",
     "classifier", "classify_batch", "calc_proj_zoom", "synth_volumes",
+    "DataGenerator", "augment_planes", "rotation_params",
 ]

@@ -80,11 +80,13 @@ SIGNATURES = {
     "rml_conv1_bn_lrelu_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p]),
+    "rml_augment": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
 }
 
 MODE_MAX, MODE_SLICE, MODE_SUM = 0, 1, 2
+AUG_ROTATE, AUG_ZOOM, AUG_NOISE = 0, 1, 2
 VOL_F32, VOL_U8 = 0, 1
 MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM}
 KERNEL_RBF, KERNEL_LINEAR = 0, 1

@@ -1,0 +1,143 @@
+// On-GPU data augmentation of the reference's training path (train.py:84-185, DataGenerator.flow -> augment), one
+// projection plane batch at a time:
+//
+//   RML_AUG_ROTATE  rotate(p):        scipy.ndimage.rotate(p, angle, reshape=False) (order-3 spline, mode 'constant',
+//                                     prefilter) then clamp to [0,1]                                    train.py:87-94
+//   RML_AUG_ZOOM    clipped_zoom(p):  zoom out: ndimage.zoom of the whole plane pasted into the centre of a zero plane;
+//                                     zoom in: ndimage.zoom of the centre crop, trimmed to the plane's size; clamp  train.py:96-144
+//   RML_AUG_NOISE   sparse_noise(p):  ONE Gaussian draw per plane added to its non-zero entries, clamp   train.py:146-154
+//
+// The random draws stay on the host (radar-ml_amd/augment.py makes them in the reference's order from the reference's
+// generators, so a seeded run reproduces the reference's data set); the kernels take them as per-plane parameters.
+//
+// SciPy's algorithm restated (scipy/ndimage/_interpolation.py rotate -> affine_transform -> spline_filter +
+// NI_GeometricTransform; zoom -> NI_ZoomShift): float64 cubic B-spline prefilter of the SOURCE region (mirror boundary
+// initialisation for mode 'constant'), output o = (o0, o1) samples the coordinate c = M o + offset (rotate) or
+// c = o * (n_in - 1) / (n_out - 1) (zoom), 4 x 4 taps around floor(c) mirrored at the region's edges, coordinates outside
+// [0, n-1] give cval = 0; the float64 sum is cast to float32 (ndimage returns the input dtype), then the reference's clamp.
+// One workgroup per plane; the source region lives in LDS as float64 (44 KB for a 31 x 176 plane).
+#include "rml_internal.h"
+#include "spline_dev.h"
+#include <math.h>
+
+namespace {
+
+using namespace rml_spline;
+
+struct AugArgs {
+    const float* src; float* dst;
+    int H, W, op;
+    const double* par;      // per plane: ROTATE 6 (m00 m01 m10 m11 off0 off1), ZOOM 1 (factor), NOISE 1 (the draw)
+};
+
+__device__ __forceinline__ float clamp01(float v) { return v > 1.0f ? 1.0f : (v < 0.0f ? 0.0f : v); }     // NaN passes, as in the reference
+
+// value of the spline with coefficients coef (h x w, row stride w) at (c0, c1); 0 outside [0,h-1] x [0,w-1]
+__device__ __forceinline__ float sample(const double* coef, int h, int w, double c0, double c1) {
+    if (!(c0 >= 0.0 && c0 <= (double)(h - 1) && c1 >= 0.0 && c1 <= (double)(w - 1))) return 0.0f;
+    const int f0 = (int)floor(c0), f1 = (int)floor(c1);
+    double w0[4], w1[4];
+    bspline3(c0 - f0, w0);
+    bspline3(c1 - f1, w1);
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double* row = coef + (int64_t)mirror_idx(f0 - 1 + p, h) * w;
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += w1[q] * row[mirror_idx(f1 - 1 + q, w)];
+        s += w0[p] * t;
+    }
+    return (float)s;
+}
+
+__global__ __launch_bounds__(256) void k_augment(AugArgs a) {
+    extern __shared__ __align__(16) double coef[];
+    const int64_t b = blockIdx.x;
+    const int H = a.H, W = a.W;
+    const float* src = a.src + b * (int64_t)H * W;
+    float* dst = a.dst + b * (int64_t)H * W;
+    const int tid = threadIdx.x;
+    if (a.op == RML_AUG_NOISE) {
+        const float nz = (float)a.par[b];               // float32 array += Python float: NumPy adds in float32
+        for (int i = tid; i < H * W; i += 256) {
+            const float v = src[i];
+            dst[i] = clamp01(v != 0.0f ? v + nz : v);
+        }
+        return;
+    }
+    // source region [top, top+h) x [left, left+w) whose spline is sampled; output window
+    int top = 0, left = 0, h = H, w = W;
+    double zf = 1.0;
+    int zh = H, zw = W, otop = 0, oleft = 0, trim_top = 0, trim_left = 0, OH = H, OW = W;
+    if (a.op == RML_AUG_ZOOM) {
+        zf = a.par[b];
+        if (zf == 1.0) {                                // clipped_zoom returns the input itself (then clamps it)
+            for (int i = tid; i < H * W; i += 256) dst[i] = clamp01(src[i]);
+            return;
+        }
+        if (zf < 1.0) {                                 // the whole plane, zoomed out into the centre of a zero plane
+            zh = (int)rint((double)H * zf); zw = (int)rint((double)W * zf);     // int(np.round(h * zoom_factor)): half to even
+            otop = (H - zh) / 2; oleft = (W - zw) / 2;
+            OH = zh; OW = zw;
+        } else {                                        // the centre crop, zoomed in and trimmed to H x W
+            h = (int)ceil((double)H / zf); w = (int)ceil((double)W / zf);
+            top = (H - h) / 2; left = (W - w) / 2;
+            OH = (int)rint((double)h * zf); OW = (int)rint((double)w * zf);    // ndimage.zoom: int(round(n * zoom))
+            trim_top = (OH - H) / 2; trim_left = (OW - W) / 2;
+        }
+    }
+    for (int i = tid; i < h * w; i += 256) {
+        const int r = i / w, c = i - r * w;
+        coef[i] = (double)src[(int64_t)(top + r) * W + left + c];
+    }
+    __syncthreads();
+    for (int c = tid; c < w; c += 256) prefilter_line(coef + c, h, w);              // axis 0
+    __syncthreads();
+    for (int r = tid; r < h; r += 256) prefilter_line(coef + (int64_t)r * w, w, 1); // axis 1
+    __syncthreads();
+    if (a.op == RML_AUG_ROTATE) {
+        const double* m = a.par + b * 6;
+        for (int o = tid; o < H * W; o += 256) {
+            const int o0 = o / W, o1 = o - o0 * W;
+            const double c0 = m[0] * o0 + m[1] * o1 + m[4];
+            const double c1 = m[2] * o0 + m[3] * o1 + m[5];
+            dst[o] = clamp01(sample(coef, H, W, c0, c1));
+        }
+        return;
+    }
+    // zoom: output index (q0, q1) of the ndimage.zoom result samples q * (n_in - 1) / (n_out - 1)
+    const double s0 = OH > 1 ? (double)(h - 1) / (double)(OH - 1) : 1.0;
+    const double s1 = OW > 1 ? (double)(w - 1) / (double)(OW - 1) : 1.0;
+    for (int o = tid; o < H * W; o += 256) {
+        const int o0 = o / W, o1 = o - o0 * W;
+        float v = 0.0f;
+        if (zf < 1.0) {
+            const int q0 = o0 - otop, q1 = o1 - oleft;
+            if (q0 >= 0 && q0 < zh && q1 >= 0 && q1 < zw) v = sample(coef, h, w, q0 * s0, q1 * s1);
+        } else {
+            v = sample(coef, h, w, (o0 + trim_top) * s0, (o1 + trim_left) * s1);
+        }
+        dst[o] = clamp01(v);
+    }
+}
+
+}  // namespace
+
+extern "C" int rml_augment(rml_ctx* ctx, int op, const float* src, int64_t B, int H, int W, const double* params,
+                           float* dst, void* stream) {
+    RML_REQUIRE(ctx && B >= 0 && H > 0 && W > 0, RML_ERR_INVALID, "rml_augment: bad arguments");
+    RML_REQUIRE(op == RML_AUG_ROTATE || op == RML_AUG_ZOOM || op == RML_AUG_NOISE, RML_ERR_INVALID, "rml_augment: unknown op %d", op);
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(src && dst && params, RML_ERR_INVALID, "rml_augment: NULL argument");
+    RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_augment: B too large");
+    const size_t lds = op == RML_AUG_NOISE ? 0 : (size_t)H * W * sizeof(double);
+    RML_REQUIRE(lds <= 150 * 1024, RML_ERR_UNSUPPORTED, "rml_augment: plane too large for the LDS-resident spline filter");
+    RML_HIP(hipSetDevice(ctx->device));
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    AugArgs a{src, dst, H, W, op, params};
+    hipLaunchKernelGGL(k_augment, dim3((unsigned)B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

@@ -318,6 +318,53 @@ def golden_generated_data(common):
     print("generated_data:", {k: v.shape for k, v in out.items()})
 
 
+def golden_augment(common):
+    """train.DataGenerator (train.py:32-185) imported from the reference and run on a small imbalanced set of Walabot-grid
+    projections, balance=True, with its two random sources seeded (np.random.seed for the np.random.uniform draws,
+    np.random.PCG64 replaced by a seeded one for the `rg.normal` draws) and every draw RECORDED, so that the kernels can be
+    checked on the recorded parameters and the Python mirror on the seeds."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import train                                            # the reference module (sklearn / scipy / matplotlib only)
+    vol, cls = synth(SEED + 91, 7, 22, 31, 176)
+    samples = []
+    for v in vol:
+        xz, yz, xy = v.max(axis=1), v.max(axis=0), v.max(axis=2)
+        samples.append(tuple((p / np.float32(255.0)).astype(np.float32) for p in (xz, yz, xy)))     # train.py:667 scaling
+    samples[3] = tuple(p * np.float32(0.37) for p in samples[3])                                   # non-grid values as well
+    labels = [0, 0, 0, 0, 1, 1, 2]
+    rec = {"uniform": [], "normal": []}
+    real_uniform, RealPCG = np.random.uniform, np.random.PCG64
+
+    def uniform(lo, hi):
+        v = real_uniform(lo, hi); rec["uniform"].append(v); return v
+
+    class RecGen(np.random.Generator):
+        def normal(self, loc=0.0, scale=1.0, size=None):
+            v = super().normal(loc, scale, size); rec["normal"].append(float(v)); return v
+
+    np.random.seed(SEED)
+    np.random.uniform = uniform
+    np.random.PCG64 = lambda: RealPCG(SEED + 1)
+    RealGen = np.random.Generator
+    np.random.Generator = RecGen
+    try:
+        gen = train.DataGenerator(rotation_range=15.0, zoom_range=0.3, noise_sd=0.2, balance=True)
+        flow = gen.flow(list(samples), list(labels), batch_size=4)
+        b1x, b1y = next(flow)
+        b2x, b2y = next(flow)
+    finally:
+        np.random.uniform, np.random.PCG64, np.random.Generator = real_uniform, RealPCG, RealGen
+    aug = list(b1x) + list(b2x)
+    out = dict(in_xz=np.stack([s[0] for s in samples]), in_yz=np.stack([s[1] for s in samples]), in_xy=np.stack([s[2] for s in samples]),
+               labels=np.array(labels), batch_size=np.int64(4), seed_uniform=np.int64(SEED), seed_pcg=np.int64(SEED + 1),
+               out_xz=np.stack([t[0] for t in aug]), out_yz=np.stack([t[1] for t in aug]), out_xy=np.stack([t[2] for t in aug]),
+               out_y=np.concatenate([b1y, b2y]), n_batch1=np.int64(len(b1y)),
+               rec_uniform=np.array(rec["uniform"]), rec_normal=np.array(rec["normal"]))
+    np.savez_compressed(os.path.join(HERE, "augment_golden.npz"), **out)
+    print("augment_golden: %d augmented tuples from %d samples, %d uniform / %d normal draws, out dtype %s"
+          % (len(aug), len(samples), len(rec["uniform"]), len(rec["normal"]), aug[0][0].dtype))
+
+
 def golden_pil_resize():
     """The resize in front of the dnn / sgan classifiers exactly as the reference calls it (dnn.py:202-205, 240-245;
     sgan.py:638-641, 676-681): scale to [-1,1], Image.fromarray(p).resize(RESCALE, resample=Image.BICUBIC).  Inputs
@@ -360,6 +407,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "generated":
         golden_generated_data(common)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        golden_augment(common)
+        sys.exit(0)
     golden_index_kats(common)
     golden_common(common, predict)
     golden_svm(common, "svm_small.npz", 8, 10, 16, 500, 120, 256, gamma=0.05)
@@ -373,3 +423,4 @@ if __name__ == "__main__":
     golden_classifier_threshold(predict)
     golden_pil_resize()
     golden_generated_data(common)
+    golden_augment(common)

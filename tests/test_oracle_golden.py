@@ -211,3 +211,33 @@ def test_multiclass_oracle_matches_sklearn():
     np.testing.assert_array_equal(g["sgd_classes"][np.argmax(d, axis=1)], g["sgd_label"])
     pr = O.calibrated_proba(d, g["sgd_calib_a"], g["sgd_calib_b"])
     np.testing.assert_allclose(pr, g["sgd_proba"], rtol=0, atol=1e-13)
+
+
+def test_augmentation_oracle_matches_the_reference_data_generator():
+    """oracle_np.aug_* against train.DataGenerator itself (imported from the reference by make_golden.py, draws recorded):
+    the same SciPy calls, so bit-identical."""
+    g = load_golden("augment_golden.npz")
+    labels = list(g["labels"])
+    bs = int(g["batch_size"])
+    u = list(g["rec_uniform"]); nrm = list(g["rec_normal"])
+    planes = [g["in_xz"], g["in_yz"], g["in_xy"]]
+    k = 0
+    want_y = []
+    reps = O.aug_repetitions(labels)
+    assert reps == [1, 1, 1, 1, 2, 2, 4]
+    for pos in range(0, len(labels), bs):
+        for si in range(pos, min(pos + bs, len(labels))):
+            for _ in range(reps[si]):
+                ang = [u.pop(0) for _ in range(3)]
+                for pi, nm in enumerate(("out_xz", "out_yz", "out_xy")):
+                    np.testing.assert_array_equal(O.aug_rotate(planes[pi][si], ang[pi]), g[nm][k])
+                zf = u.pop(0)
+                for pi, nm in enumerate(("out_xz", "out_yz", "out_xy")):
+                    np.testing.assert_array_equal(O.aug_clipped_zoom(planes[pi][si], zf), g[nm][k + 1])
+                nz = [nrm.pop(0) for _ in range(3)]
+                for pi, nm in enumerate(("out_xz", "out_yz", "out_xy")):
+                    np.testing.assert_array_equal(O.aug_sparse_noise(planes[pi][si], nz[pi]), g[nm][k + 2])
+                want_y += [labels[si]] * 3
+                k += 3
+    assert k == len(g["out_y"]) and not u and not nrm
+    np.testing.assert_array_equal(g["out_y"], want_y)

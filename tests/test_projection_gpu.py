@@ -425,3 +425,61 @@ def test_nan_policy_of_the_max_projection_is_pinned(rml, shape):
         assert not np.isnan(g).any()
         np.testing.assert_array_equal(g, w)
     assert got[1][1, 0, 0] == -np.inf
+
+
+def test_augmentation_kernels_match_the_reference_data_generator(rml):
+    """csrc/augment.hip (rotate / clipped zoom / sparse noise, train.py:84-185) against train.DataGenerator itself: first the
+    kernels on the draws the reference made (recorded by make_golden.py), then the Python mirror ``rml.DataGenerator`` seeded
+    like the reference run -- it must make the same draws, in the same order, and return the same augmented data set.
+    float64 spline arithmetic on both sides, float32 results: 2e-6 absolute on values in [0, 1]."""
+    from conftest import load_golden
+    g = load_golden("augment_golden.npz")
+    labels = [int(v) for v in g["labels"]]
+    planes = [g["in_xz"], g["in_yz"], g["in_xy"]]
+    outs = [g["out_xz"], g["out_yz"], g["out_xy"]]
+    reps = O.aug_repetitions(labels)
+    u = list(g["rec_uniform"]); nrm = list(g["rec_normal"])
+    bs = int(g["batch_size"])
+    k = 0
+    worst = 0.0
+    for pos in range(0, len(labels), bs):
+        for si in range(pos, min(pos + bs, len(labels))):
+            for _ in range(reps[si]):
+                ang = [u.pop(0) for _ in range(3)]
+                zf = u.pop(0)
+                nz = [nrm.pop(0) for _ in range(3)]
+                for pi in range(3):
+                    p = planes[pi][si][None]
+                    r = rml.augment_planes(p, "rotate", rml.rotation_params(ang[pi], p.shape[1:])[None]).cpu().numpy()[0]
+                    z = rml.augment_planes(p, "zoom", np.array([zf])).cpu().numpy()[0]
+                    n = rml.augment_planes(p, "noise", np.array([nz[pi]])).cpu().numpy()[0]
+                    worst = max(worst, np.abs(r - outs[pi][k]).max(), np.abs(z - outs[pi][k + 1]).max())
+                    np.testing.assert_array_equal(n, outs[pi][k + 2])          # float32 add + clamp: bit-exact
+                k += 3
+    assert worst <= 2e-6, worst
+    # zoom factor exactly 1 returns the (clamped) input; batched call with mixed factors
+    p = planes[0][:3]
+    zs = np.array([1.0, 0.8, 1.25])
+    got = rml.augment_planes(p, "zoom", zs).cpu().numpy()
+    for b in range(3):
+        assert np.abs(got[b] - O.aug_clipped_zoom(p[b], zs[b])).max() <= 2e-6
+    # the mirror, seeded like the reference run
+    import numpy.random as npr
+    real_pcg = npr.PCG64
+    npr.seed(int(g["seed_uniform"]))
+    npr.PCG64 = lambda: real_pcg(int(g["seed_pcg"]))
+    try:
+        gen = rml.DataGenerator(rotation_range=15.0, zoom_range=0.3, noise_sd=0.2, balance=True)
+        flow = gen.flow([tuple(pl[i] for pl in planes) for i in range(len(labels))], labels, batch_size=bs)
+        b1x, b1y = next(flow)
+        b2x, b2y = next(flow)
+    finally:
+        npr.PCG64 = real_pcg
+    assert len(b1y) == int(g["n_batch1"])
+    np.testing.assert_array_equal(np.concatenate([b1y, b2y]), g["out_y"])
+    aug = list(b1x) + list(b2x)
+    assert len(aug) == len(g["out_y"])
+    for j, t in enumerate(aug):
+        for pi in range(3):
+            assert t[pi].dtype == np.float32 and t[pi].shape == outs[pi][j].shape
+            assert np.abs(t[pi] - outs[pi][j]).max() <= 2e-6, (j, pi)
