@@ -53,8 +53,8 @@ def pmc(fetch_db, write_db):
     keys = sorted(set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"]), key=lambda k: -sum(d for _, d in out["FETCH_SIZE"].get(k, [(0, 0)])))
     summary = {}
     for k in keys:
-        f = [x for x in out["FETCH_SIZE"].get(k, []) if x[1] > 20000]
-        w = [x for x in out["WRITE_SIZE"].get(k, []) if x[1] > 20000]
+        f = [x for x in out["FETCH_SIZE"].get(k, []) if x[1] > 20000][1:] or [x for x in out["FETCH_SIZE"].get(k, []) if x[1] > 20000]
+        w = [x for x in out["WRITE_SIZE"].get(k, []) if x[1] > 20000][1:] or [x for x in out["WRITE_SIZE"].get(k, []) if x[1] > 20000]
         if not f and not w:
             continue
         fk = statistics.mean(v for v, _ in f) if f else 0.0
@@ -65,12 +65,13 @@ def pmc(fetch_db, write_db):
         summary["%s|grid=%d" % k] = {"fetch_kb": fk, "write_kb": wk, "avg_us": du, "hbm_bytes_corrected": hbm}
     grid = [int(t) for t in os.environ.get("RML_PMC_GRID", "64x64x128").split("x")]
     doc = {"grid": grid, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction for gfx950", "kernels": summary}
-    for prefix, key in (("k_project_fast", "project_hbm_bytes_per_launch"), ("k_project_u8_max", "u8_project_hbm_bytes_per_launch")):
+    for prefix, key in (("k_project_fast", "project_hbm_bytes_per_launch"), ("k_project_u8_max", "u8_project_hbm_bytes_per_launch"),
+                        ("k_project_wave", "walabot_project_hbm_bytes_per_launch")):
         proj = {k: v for k, v in summary.items() if k.startswith(prefix) and v["fetch_kb"] > 1e5}
         if proj:
             bk = max(proj, key=lambda k: proj[k]["fetch_kb"])
             doc[key] = proj[bk]["hbm_bytes_corrected"]
-            doc[key.replace("hbm_bytes_per_launch", "frames_per_launch")] = int(bk.split("grid=")[1]) // 256
+            doc[key.replace("hbm_bytes_per_launch", "frames_per_launch")] = 16384 if prefix == "k_project_wave" else int(bk.split("grid=")[1]) // 256
     if "project_frames_per_launch" in doc:
         doc["frames_per_launch"] = doc["project_frames_per_launch"]
     json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
