@@ -99,3 +99,63 @@ def test_new_entry_points_reject_bad_arguments(rml):
                                         _lib.ptr(z), _lib.ptr(z), _lib.ptr(ws), _lib.ptr(xh), st) == -2               # C = 12
     assert lib.rml_bn_lrelu_pad_forward(ctx, _lib.ptr(xh), 7, 2, 4, 4, 16, 1, 1, _lib.ptr(g), _lib.ptr(z), 1e-3, 0.01, 0.2, None, None,
                                         _lib.ptr(z), _lib.ptr(z), _lib.ptr(ws), _lib.ptr(xh), st) == -1               # dtype
+
+
+def test_round2_entry_points_reject_bad_arguments(rml):
+    """rml_project_slices / rml_svm_set_platt / rml_augment: status codes and messages; and two host threads sharing the
+    context (the workspace users serialise on it: include/radarml.h conventions)."""
+    import threading
+    import torch
+    from radar_ml_amd import _lib
+    import oracle_np as O
+    from conftest import load_golden, svm_model_arrays
+    lib = _lib.load()
+    ctx = _lib.context()
+    st = _lib.stream_ptr()
+    v = torch.zeros((2, 4, 4, 8), device="cuda")
+    D = 4 * 8 + 4 * 8 + 16
+    feat = torch.empty((6, D), device="cuda")
+    ijk = torch.zeros((6, 3), dtype=torch.int32, device="cuda")
+    assert lib.rml_project_slices(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 0, _lib.ptr(ijk), 0.0, 7, _lib.ptr(feat), D, None, 0, None, None, None, st) == -1
+    assert b"target" in lib.rml_last_error()
+    assert lib.rml_project_slices(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 3, None, 0.0, 7, _lib.ptr(feat), D, None, 0, None, None, None, st) == -1
+    assert lib.rml_project_slices(ctx, _lib.ptr(v), 0, 2, 4, 4, 8, 3, _lib.ptr(ijk), 0.0, 7, _lib.ptr(feat), D, None, 0, None, None, None, st) == 0
+    p = torch.zeros((2, 8, 8), device="cuda"); q = torch.empty_like(p)
+    par = torch.zeros((2, 6), dtype=torch.float64, device="cuda")
+    assert lib.rml_augment(ctx, 7, _lib.ptr(p), 2, 8, 8, _lib.ptr(par), _lib.ptr(q), st) == -1 and b"op" in lib.rml_last_error()
+    assert lib.rml_augment(ctx, 0, _lib.ptr(p), 2, 8, 8, None, _lib.ptr(q), st) == -1
+    assert lib.rml_augment(ctx, 0, _lib.ptr(p), 2, 200, 200, _lib.ptr(par), _lib.ptr(q), st) == -2          # plane larger than the LDS
+    assert lib.rml_augment(ctx, 0, None, 0, 8, 8, None, None, st) == 0
+    g = load_golden("svm_small.npz")
+    svc = rml.GpuSVC(*[svm_model_arrays(g)[k] for k in ("sv", "dual_coef", "intercept", "n_support", "gamma", "classes")])
+    assert lib.rml_svm_set_platt(ctx, svc._h, None, None) == -1
+    # two threads, two streams, one context: results must be what one thread gets
+    m = svm_model_arrays(g)
+    X = g["test_feat_u8"].astype(np.float32) / np.float32(255.0)
+    want = svc.decision_function(X)
+    vol, _ = O.synth_volumes(2, 64, 8, 10, 16)
+    wantp = O.project_max(vol)
+    errs = []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    if i == 0:
+                        got = svc.decision_function(X)
+                        assert np.array_equal(got, want)
+                    else:
+                        t = rml.derive_targets(torch.from_numpy(vol).cuda(), 2).cpu().numpy()
+                        assert t.shape == (64, 2, 3)
+                        got = rml.project(vol, mode="max")
+                        assert all(np.array_equal(a, b) for a, b in zip(got, wantp))
+        except Exception as e:          # pragma: no cover
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
