@@ -244,7 +244,9 @@ def run_workload(a, env, grid, frames, primary):
     achieved = alg_bytes_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None          # filled in by main() from this run's own PMC passes (tools/bench_support.measure_traffic)
     zq = Z // 4
-    kname = "k_project_fast" if zq & (zq - 1) == 0 else ("k_project_wave" if 32 < zq <= 64 and Y <= 32 else "k_project_rowgroup")
+    rpl = 1 if 32 < zq <= 64 else (64 // zq if zq in (16, 32) and Y % (64 // zq) == 0 else 0)
+    wave = os.environ.get("RML_WAVEFRAME", "1") != "0" and rpl > 0 and Y // rpl <= 32      # wave_kernel_wanted(share_cu) of csrc/project.hip
+    kname = "k_project_wave" if wave else ("k_project_fast" if zq & (zq - 1) == 0 else "k_project_rowgroup")
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,

@@ -497,7 +497,13 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
     constexpr int NG = (NY + G - 1) / G;                // row groups per plane
     static_assert(NG == 1 || NG % 2 == 0, "the two row buffers must alternate statically");
     constexpr int U = NG == 1 ? 2 : NG;                 // steps per trip of the main loop (buffer = step parity)
-    const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
+    // Short rows (Z/4 = 32 or 16 quads): RPL = 2 or 4 consecutive rows form one VIRTUAL row of 64 quads -- the plane is
+    // viewed as (Y/RPL) x (RPL*Z), which is the same memory, so every load instruction is still one contiguous <= 1 KB
+    // piece and yz keeps its layout (row j' of the view = rows RPL*j' .. of yz).  Only the epilogues know about it: xz folds
+    // the RPL lane groups of a virtual row, and xy lane j reads the lane group of its real row.
+    const int X = a.X, Yr = a.Y, Zr = a.Z, ZQr = a.ZQ;
+    const int RPL = (ZQr <= 32 && 64 / ZQr >= 2 && Yr % (64 / ZQr) == 0) ? 64 / ZQr : 1;
+    const int Y = Yr / RPL, Z = Zr * RPL, ZQ = ZQr * RPL;           // the view the streaming loop works on
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t stride = (int64_t)gridDim.x * 4;
@@ -592,22 +598,23 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
                     const int i = ci + (NG == 1 ? u : 0);
                     int lane_e = lane;                  // opaque: keeps the store addresses out of loop-invariant hoisting
                     asm volatile("" : "+v"(lane_e));    // (hipcc would hold NY pointer pairs across the streaming loop)
-#ifdef RML_EXP_NOPLANE
-                    if (i == 0)
-#endif
-                    if (lane_e < ZQ) em.put4(0, (int64_t)i * Z + 4 * lane_e, xz);
-#ifdef RML_EXP_NOPLANE
-                    if (i == 0)
-#endif
-                    {
-                    // xy[i, j]: lane j folds the ZQ per-column partials of row j (transposed, conflict-free b128 reads)
-                    const float* rowp = xyl + (lane_e < NY ? lane_e : NY - 1) * kXyStride;
-                    float m = id;
-                    for (int q = 0; q < ZQ; q += 4) {
-                        const float4 t = *reinterpret_cast<const float4*>(rowp + q);
-                        m = Op<MODE>::f(m, Op<MODE>::f(Op<MODE>::f(t.x, t.y), Op<MODE>::f(t.z, t.w)));
+                    // xz[i, k]: fold the RPL lane groups of the virtual row (real rows of different parity)
+                    for (int off = ZQr; off < ZQ; off <<= 1) {
+                        float4 o;
+                        o.x = __shfl_xor(xz.x, off); o.y = __shfl_xor(xz.y, off); o.z = __shfl_xor(xz.z, off); o.w = __shfl_xor(xz.w, off);
+                        xz = op4<MODE>(xz, o);
                     }
-                    if (lane_e < Y) em.put1(2, (int64_t)i * Y + lane_e, m);
+                    if (lane_e < ZQr) em.put4(0, (int64_t)i * Zr + 4 * lane_e, xz);
+                    // xy[i, j]: lane j folds the per-column partials of real row j = lane group j % RPL of virtual row j / RPL
+                    // (transposed, conflict-free b128 reads)
+                    for (int jr = lane_e; jr < Yr; jr += 64) {          // more than 64 real rows when 4 of them share a virtual row
+                        const float* rowp = xyl + (jr / RPL) * kXyStride + (jr % RPL) * ZQr;
+                        float m = id;
+                        for (int q = 0; q < ZQr; q += 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(rowp + q);
+                            m = Op<MODE>::f(m, Op<MODE>::f(Op<MODE>::f(t.x, t.y), Op<MODE>::f(t.z, t.w)));
+                        }
+                        em.put1(2, (int64_t)i * Yr + jr, m);
                     }
                     xz = id4;
                 }
@@ -616,16 +623,10 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
         int lane_f = lane, Y_f = Y;
         asm volatile("" : "+v"(lane_f), "+s"(Y_f));
         const bool act_f = lane_f < ZQ;
-#ifdef RML_EXP_NOYZ      // experiment build: yz leaves through ONE store (what does the unrolled epilogue cost?)
-        float4 yzall = id4;
-        static_for<NY>([&](auto jc) { yzall = op4<MODE>(yzall, yz[decltype(jc)::value]); });
-        if (act_f) em.put4(1, 4 * lane_f, yzall);
-#else
         static_for<NY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j]);
         });
-#endif
         em.finish_wave(lane_f);
     }
 }
@@ -657,13 +658,34 @@ void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
 }
 
 // returns true when the wave-per-frame kernel took the launch
-template <typename VT, int MODE>
-bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
-    // RML_WAVEFRAME: 0 = off, 1 = whole-plane buffers (default), 2 = quarter-plane buffers (two waves per SIMD)
+// rows per load instruction of the wave-per-frame kernel (0 = shape not handled): 1 for long rows (32 < Z/4 <= 64), 2 / 4
+// for rows of 32 / 16 quads when Y divides; the VIEW (Y / RPL rows of RPL * Z/4 quads) must have at most 32 rows
+int wave_kernel_rpl(int ZQ, int Y) {
+    if (ZQ > 32 && ZQ <= 64) return Y <= 32 ? 1 : 0;
+    if (ZQ == 32 || ZQ == 16) {
+        const int rpl = 64 / ZQ;
+        return (Y % rpl == 0 && Y / rpl <= 32) ? rpl : 0;
+    }
+    return 0;
+}
+
+// RML_WAVEFRAME: 0 = off, 1 = on (default; long rows always, short rows -- where k_project_fast is as fast stand-alone --
+// only beside a GEMM), 2 = quarter-plane buffers everywhere, 3 = also short rows stand-alone
+bool wave_kernel_wanted(int ZQ, int Y, bool share_cu) {
     const char* env = getenv("RML_WAVEFRAME");          // read per call (tests flip it): a getenv is noise next to a launch
     const int knob = env ? atoi(env) : 1;
-    if (knob == 0 || pp.ZQ <= 32 || pp.ZQ > 64 || pp.Y > 32) return false;
-    const int Y = pp.Y;
+    const int rpl = wave_kernel_rpl(ZQ, Y);
+    if (knob == 0 || rpl == 0) return false;
+    return rpl == 1 || share_cu || knob == 3;
+}
+
+// returns true when the wave-per-frame kernel took the launch
+template <typename VT, int MODE>
+bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
+    if (!wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0)) return false;
+    const char* env = getenv("RML_WAVEFRAME");
+    const int knob = env ? atoi(env) : 1;
+    const int Y = pp.Y / wave_kernel_rpl(pp.ZQ, pp.Y);  // rows of the view
     // whole-plane buffers need an even number of planes; beside a GEMM the quarter-plane variant (206 VGPRs) leaves it room
     const bool quarter = knob == 2 || (pp.X & 1) || pp.o.share_cu;
 #define RML_WAVE_CASE(NYV)                                                                     \
@@ -989,11 +1011,6 @@ __global__ __launch_bounds__(64) void k_profiles_topk(const float* xzs, const fl
     }
 }
 
-bool wave_kernel_shape(int ZQ, int Y) {
-    const char* env = getenv("RML_WAVEFRAME");
-    return !(env && atoi(env) == 0) && ZQ > 32 && ZQ <= 64 && Y <= 32;
-}
-
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 template <typename VT, int MODE, int LPR, int NM, bool FULL>
@@ -1101,11 +1118,11 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
 }
 }  // namespace
 
-bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z) {
+bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu) {
     (void)X;
     if (mode != RML_MODE_MAX && mode != RML_MODE_SUM) return false;
     if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX && Z % 16 == 0) return false;      // the byte-native kernel takes those
-    return Z % 4 == 0 && wave_kernel_shape(Z / 4, Y);
+    return Z % 4 == 0 && wave_kernel_wanted(Z / 4, Y, share_cu);
 }
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
@@ -1116,6 +1133,7 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     ProjParams pp;
     fill_params(pp, V, B, X, Y, Z, ijk, o);       // B counts output rows
     pp.tpf = targets_per_frame;
+    if (getenv("RML_WAVE_SHARE")) pp.o.share_cu = 1;    // measurement knob: the pipeline's kernel configuration in a stand-alone launch
     const int num_cu = ctx ? ctx->num_cu : 256;
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;

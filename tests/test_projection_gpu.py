@@ -44,14 +44,18 @@ def test_sum_projection_exact_on_integer_data(rml, shape):
         np.testing.assert_array_equal(g, w)      # integer data: float32 sums are exact in any order
 
 
-@pytest.mark.parametrize("knob", ["1", "2"])
-@pytest.mark.parametrize("shape", [(22, 31, 176), (4, 8, 132), (3, 20, 180), (6, 32, 256), (2, 13, 148)])
+@pytest.mark.parametrize("shape,knob", [(s, k) for k in ("1", "2") for s in [(22, 31, 176), (4, 8, 132), (3, 20, 180), (6, 32, 256), (2, 13, 148)]]
+                         + [(s, "3") for s in [(16, 64, 128), (6, 16, 64), (5, 20, 128), (8, 62, 128), (4, 128, 64), (3, 4, 64)]])
 def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
     """The persistent wave-per-frame kernel (k_project_wave): more frames than resident waves, so every wave walks several
     frames with the cross-frame prefetch, in both buffer configurations (RML_WAVEFRAME=1 whole plane / 2 quarter plane),
-    max and sum, float rows + codes + statistics."""
+    max and sum, float rows + codes + statistics.  Knob 3: short rows (Z/4 = 32 or 16) through the same kernel, 2 or 4 real
+    rows per virtual 64-quad row -- the configuration the fused pipeline uses beside the GEMM (forced stand-alone here, also
+    with RML_WAVE_SHARE: quarter-plane buffers, one workgroup per CU)."""
     import torch
     monkeypatch.setenv("RML_WAVEFRAME", knob)
+    if knob == "3" and shape[0] % 2 == 0:
+        monkeypatch.setenv("RML_WAVE_SHARE", "1")
     X, Y, Z = shape
     B = 2600 if X * Y * Z < 60000 else 1100
     rng = np.random.default_rng(X * 1000 + Y)

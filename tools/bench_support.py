@@ -170,7 +170,7 @@ def measure_traffic(configs, timeout_s=240):
     spec = json.dumps(configs)
     got = {}
     tmp = tempfile.mkdtemp(prefix="rml_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RML_WAVE_SHARE="1")      # the child launches the kernel configuration of the fused pipeline
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
