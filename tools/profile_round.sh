@@ -18,7 +18,7 @@ python $R/tools/prof_summary.py stats $R/gpurun_out/prof_stats/k_results.db > $R
 # roofline.traffic with: tools/pmc_child.py), one pass per counter, kernel trace only
 CFG='[{"tag":"primary_f32","grid":[64,64,128],"frames":16384,"u8":false},{"tag":"primary_u8","grid":[64,64,128],"frames":16384,"u8":true},{"tag":"walabot_f32","grid":[22,31,176],"frames":16384,"u8":false},{"tag":"walabot_u8","grid":[22,31,176],"frames":16384,"u8":true}]'
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/prof_$c -o k -- python $R/tools/pmc_child.py "$CFG" > /dev/null 2> $R/gpurun_out/prof_$c.err
+    RML_WAVE_SHARE=1 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/prof_$c -o k -- python $R/tools/pmc_child.py "$CFG" > /dev/null 2> $R/gpurun_out/prof_$c.err
 done
 cd $R
 python tools/prof_summary.py pmc gpurun_out/prof_FETCH_SIZE/k_results.db gpurun_out/prof_WRITE_SIZE/k_results.db > gpurun_out/${TAG}_pmc.txt
