@@ -211,15 +211,18 @@ def run_workload(a, env, grid, frames, primary):
         if world > 1:
             dist.all_reduce(t8, op=dist.ReduceOp.MAX)
         dt8 = float(t8.item())
-        same = bool(torch.equal(out8["label_calib"], out["label_calib"]) and torch.equal(out8["label_vote"], out["label_vote"])
-                    and torch.equal(out8["dec_ovo"], out["dec_ovo"]))
+        # the two ingests may run on different exact-GEMM tiles (128x128 beside the wave projection, 256x256 here): the int32 dot
+        # products are the same integers, the float64 sums over SV tiles differ in order only
+        lab_same = bool(torch.equal(out8["label_calib"], out["label_calib"]) and torch.equal(out8["label_vote"], out["label_vote"]))
+        dec_diff = float((out8["dec_ovo"] - out["dec_ovo"]).abs().max())
+        same = lab_same and dec_diff <= 1e-9
         l8 = max(1, nl8.value)
         a8 = ms8.value / l8
         ach8 = (X * Y * Z + 16) * (nf8.value / l8) / (a8 * 1e-3) / 1e9 if a8 > 0 else 0.0
         tr8 = None          # filled in by main() from this run's own PMC passes (tools/bench_support.measure_traffic)
         u8 = {"value": round(world * B * a.steps / dt8, 1), "unit": "frames/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3),
               "workload": "the same %d frames/GPU as uint8 volumes (1 byte per voxel)" % B,
-              "identical_to_f32_ingest": same,
+              "identical_to_f32_ingest": same, "labels_identical": lab_same, "dec_ovo_max_abs_diff_vs_f32_ingest": dec_diff,
               "hbm_frac_end_to_end": round(B * a.steps / dt8 * (X * Y * Z + 16) / 1e9 / HBM_PEAK_GBS, 4),
               "roofline": {"bound": "hbm", "kernel": "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>",
                            "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
