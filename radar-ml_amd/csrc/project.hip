@@ -671,7 +671,10 @@ int wave_kernel_rpl(int ZQ, int Y) {
 
 // RML_WAVEFRAME: 0 = off, 1 = on (default; long rows always, short rows -- where k_project_fast is as fast stand-alone --
 // only beside a GEMM), 2 = quarter-plane buffers everywhere, 3 = also short rows stand-alone
-bool wave_kernel_wanted(int ZQ, int Y, bool share_cu) {
+// Small batches stay on the workgroup-per-frame kernels: a single wave streams a 480 KB frame in ~50 us, which is what a
+// B = 1 call would wait for (single-observation latency 167 -> 210 us when this kernel took every batch size).
+bool wave_kernel_wanted(int ZQ, int Y, bool share_cu, int64_t B, int num_cu) {
+    if (B < 2 * (int64_t)num_cu) return false;
     const char* env = getenv("RML_WAVEFRAME");          // read per call (tests flip it): a getenv is noise next to a launch
     const int knob = env ? atoi(env) : 1;
     const int rpl = wave_kernel_rpl(ZQ, Y);
@@ -682,7 +685,7 @@ bool wave_kernel_wanted(int ZQ, int Y, bool share_cu) {
 // returns true when the wave-per-frame kernel took the launch
 template <typename VT, int MODE>
 bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
-    if (!wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0)) return false;
+    if (!wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0, pp.B, num_cu)) return false;
     const char* env = getenv("RML_WAVEFRAME");
     const int knob = env ? atoi(env) : 1;
     const int Y = pp.Y / wave_kernel_rpl(pp.ZQ, pp.Y);  // rows of the view
@@ -1118,11 +1121,11 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
 }
 }  // namespace
 
-bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu) {
+bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B, int num_cu) {
     (void)X;
     if (mode != RML_MODE_MAX && mode != RML_MODE_SUM) return false;
     if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX && Z % 16 == 0) return false;      // the byte-native kernel takes those
-    return Z % 4 == 0 && wave_kernel_wanted(Z / 4, Y, share_cu);
+    return Z % 4 == 0 && wave_kernel_wanted(Z / 4, Y, share_cu, B, num_cu);
 }
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,

@@ -114,7 +114,7 @@ struct ProjOut {
 
 // true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then
 // pairs it with the 128x128 GEMM, whose workgroups fit beside it on a CU)
-bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu);
+bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B, int num_cu);
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);

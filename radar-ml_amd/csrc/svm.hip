@@ -1228,7 +1228,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
-    const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true);
+    const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
     const int64_t small_chunk = (int64_t)X * Y * Z <= 200000 ? 16384 : 8192;
     const int64_t CH = (grid_ok && !wave_proj) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
                                                : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);

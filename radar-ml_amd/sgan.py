@@ -223,7 +223,9 @@ class DiscriminatorTrainer:
             self._zero_grad(opt)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: the RCCL watchdog thread of a multi-rank job queries events while we capture; in the default
+            # (global) mode that invalidates the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
                     logits = self.net(*st["xs"])
                 loss = make_loss(logits, *st["targets"])
