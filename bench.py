@@ -609,11 +609,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         a.gpus = world
+    if os.environ.get("RML_BENCH_ONE_DEVICE"):      # dry run of the N > 1 control flow on a 1-GPU box: every rank on cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("RML_BENCH_ONE_DEVICE"):
+            dist.init_process_group("gloo")         # RCCL refuses two ranks on one device; gloo stages CUDA tensors through the host
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()

@@ -36,7 +36,12 @@ def gather_labels(local, n_frames=None, group=None):
         local = torch.cat([local, pad], dim=0)
     local = local.contiguous()
     out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
+    try:
+        dist.all_gather_into_tensor(out, local, group=group)
+    except RuntimeError:                    # a backend without the flat form (gloo on CUDA tensors): list form, same result
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        out = torch.cat(parts, dim=0)
     if min(sizes) == mx:
         return out
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], dim=0)

@@ -166,7 +166,9 @@ class DiscriminatorTrainer:
             for p in params:
                 if p.dtype != torch.float32:
                     raise TypeError("flat gradient bucket: float32 master parameters expected")
-                p.grad = self._flat[off:off + p.numel()].view_as(p)
+                # the view takes the parameter's own strides (channels_last convolution kernels): the fused Adam and autograd's
+                # gradient-layout contract want grad and param laid out alike
+                p.grad = torch.as_strided(self._flat, p.size(), p.stride(), storage_offset=off)
                 off += p.numel()
         elif mode is not None:
             raise ValueError("ddp must be None, False, 'flat' or 'torch'")

@@ -91,8 +91,10 @@ def _ddp_worker(rank, world, port, q, mode=None):
     import radar_ml_amd  # noqa
     sgan = importlib.import_module("radar_ml_amd.sgan")
     torch.manual_seed(rank)                                    # DIFFERENT initial weights: the trainer must broadcast rank 0's
-    d = sgan.Discriminator(((16, 16, 1),) * 3, 3)
-    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None, ddp=mode)     # None: picks the flat-bucket all-reduce up from the process group
+    d = sgan.Discriminator(((16, 16, 1),) * 3, 3).to(memory_format=torch.channels_last)     # as define_discriminator lays it out
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype=None, ddp=mode)
+    if mode is None:
+        assert all(p.grad.stride() == p.stride() for p in d.parameters())                 # flat-bucket views follow the parameters' layout     # None: picks the flat-bucket all-reduce up from the process group
     rng = np.random.default_rng(100 + rank)                    # each rank its own shard of the batch
     x = [rng.uniform(-1, 1, (8, 16, 16, 1)).astype(np.float32) for _ in range(3)]
     tr.train_on_batch_c(x, rng.integers(0, 3, 8))
