@@ -505,7 +505,7 @@ def run_dnn(a, env):
     convs, dense = model.keras_weights()
     want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
     got = res["f32"][1][:npar].float().cpu().numpy()
-    # roofline of the dominant kernel of this row, k_dnn_trunk (bf16 MFMA): timed with events on the stream it runs on
+    # roofline of the dominant kernel of this row, k_dnn_trunk_rf (bf16 MFMA): timed with events on the stream it runs on
     from radar_ml_amd import nn_common
     nb = int(min(8192, B))
     feat = rml.process_volumes(V[:nb], mode="max", scale=False)
@@ -528,7 +528,7 @@ def run_dnn(a, env):
            "uint8_identical_labels": bool(torch.equal(res["u8"][1].argmax(1), res["f32"][1].argmax(1))),
            "config": {"workload": "configs[3]: %d frames/GPU of %dx%dx%d -> 3 x 80x80 -> multi-view CNN (2.52 M parameters, "
                                   "54.7 MFLOP/frame), random-init weights" % (B, X, Y, Z), "frames_per_gpu": B},
-           "roofline": {"bound": "mfma", "kernel": "k_dnn_trunk", "achieved": round(trunk_tf, 1), "peak": BF16_PEAK, "unit": "TFLOP/s",
+           "roofline": {"bound": "mfma", "kernel": "k_dnn_trunk_rf", "achieved": round(trunk_tf, 1), "peak": BF16_PEAK, "unit": "TFLOP/s",
                         "frac": round(trunk_tf / BF16_PEAK, 4), "avg_launch_ms": round(trunk_ms, 4), "frames_per_launch": nb,
                         "algorithmic_flop_per_frame": conv_flop, "traffic": None},
            "parity": {"frames": npar, "proba_max_abs_err_vs_float64_oracle": float(np.abs(got - want).max()),

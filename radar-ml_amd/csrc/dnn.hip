@@ -24,8 +24,9 @@
 // LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) so that they do not drain the plane prefetch.
 // Numerics: bf16 operands (conv1 bias included), float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
 // Measured (8192 samples of 3 x 80x80, MI355X): 0.68 ms = 12.1 M samples/s; the same layers through PyTorch/MIOpen
-// in bf16 channels_last take 13.9 ms.
+// in bf16 channels_last take 13.9 ms.  Planes whose LDS layout fits go to k_dnn_trunk_rf further down (0.55-0.61 ms).
 #include "rml_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -62,6 +63,14 @@ __device__ __forceinline__ uint32_t pk_relu(uint32_t v) {             // bf16 is
     s16x2 s = *reinterpret_cast<s16x2*>(&v);
     s = __builtin_elementwise_max(s, s16x2{0, 0});
     return *reinterpret_cast<uint32_t*>(&s);
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
 }
 
 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetch of the next plane
@@ -364,12 +373,276 @@ int launch_trunk(const TrunkArgs& a, int num_cu, hipStream_t stream) {
     return RML_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_dnn_trunk_rf: the same two convolutions with the conv1 image kept in REGISTERS.
+//
+// k_dnn_trunk above is bound by the LDS, not by the matrix cores: every conv1 pixel is stored to LDS once and read back
+// 2.25 times (3x3 taps at stride 2) by two waves each (one per 16-channel tile), 1 KB of ds_read_b128 per 16-cycle MFMA.
+// Here the conv1 image never exists.  With v_mfma_f32_32x32x16_bf16 the conv1 accumulators of a 32-pixel tile already
+// ARE the B operand of conv2 for that tile: a lane (pixel n = lane & 31, k-group h = lane / 32) holds, for register r,
+// channel 8 (r / 4) + 4 h + r % 4 of pixel n, and conv2's B operand wants 8 k-values of column n per lane -- any K
+// order will do as long as the weight fragments use the same one.  So for every (tile of 32 conv2 pixels, tap) conv1 is
+// evaluated on the matrix cores AT the 32 conv1 pixels that tap reads (conv1 is recomputed 2.25 times: +25 % MFMA work
+// in total), converted to bf16 and relu'd in registers (v_cvt_pk_bf16_f32 + v_pk_max_i16) and fed straight to the four
+// conv2 MFMAs of the tap (K = 16 conv1 channels each, all 32 output channels).
+//
+// One 8-wave workgroup per CU, persistent.  A WAVE owns a sample: its bf16 plane sits in a wave-private LDS region (two
+// 8-byte reads per tap and lane: window rows r0 r1, or r2 + the bias's 1.0; no VALU in the gather), it walks the sample's
+// tiles with no barrier and no exchange with other waves, and stores finished 32-byte channel runs.  The conv2 weight
+// fragments (36 KB per branch, already in MFMA operand order) are shared by the eight waves through LDS: one
+// ds_read_b128 per conv2 MFMA, a quarter of the LDS read rate.  Branches are processed one after the other (three
+// weight loads per workgroup and launch).
+// Conv1 pixels that are conv2's 'same' padding (row OH1 / column OW1) come out as exact zeros: their window lies in the
+// plane's zero border and their bias slot reads 0.0 instead of 1.0.  K slots of a conv1 window (8 per lane): k-group 0
+// [r0c0 r0c1 r0c2 r0c3 r1c0 r1c1 r1c2 r1c3] with weights [w00 w01 w02 0 w10 w11 w12 0]; k-group 1 [r2c0 r2c1 r2c2 r2c3
+// 1 1 1 1] with [w20 w21 w22 0 bias 0 0 0] (slots with zero weights hold plane values: finite inputs assumed, as above).
+// A DS access wider than 4 bytes must be naturally aligned or it is replayed at 64 cycles (MI355X_MICROARCH.md, LDS):
+// the windows of the kx = 1 taps start 4 bytes off the 8-byte grid and are read dword by dword, through addresses the
+// compiler cannot see through (it would fuse them into one 8-byte read otherwise).
+constexpr int RF_WAVES = 8;
+struct RfLayout {
+    int RSB;                                   // bytes per plane row in LDS: (W + 4) bf16
+    uint32_t plane, off_w, off_ones, off_zero, off_bias, total;
+    __host__ __device__ RfLayout(int H, int W) {
+        RSB = (W + 4) * 2;
+        plane = ((uint32_t)(H + 4) * RSB + 15) & ~15u;
+        off_w = RF_WAVES * plane;              // [tap][k-step][lane] 16 B: conv2 A operands
+        off_ones = off_w + 36 * 1024;
+        off_zero = off_ones + 16;
+        off_bias = off_zero + 16;              // [h][16] float: conv2 bias in accumulator order
+        total = off_bias + 128;
+    }
+};
+
+#ifndef RML_RF_ABL
+#define RML_RF_ABL 0        // experiment builds only: 2 = no convert/relu, 3 = no stores
+#endif
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <bool INBF>
+__global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = a.H, W = a.W, OH2 = H / 4, OW2 = W / 4, P = OH2 * OW2;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const RfLayout L(H, W);
+    const int RSB = L.RSB;
+    const int off_ones = (int)L.off_ones, off_zero = (int)L.off_zero;
+    unsigned char* const plane = smem + wave * L.plane;
+    for (uint32_t i = tid; i < (L.total >> 4); i += 64 * RF_WAVES) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 4) reinterpret_cast<uint32_t*>(smem + off_ones)[tid] = 0x3F803F80u;
+
+    constexpr int QE = INBF ? 8 : 4;            // elements per 16-byte quad of a plane row
+    const int WQ = W / QE, nquad = H * WQ;
+    const int NT = (P + 31) >> 5;
+    const int incr = 32 / OW2, incc = 32 - incr * OW2;
+    const int pr0 = n / OW2, pc0 = n - pr0 * OW2;
+    const int64_t sstride = (int64_t)gridDim.x * RF_WAVES;
+
+    for (int br = 0; br < 3; ++br) {
+        __syncthreads();                        // every wave is done with the previous branch's weights
+        // conv2 weights in operand order: block (tap t, k-step s = 2 ct + half), lane (cout m, k-group h) holds input
+        // channels 32 ct + 16 half + 8 (i / 4) + 4 h + i % 4, i = 0..7 -- the order the conv1 accumulators come in
+        for (int i = tid; i < 36 * 64; i += 64 * RF_WAVES) {
+            const int blk = i >> 6, l = i & 63, t = blk >> 2, s = blk & 3;
+            const uint16_t* g = a.w2t + ((size_t)br * C2 + (l & 31)) * K2 + t * 64 + 16 * s + 4 * (l >> 5);
+            const uint2 lo = *reinterpret_cast<const uint2*>(g), hi = *reinterpret_cast<const uint2*>(g + 8);
+            *reinterpret_cast<uint4*>(smem + L.off_w + i * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        if (tid < 32) reinterpret_cast<float*>(smem + L.off_bias)[tid] = a.b2[br * C2 + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4) + (tid & 3)];
+        __syncthreads();
+        bf16x8 w1f[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* wr_ = a.w1 + ((size_t)br * C1 + ct * 32 + n) * KTAPS;
+            const float bias = a.b1[br * C1 + ct * 32 + n];
+            uint4 u;
+            if (h == 0) u = make_uint4(pk_bf16(wr_[0], wr_[1]), pk_bf16(wr_[2], 0.f), pk_bf16(wr_[3], wr_[4]), pk_bf16(wr_[5], 0.f));
+            else u = make_uint4(pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[8], 0.f), pk_bf16(bias, 0.f), 0u);
+            w1f[ct] = *reinterpret_cast<bf16x8*>(&u);
+        }
+        const unsigned char* wl = smem + L.off_w + lane * 16;
+        const f32x4* biasl = reinterpret_cast<const f32x4*>(smem + L.off_bias + h * 64);
+
+        for (int64_t b = (int64_t)blockIdx.x * RF_WAVES + wave; b < a.B; b += sstride) {
+            // ---- the wave's plane: [0,H) x [0,W) of its LDS region (the border stays zero)
+            {
+                const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(
+                    static_cast<const unsigned char*>(a.in[br]) + b * (int64_t)H * W * (INBF ? 2 : 4));
+#pragma unroll 4
+                for (int i = lane; i < nquad; i += 64) {
+                    const int rr = i / WQ;
+                    const uint4 v = src4[i];
+                    uint2* d = reinterpret_cast<uint2*>(plane + rr * RSB + (i - rr * WQ) * QE * 2);      // rows are 8-byte aligned
+                    if (INBF) { d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w); }
+                    else d[0] = make_uint2(pk_bf16(__uint_as_float(v.x), __uint_as_float(v.y)), pk_bf16(__uint_as_float(v.z), __uint_as_float(v.w)));
+                }
+            }
+            int pr = pr0, pc = pc0;
+            // the lane's 32 bytes of a pixel's feature row: channels 16 h .. 16 h + 15 of this branch
+            uint16_t* dst = a.feat + (b * (int64_t)P + n) * 96 + br * 32 + 16 * h;
+            for (int tile = 0; tile < NT; ++tile) {
+                // ---- addresses of this tile's windows
+                const bool live = tile * 32 + n < P;
+                const int prc = live ? pr : OH2 - 1, pcc = live ? pc : OW2 - 1;
+                const bool lastrow = prc == OH2 - 1, lastcol = pcc == OW2 - 1;
+                const int base0 = (int)(wave * L.plane) + (4 * prc + 2 * h) * RSB + 8 * pcc;
+                // a: window rows r0 (r2 in k-group 1); b: r1 (the bias's 1.0 / 0.0); index = ky.  The kx = 1 windows start
+                // 4 bytes off the 8-byte grid: dword reads at a1, a2 and b1, b1b
+                int a0[3], a1[3], a2[3], b0[3], b1[3], b1b[3], b2[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    a0[ky] = base0 + 2 * ky * RSB;
+                    a1[ky] = opaque(a0[ky] + 4);
+                    a2[ky] = opaque(a0[ky] + 8);
+                    const bool zr = ky == 2 && lastrow;
+                    b0[ky] = h ? (zr ? off_zero : off_ones) : a0[ky] + RSB;
+                    b1[ky] = opaque(b0[ky] + 4);
+                    b1b[ky] = opaque(b0[ky] + 8);
+                    b2[ky] = opaque(h ? ((zr || lastcol) ? off_zero : off_ones) : a0[ky] + RSB + 8);
+                }
+                auto gather = [&](int t) -> bf16x8 {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    uint4 u;
+                    if (kx == 1) {
+                        u.x = *reinterpret_cast<const uint32_t*>(smem + a1[ky]);
+                        u.y = *reinterpret_cast<const uint32_t*>(smem + a2[ky]);
+                        u.z = *reinterpret_cast<const uint32_t*>(smem + b1[ky]);
+                        u.w = *reinterpret_cast<const uint32_t*>(smem + b1b[ky]);
+                    } else {
+                        const uint2 a_ = *reinterpret_cast<const uint2*>(smem + (kx == 2 ? a2[ky] : a0[ky]));
+                        const uint2 b_ = *reinterpret_cast<const uint2*>(smem + (kx == 2 ? b2[ky] : b0[ky]));
+                        u = make_uint4(a_.x, a_.y, b_.x, b_.y);
+                    }
+                    return *reinterpret_cast<bf16x8*>(&u);
+                };
+                auto conv1 = [&](int ct, const bf16x8& w) -> f32x16 {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct], w, z, 0, 0, 0);
+                };
+                auto cvt = [&](const f32x16& c, bf16x8& p0, bf16x8& p1) {
+#if RML_RF_ABL == 2
+                    uint4 v0 = make_uint4(__float_as_uint(c[0]), __float_as_uint(c[2]), __float_as_uint(c[4]), __float_as_uint(c[6]));
+                    uint4 v1 = make_uint4(__float_as_uint(c[8]), __float_as_uint(c[10]), __float_as_uint(c[12]), __float_as_uint(c[14]));
+                    p0 = *reinterpret_cast<bf16x8*>(&v0); p1 = *reinterpret_cast<bf16x8*>(&v1);
+                    return;
+#endif
+                    uint4 u0 = make_uint4(pk_relu(pk_bf16(c[0], c[1])), pk_relu(pk_bf16(c[2], c[3])), pk_relu(pk_bf16(c[4], c[5])), pk_relu(pk_bf16(c[6], c[7])));
+                    uint4 u1 = make_uint4(pk_relu(pk_bf16(c[8], c[9])), pk_relu(pk_bf16(c[10], c[11])), pk_relu(pk_bf16(c[12], c[13])), pk_relu(pk_bf16(c[14], c[15])));
+                    p0 = *reinterpret_cast<bf16x8*>(&u0);
+                    p1 = *reinterpret_cast<bf16x8*>(&u1);
+                };
+                auto wread = [&](int t, bf16x8 (&w)[4]) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) w[s] = *reinterpret_cast<const bf16x8*>(wl + (t * 4 + s) * 1024);
+                };
+                // ---- 9 taps, software-pipelined: round t issues the conv1 MFMAs of tap t+2, the window reads of tap t+3, the
+                //      weight reads of tap t+1, the four conv2 MFMAs of tap t and the convert/relu of tap t+1: nothing issued
+                //      in a round depends on anything else issued in it
+                bf16x8 win[3];
+                win[0] = gather(0); win[1] = gather(1); win[2] = gather(2);
+                bf16x8 wq[2][4];
+                wread(0, wq[0]);
+                f32x16 c1[2][2];
+                c1[0][0] = conv1(0, win[0]); c1[0][1] = conv1(1, win[0]);
+                c1[1][0] = conv1(0, win[1]); c1[1][1] = conv1(1, win[1]);
+                f32x16 acc0, acc1;
+                {
+                    const f32x4 q0 = biasl[0], q1 = biasl[1], q2 = biasl[2], q3 = biasl[3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc0[r] = q0[r]; acc0[4 + r] = q1[r]; acc0[8 + r] = q2[r]; acc0[12 + r] = q3[r]; }
+                }
+                bf16x8 p[2][4];
+                cvt(c1[0][0], p[0][0], p[0][1]);
+                cvt(c1[0][1], p[0][2], p[0][3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 2 < 9) { c1[t & 1][0] = conv1(0, win[(t + 2) % 3]); c1[t & 1][1] = conv1(1, win[(t + 2) % 3]); }
+                    if (t + 3 < 9) win[t % 3] = gather(t + 3);
+                    if (t + 1 < 9) wread(t + 1, wq[(t + 1) & 1]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[t & 1][0], p[t & 1][0], acc0, 0, 0, 0);
+                    if (t == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0][1], p[0][1], z, 0, 0, 0);
+                    } else {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[t & 1][1], p[t & 1][1], acc1, 0, 0, 0);
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[t & 1][2], p[t & 1][2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[t & 1][3], p[t & 1][3], acc1, 0, 0, 0);
+                    if (t + 1 < 9) {
+                        cvt(c1[(t + 1) & 1][0], p[(t + 1) & 1][0], p[(t + 1) & 1][1]);
+                        cvt(c1[(t + 1) & 1][1], p[(t + 1) & 1][2], p[(t + 1) & 1][3]);
+                    }
+                    // issue order: one MFMA (32 cycles of the matrix pipe = 8 issue slots), one or two LDS reads, five or six of
+                    // the round's 32 convert / relu instructions, ...
+                    if (t + 2 < 9) {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (t + 2 < 9) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- relu, bf16; the lane pair (n, n + 32) regroups its 4 x (4 + 4) channels into 16 contiguous ones per lane
+                uint32_t d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = pk_relu(pk_bf16(acc0[2 * j] + acc1[2 * j], acc0[2 * j + 1] + acc1[2 * j + 1]));
+                const auto s00 = __builtin_amdgcn_permlane32_swap(d[0], d[4], false, false);     // channels 0-3 | 16-19 <-> 4-7 | 20-23
+                const auto s01 = __builtin_amdgcn_permlane32_swap(d[1], d[5], false, false);
+                const auto s10 = __builtin_amdgcn_permlane32_swap(d[2], d[6], false, false);     // channels 8-11 | 24-27 <-> 12-15 | 28-31
+                const auto s11 = __builtin_amdgcn_permlane32_swap(d[3], d[7], false, false);
+#if RML_RF_ABL == 3
+                if (live && d[0] == 0x12345u) {
+#else
+                if (live) {
+#endif
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
+                    *reinterpret_cast<uint4*>(dst + 8) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
+                }
+                dst += 32 * 96;
+                pr += incr; pc += incc;
+                if (pc >= OW2) { pc -= OW2; pr += 1; }
+            }
+        }
+    }
+}
+
+template <bool INBF>
+int launch_trunk_rf(const TrunkArgs& a, int num_cu, hipStream_t stream) {
+    const RfLayout L(a.H, a.W);
+    if (L.total > 160 * 1024) return RML_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk_rf<INBF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    const int64_t need = (a.B + RF_WAVES - 1) / RF_WAVES;
+    hipLaunchKernelGGL((k_dnn_trunk_rf<INBF>), dim3((unsigned)(need < num_cu ? need : num_cu)), dim3(64 * RF_WAVES), L.total, stream, a);
+    return RML_OK;
+}
+
 }  // namespace
 
 namespace {
 template <bool INBF>
 int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
     int rc = RML_ERR_UNSUPPORTED;
+    static const int which = [] { const char* e = getenv("RML_DNN_TRUNK"); return e ? atoi(e) : 1; }();      // 0: LDS-image kernel only
+    if (which) rc = launch_trunk_rf<INBF>(a, num_cu, st);
+    if (rc != RML_ERR_UNSUPPORTED) return rc;
     // (measured and dropped: a wave-specialised variant -- one 8-wave workgroup per CU, 4 producer waves doing conv1 and 4
     // consumer waves doing conv2 on a double-buffered conv1 image, one producer and one consumer per SIMD: 0.72 ms against
     // 0.675, archived as tools/exp/dnn_trunk_wave_specialised_kernel.hip.txt; and 2-row strips at three workgroups per CU -- 148 VGPRs, 49 KB LDS -- 0.78 ms against 0.69:
