@@ -691,6 +691,24 @@ def main():
             sgan_row = {"error": repr(e)[:200]}
 
     if rank == 0:
+        # second denominator of SURVEY.md §8d: what a plain device-to-device copy reaches on THIS box (read + write bytes)
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+            res["roofline"]["measured_copy_GBs"] = round(copy_gbs, 1)
+            res["roofline"]["frac_of_measured_copy"] = round(res["roofline"]["achieved"] / copy_gbs, 4)
+        except Exception:
+            pass
         line = {
             "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
