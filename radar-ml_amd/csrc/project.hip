@@ -640,7 +640,7 @@ void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
     const int64_t cap = (int64_t)num_cu * per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
     // beside a GEMM: the request is padded past half of the CU's LDS, so that the dispatcher cannot put two of these
-    // persistent workgroups on one CU (and none on another) while GEMM workgroups (72.7 KB) still fit next to one
+    // persistent workgroups on one CU (and none on another) while GEMM workgroups (69.6 KB) still fit next to one
     size_t pad = 0;
     if (pp.o.share_cu && per_cu == 1) {
         const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     const int s = lane / CPR, c = lane - s * CPR;
     const int64_t b = blockIdx.x;
     // LDS: yz [4 waves][Y][Z], xz [X][Z], xy [X*Y] (dense).  The reduction scratch of Emitter::finish lies over yz
-    // (finish synchronises before it writes): two of these workgroups and one k_svm_gemm workgroup (72.7 KB) then
+    // (finish synchronises before it writes): two of these workgroups and one k_svm_gemm workgroup (69.6 KB) then
     // fit a CU together at 64x64x128, which is what lets the fused pipeline overlap them.
     unsigned char* yz_s = lds8;
     unsigned char* xz_s = yz_s + (size_t)4 * Y * Z;

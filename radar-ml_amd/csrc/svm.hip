@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
 
     const bool rbf = (a.kernel == RML_KERNEL_RBF);
-    double* xch = svw + kTile * (1 + PT);      // [128][PT] cross-thread exchange
+    // [128][PT] cross-thread exchange, over the tile images once they are consumed: the request stays at 4 tiles + the SV table
+    // (69 632 B for three pairs; with the exchange behind the table it was 72 704 B.  Same-box A/B of the fused pipeline at
+    // 64x64x128: +2 % with the smaller request, the byte-native rows unchanged)
+    double* xch = reinterpret_cast<double*>(smem);
     if constexpr (PATH == PATH_F64) {
         // float64 accumulators: 128 x 128 x 8 B = 128 KiB, so the LDS round trip is done in two column
         // halves of 64 KiB (the waves with wc == pass own that half).  Thread t then owns sample column
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
     }
+    __syncthreads();                           // G consumed: its LDS carries the exchange between the two SV halves
     if (h == 1) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) xch[nl * PT + p] = S[p];
@@ -839,7 +843,7 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     // RML_GEMM_LDS_EXTRA pads the request (experiment knob: > 8 KB leaves one GEMM workgroup per CU, so that the
     // HBM-bound projection of the next chunk keeps its wave slots while the two overlap)
     static const size_t lds_extra = [] { const char* e = getenv("RML_GEMM_LDS_EXTRA"); long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 * 1024 ? v : 0); }();
-    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + 2 * m->PT) * sizeof(double) + lds_extra;
+    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + m->PT) * sizeof(double) + lds_extra;
     const int FT8 = (int)round_up(ga.FT, 8);
     dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
 #define RML_GEMM_CASE(PTV)                                                                                         \
