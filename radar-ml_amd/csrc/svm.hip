@@ -1233,9 +1233,13 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
     const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
+    // Byte volumes (k_project_u8_max, two workgroups per CU) take the 128x128 GEMM and the small chunks as well: its
+    // workgroups fit beside the projection's, the 256x256 kernel's time-slice the CUs with them and three chunks per 65 536
+    // frames leave the pipeline mostly filling and draining (64x64x128 uint8, same box: 6.0 -> 6.7-7.1 M frames/s).
+    const bool small_gemm = wave_proj || vdtype == RML_VOL_U8;
     const int64_t small_chunk = (int64_t)X * Y * Z <= 200000 ? 16384 : 8192;
-    const int64_t CH = (grid_ok && !wave_proj) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
-                                               : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
+    const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
+                                                : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
@@ -1284,7 +1288,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
             rml_prof_mark_gemm(ctx, aux);
             rc = run_chunk(ctx, m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
-                           /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true, /*allow_big=*/!wave_proj);
+                           /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true, /*allow_big=*/!small_gemm);
             rml_prof_mark_gemm(ctx, aux);
             if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
             if (rc) return rc;
@@ -1299,7 +1303,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            const int group = (!wave_proj && use_big_gemm(m, n, ctx->num_cu)) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            const int group = (!small_gemm && use_big_gemm(m, n, ctx->num_cu)) ? 2 : 1;      // the same decision run_chunk takes for this chunk
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
@@ -1324,7 +1328,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
-                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!wave_proj);
+                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
