@@ -1227,8 +1227,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // with a CU partition the projections run on the context's masked stream, forked from the caller's
     hipStream_t st = ctx->proj_stream ? ctx->proj_stream : caller;
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
-    // frames per chunk: 8192, or 16384 for small frames (measured: 22x31x176 +2.5 % at 16384, 64x64x128 -2 % (f32) / -10 %
-    // (uint8); 32768 is slower everywhere); RML_CHUNK overrides
+    // frames per chunk: see small_chunk below; RML_CHUNK overrides
     // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
@@ -1237,7 +1236,9 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // workgroups fit beside the projection's, the 256x256 kernel's time-slice the CUs with them and three chunks per 65 536
     // frames leave the pipeline mostly filling and draining (64x64x128 uint8, same box: 6.0 -> 6.7-7.1 M frames/s).
     const bool small_gemm = wave_proj || vdtype == RML_VOL_U8;
-    const int64_t small_chunk = (int64_t)X * Y * Z <= 200000 ? 16384 : 8192;
+    // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
+    // uint8 17.4 vs 17.7)
+    const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
     const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
