@@ -256,23 +256,25 @@ def run_workload(a, env, grid, frames, primary):
                 "algorithmic_bytes_per_frame": alg_bytes_frame}
 
     # ---- the GEMM alone (one pipeline chunk of code rows, nothing else on the GPU) ------------------------
+    #      "alone": the 128x128 kernel the pipeline runs beside the projection; "alone_large_batch": 16 384 code rows through
+    #      rml_svm_decision's own choice (the 256x256 tile), the rate a caller of decision_function on feature rows gets
     if groof is not None:
-        nb = int(min(frames_per_launch, B))
-        _, q, isum, isq, flags = rml.process_volumes(V[:nb], mode="max", scale=True, codes=True)
-        if q.stride(0) % 16 == 0:
-            for _ in range(2):
-                svc.decide_codes(q, isum, isq, flags, want_proba=True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                svc.decide_codes(q, isum, isq, flags, want_proba=True)
-            e1.record()
-            e1.synchronize()
-            alone_ms = e0.elapsed_time(e1) / 5
-            alone = 2.0 * D * M * nb / (alone_ms * 1e-3) / 1e12
-            groof["alone"] = {"frames": nb, "ms": round(alone_ms, 4), "achieved": round(alone, 1),
+        for key, nb in (("alone", int(min(frames_per_launch, B))), ("alone_large_batch", int(min(16384, B)))):
+            _, q, isum, isq, flags = rml.process_volumes(V[:nb], mode="max", scale=True, codes=True)
+            if q.stride(0) % 16 == 0:
+                for _ in range(2):
+                    svc.decide_codes(q, isum, isq, flags, want_proba=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    svc.decide_codes(q, isum, isq, flags, want_proba=True)
+                e1.record()
+                e1.synchronize()
+                alone_ms = e0.elapsed_time(e1) / 5
+                alone = 2.0 * D * M * nb / (alone_ms * 1e-3) / 1e12
+                groof[key] = {"frames": nb, "ms": round(alone_ms, 4), "achieved": round(alone, 1),
                               "frac": round(alone / I8_MFMA_PEAK_TOPS, 4)}
-        del q, isum, isq, flags
+            del q, isum, isq, flags
 
     # ---- configs[1]: the projection kernel alone (HBM-roofline check; float32 feature rows written) ------------
     proj_only = None
