@@ -76,6 +76,9 @@ typedef struct rml_linear rml_linear;
 #define RML_PATH_F32   1   /* v_mfma_f32_32x32x2_f32: opt-in, approximate (f32 accumulate, ~1e-4)     */
 #define RML_PATH_I8    2   /* v_mfma_i32_32x32x32_i8 on u8 codes, exact int32 dot products            */
 #define RML_PATH_F64   3   /* v_mfma_f64_16x16x4_f64 on widened float32 rows: libsvm-class accuracy   */
+#define RML_PATH_DIGITS 4  /* general rows as four balanced int8 digits of a 32-bit fixed-point value: ten exact
+                              digit-plane products on v_mfma_i32_32x32x32_i8 (|d(u.u)| ~ 1e-8); rows outside the
+                              model's fixed-point range take RML_PATH_F64.  RML_PATH_AUTO picks it for large batches */
 
 const char* rml_version(void);
 const char* rml_last_error(void);

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libradarml_hip.so")
 ARCH = "gfx950"
+FORCE_ALL = False
 
 
 def _hipcc():
@@ -43,8 +44,10 @@ def build(force=False, verbose=False, variant=None, defines=()):
     if variant:
         lib_out = os.path.join(HERE, "libradarml_hip_%s.so" % variant)
         return _build(lib_out, os.path.join(HERE, "build", variant), verbose, ["-D" + d for d in defines])
+    global FORCE_ALL
     if not force and not is_stale():
         return LIB
+    FORCE_ALL = bool(force)
     return _build(LIB, os.path.join(HERE, "build"), verbose, [])
 
 
@@ -54,9 +57,16 @@ def _build(LIB, objdir, verbose, extra):
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra)
     objs = []
     procs = []
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdr_t = max([os.path.getmtime(h) for h in hdrs] + [0.0])
+    stamp = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
+        # per-object staleness: project.hip alone takes minutes, the others seconds
+        if same_flags and not FORCE_ALL and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -65,6 +75,8 @@ def _build(LIB, objdir, verbose, extra):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     tmp = LIB + ".tmp"
     cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

@@ -141,6 +141,13 @@ struct rml_svm {
     double* intercept = nullptr;  // P
     double* calib = nullptr;      // 2*C (a then b)
     double* platt = nullptr;      // libsvm probA | probB (2 x kMaxP), set by rml_svm_set_platt
+    // digit path (general rows on the int8 matrix cores, svm.hip "multi-digit"): every value v is the 32-bit fixed-point
+    // number u = (v - dig_c0) / dig_s in [-1, 1), split into four balanced int8 digits; plane i of row r lives at
+    // sv_dig + (i * Mpad + r) * Dq (plane-major: the row stride stays the odd multiple of 128 B)
+    bool dig_ok = false;
+    double dig_c0 = 0, dig_s = 1;
+    int8_t* sv_dig = nullptr;     // 4 x Mpad x Dq
+    double* sv_dig_nsq = nullptr; // Mpad  ||u_sv||^2 of the quantised values
     uint32_t mask_hint = 0;
 };
 

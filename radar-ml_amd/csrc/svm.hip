@@ -62,6 +62,58 @@ constexpr int kStepBytes = 128;    // K-step bytes per row
 constexpr int kTileBytes = kTile * kStepBytes;   // 16 KiB
 constexpr int PATH_I8 = 0, PATH_F32 = 1, PATH_F64 = 2;
 
+// exp(x) for x <= 0 in float64, table-driven (Tang 1989): x = n L + r with L = ln2/64, n = 64 k + j, |r| <= L/2 = 0.0054,
+//     exp(x) = 2^k * T[j] * (1 + p(r)),   p(r) = r + r^2 (1/2 + r (1/6 + r (1/24 + r (1/120 + r/720)))),   T[j] = 2^(j/64).
+// Error: n L_hi is exact (L_hi carries 32 bits, |n| < 2^17), the reduction error is ~|n| ulp(L_lo) ~ 1e-22; the polynomial is
+// truncated at r^7/5040 < 3e-20; T[j] is correctly rounded (0.5 ulp) and T + T p is one fma (0.5 ulp) on a p computed to
+// ~1e-19 absolute: < 1.1 ulp in all, against ~1 ulp for the library routine it replaces (a degree-11 polynomial on |r| <= ln2/2
+// plus range selects: ~35 instructions and a 20-deep dependent chain per kernel value, here 17 and 12).  Arguments below
+// -1000 are clamped; v_ldexp_f64 then underflows to 0 like libm.  tab = the 64-entry table in LDS (exp_tab_init).
+__constant__ double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+constexpr int kExpTabBytes = 64 * 8;
+
+__device__ __forceinline__ void exp_tab_init(double* tab, int tid) {
+    if (tid < 64) tab[tid] = kExp2Tab[tid];
+}
+
+#ifndef RML_LIBM_EXP
+#define RML_LIBM_EXP 0      // experiment builds only: 1 = the library exp() in the epilogues
+#endif
+__device__ __forceinline__ double rml_exp_neg(double x, const double* tab) {
+#if RML_LIBM_EXP
+    return exp(x);
+#else
+    x = fmax(x, -1000.0);
+    const double nf = rint(x * 0x1.71547652b82fep+6);              // x * 64/ln2
+    double r = fma(nf, -0x1.62e42fee00000p-7, x);
+    r = fma(nf, -0x1.a39ef35793c76p-39, r);
+    const int n = (int)nf;
+    const double T = tab[n & 63];
+    double p = fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7);   // 1/720, 1/120
+    p = fma(r, p, 0x1.5555555555555p-5);                               // 1/24
+    p = fma(r, p, 0x1.5555555555555p-3);                               // 1/6
+    p = fma(r, p, 0.5);
+    p = fma(r * r, p, r);
+    return ldexp(fma(T, p, T), n >> 6);
+#endif
+}
+
 struct GemmArgs {
     const uint8_t* sv; int64_t ld_sv;     // SV operand, bytes per row
     const uint8_t* x;  int64_t ld_x;      // sample operand, bytes per row
@@ -103,8 +155,10 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     const int64_t f0 = (int64_t)ftile * kTile;
     const int64_t m0 = (int64_t)stile * kTile;
 
-    // per-SV epilogue table in LDS: [128][1+PT] float64
+    // per-SV epilogue table in LDS: [128][1+PT] float64, then the 2^(j/64) table of rml_exp_neg
     double* svw = reinterpret_cast<double*>(smem + 4 * kTileBytes);
+    const double* etab = svw + kTile * (1 + PT);
+    exp_tab_init(svw + kTile * (1 + PT), tid);
     for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
         int m = idx / (1 + PT), c = idx - m * (1 + PT);
         svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
@@ -289,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
                 if (rbf) {
                     double d2 = xt + e[0] - 2.0 * g;
                     d2 = d2 > 0.0 ? d2 : 0.0;
-                    kv = exp(-a.gs * d2);
+                    kv = rml_exp_neg(-a.gs * d2, etab);
                 } else {
                     kv = g;
                 }
@@ -366,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #if RML_GEMM_ABL == 1
             kv = d2;
 #else
-            kv = exp(-a.gs * d2);
+            kv = rml_exp_neg(-a.gs * d2, etab);
 #endif
         } else {
             kv = (PATH == PATH_I8) ? (g + xt + e[0]) * a.gs : g;
@@ -406,7 +460,11 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 constexpr int kBig = 256;
 constexpr int kBigStageBytes = 2 * kBig * kStepBytes;     // 64 KiB: [SV 256 x 128 B][samples 256 x 128 B]
 
-template <int PT>
+// STAG = 1 (round 3): the two waves of a SIMD take turns at the VMEM queue.  Waves 0-3 (one per SIMD) issue their share of
+// stage kt+1 right after the barrier, as before; their SIMD partners, waves 4-7, first run half of their MFMAs and issue
+// their share then.  A burst of all 64 DMA instructions fills the CU's VMEM queue and every wave idles in its in-order issue
+// stage (no MFMA goes out for ~800-1000 cycles per step); with two half bursts one wave of each SIMD always has MFMAs to run.
+template <int PT, int STAG = 0>
 __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -424,6 +482,8 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
     const int64_t m0 = (int64_t)stile * kBig;
 
     double* svw = reinterpret_cast<double*>(smem + 2 * kBigStageBytes);    // [256][1+PT]; rows past Mpad carry W = 0
+    const double* etab = svw + kBig * (1 + PT);
+    exp_tab_init(svw + kBig * (1 + PT), tid);
     for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
         int m = idx / (1 + PT), c = idx - m * (1 + PT);
         const bool in = m0 + m < a.Mpad;
@@ -480,9 +540,10 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
     // Tried and measured slower: issuing the stage in four slices between the MFMA groups (1.11 ms: it lands later), touching
     // the lines of stage kt+3 with one dword load per lane to make the later DMA an L2 hit (0.99 ms).
     stage(0, 0);
+    const bool late = STAG && __builtin_amdgcn_readfirstlane(tid) >= 256;      // waves 4-7: issue after the first half of the MFMAs
     for (int kt = 0; kt < a.KT; ++kt) {
         __syncthreads();                               // DMA of step kt landed and visible; other buffer free
-        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT && !late) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* sb = smem + (kt & 1) * kBigStageBytes;
         // two fragment register sets: reads of sub-step kk+1 are in flight under the MFMAs of kk
         v4i af[2][4], bf[2][2];
@@ -513,6 +574,10 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
 #endif
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (STAG && kk == 1) {
+                if (late && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -551,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
             if (rbf) {
                 double d2 = xt + e[0] - 2.0 * g;
                 d2 = d2 > 0.0 ? d2 : 0.0;
-                kv = exp(-a.gs * d2);
+                kv = rml_exp_neg(-a.gs * d2, etab);
             } else {
                 kv = (g + xt + e[0]) * a.gs;
             }
@@ -573,6 +638,530 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
                 if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same tile with a deeper staging ring (round 3).  Two 64 KiB stages give the DMA of step k+1 exactly one step of
+// compute to land in, and between the end of one burst and the next barrier nothing is in flight: ~32 KiB on average, which
+// at the loaded L2 latency (~2 us) is ~19 B/clk per CU where the MFMAs want 32.  Here the ring unit is one OPERAND stage
+// (256 rows x 128 B = 32 KiB) and all 160 KiB of LDS are ring: 5 slots, operand-stage n (n = 2k: SVs of step k, 2k+1:
+// samples of step k) lives in slot n % 5.  At the barrier of step k the two slots of step k-1 are free and take stages
+// 2k+3 and 2k+4, so a stage has 1.5 steps to land and 64-96 KiB are in flight for most of a step.  Waves wait with a counted
+// s_waitcnt vmcnt(4) (everything but the newest stage, 4 DMA instructions per wave) and meet at a raw s_barrier --
+// __syncthreads() would drain the DMA queue.  The per-SV epilogue table moves out of the K loop's LDS: it is loaded after
+// the loop into slot 4 (the epilogue's G image takes slots 0-3).
+// ------------------------------------------------------------------------------------------
+constexpr int kOpStageBytes = kBig * kStepBytes;          // 32 KiB
+constexpr int kRingSlots = 5;
+
+// ILV = 1: the eight DMA instructions a wave issues per step are spread between its MFMA groups instead of going out in one
+// burst after the barrier.  A burst fills the CU's VMEM queue (64 KiB from 8 waves at once), every wave then sits in its
+// in-order issue stage for ~800-1000 cycles and no MFMA is issued meanwhile: step = burst + 2048 MFMA cycles.  Spread out, a
+// DMA instruction's issue time hides under the other wave's MFMAs -- which the two-stage kernel cannot afford (a late issue
+// is a late landing there: measured slower), and the ring can: the sample stage of step k+1 goes out in the first half of
+// step k, the SV stage of step k+2 in the second half.
+template <int PT, int ILV>
+__global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int FT2 = (a.FT + 1) >> 1;
+    const int XPX = (FT2 + 7) >> 3;
+    const int ftile = (slot % XPX) * 8 + xcd;
+    const int stile = slot / XPX;
+    if (ftile >= FT2) return;
+    if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kBig;
+    const int64_t m0 = (int64_t)stile * kBig;
+
+    const uint8_t* gsv[4];
+    const uint8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        int64_t mr = m0 + r; mr = mr < a.sv_rows ? mr : a.sv_rows - 1;
+        gsv[q] = a.sv + mr * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    // issue cursor: next operand stage n to issue and its slot
+    int ni = 0, si = 0;
+    const int nstages = 2 * a.KT;
+    auto issue = [&]() {
+        unsigned char* base = smem + si * kOpStageBytes + wave * 4096;
+        const int64_t ko = (int64_t)(ni >> 1) * kStepBytes;
+        if (ni & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16(gx[q] + ko, base + q * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16(gsv[q] + ko, base + q * 1024);
+        }
+        ++ni; si = si + 1 == kRingSlots ? 0 : si + 1;
+    };
+
+    int aoff[4], asw[4], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int ra = wr * 128 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        boff[t] = rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    issue(); issue(); issue();                          // SV_0, X_0, SV_1
+    int sa = 0;                                         // slot of the SV stage of the step being computed
+    if constexpr (ILV == 0) {
+    for (int kt = 0; kt < a.KT; ++kt) {
+        // stages 2kt and 2kt+1 landed: everything this wave issued except the newest stage (2kt+2, when it exists)
+        if (kt + 1 < a.KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // ... for every wave's pieces; and step kt-1 is consumed by everyone
+        asm volatile("" ::: "memory");
+        if (ni < nstages) issue();
+        if (ni < nstages) issue();
+        const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
+        const unsigned char* pa = smem + sa * kOpStageBytes;
+        const unsigned char* pb = smem + sbx * kOpStageBytes;
+        sa = sa + 2 >= kRingSlots ? sa + 2 - kRingSlots : sa + 2;
+        v4i af[2][4], bf[2][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((chalf ^ asw[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((chalf ^ bsw[t]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int ch = 2 * (kk + 1) + chalf;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((ch ^ asw[t]) << 4));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    } else {
+    // interleaved issue: step kt sends the sample stage of step kt+1 (slot (2kt+3) % 5) in its first half and the SV stage of
+    // step kt+2 (slot (2kt+4) % 5) in its second half, one DMA instruction after every four MFMAs
+    int sx = 3, ss = 4;                                 // slots of those two stages at kt = 0
+    auto step = [&](int kt, auto hx_, auto hs_) {
+        constexpr bool HX = decltype(hx_)::value, HS = decltype(hs_)::value;
+        if constexpr (HX) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
+        const unsigned char* pa = smem + sa * kOpStageBytes;
+        const unsigned char* pb = smem + sbx * kOpStageBytes;
+        sa = sa + 2 >= kRingSlots ? sa + 2 - kRingSlots : sa + 2;
+        unsigned char* dx = smem + sx * kOpStageBytes + wave * 4096;
+        unsigned char* dsv = smem + ss * kOpStageBytes + wave * 4096;
+        sx = sx + 2 >= kRingSlots ? sx + 2 - kRingSlots : sx + 2;
+        ss = ss + 2 >= kRingSlots ? ss + 2 - kRingSlots : ss + 2;
+        const int64_t kox = (int64_t)(kt + 1) * kStepBytes, kos = (int64_t)(kt + 2) * kStepBytes;
+        v4i af[2][4], bf[2][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((chalf ^ asw[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((chalf ^ bsw[t]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int ch = 2 * (kk + 1) + chalf;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((ch ^ asw[t]) << 4));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int g = 2 * kk + half;            // DMA instruction 0..7 of this step
+                if (g < 4) { if constexpr (HX) glds16(gx[g] + kox, dx + g * 1024); }
+                else       { if constexpr (HS) glds16(gsv[g - 4] + kos, dsv + (g - 4) * 1024); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < a.KT; ++kt) step(kt, T_{}, T_{});
+    if (kt + 1 < a.KT) { step(kt, T_{}, F_{}); ++kt; }
+    if (kt < a.KT) step(kt, F_{}, F_{});
+    }
+
+    // ---- epilogue (as k_svm_gemm_i8_256; the SV table is loaded now, into slot 4) ----
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    double* svw = reinterpret_cast<double*>(smem + 4 * kOpStageBytes);     // [256][1+PT] + exp table
+    const double* etab = svw + kBig * (1 + PT);
+    __syncthreads();                                   // every wave is done with the ring
+    exp_tab_init(svw + kBig * (1 + PT), tid);
+    for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        const bool in = m0 + m < a.Mpad;
+        svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
+    }
+    int* gl = reinterpret_cast<int*>(smem);
+    const int nl = tid & 127, h = tid >> 7;
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if ((wc >> 1) == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                        const int nn = (wc & 1) * 64 + j * 32 + (lane & 31);
+                        gl[ml * kTile + nn] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        const int64_t n = f0 + pass * kTile + nl;
+        const int64_t nc = n < a.N ? n : a.N - 1;
+        const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+        double S[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = 0.0;
+        const int* gcol = gl + nl;
+#pragma unroll 2
+        for (int mm = 0; mm < 64; ++mm) {
+            const int ml = h * 64 + mm;
+            const double* e = svw + ml * (1 + PT);
+            const double g = (double)gcol[ml * kTile];
+            double kv;
+            if (rbf) {
+                double d2 = xt + e[0] - 2.0 * g;
+                d2 = d2 > 0.0 ? d2 : 0.0;
+                kv = rml_exp_neg(-a.gs * d2, etab);
+            } else {
+                kv = (g + xt + e[0]) * a.gs;
+            }
+#pragma unroll
+            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+        }
+        __syncthreads();
+        double* x4 = reinterpret_cast<double*>(smem);  // [4][128][PT]
+#pragma unroll
+        for (int p = 0; p < PT; ++p) x4[(h * kTile + nl) * PT + p] = S[p];
+        __syncthreads();
+        if (h == 0 && n < a.N) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                double t = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
+                t += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
+                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
+                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// General rows on the int8 matrix cores: "multi-digit" exact products (SURVEY 8 a-5 for data that is not on the code
+// grid: train.py:496-517 augmentation, a non-unit proj_zoom of predict.py:109-116, the reference's generated_data pickles).
+//
+// Every value v (sample feature or SV component) is read as the 32-bit fixed-point number u = (v - c0) / s in [-1, 1)
+// (c0, s per model; s a power of two, so float32 inputs >= s 2^-8 are represented exactly and smaller ones to 2^-32 s),
+// I = rint(u 2^31), split into four BALANCED int8 digits  I = a0 2^24 + a1 2^16 + a2 2^8 + a3,  a_i in [-128, 127].  Then
+//     u_x . u_s = 2^-14 sum_{i,j} 2^-8(i+j) (a_i^x . a_j^s)
+// and every digit-plane product is an exact int32 GEMM on v_mfma_i32_32x32x32_i8 (|.| <= 2^14 K < 2^29).  The ten pairs with
+// i + j <= 3 are kept (the dropped ones weigh 2^-46 per digit product: typical 1e-8 on u.u), grouped by
+// g = i + j and accumulated from the least significant group up IN THE SAME int32 accumulator: after a group the
+// accumulator is divided by 256 with rounding, (acc + 128) >> 8, and keeps accumulating the next group on top (4 x 2^28.3
+// < 2^31).  Before the most significant group the running value is split acc = 256 q + r: q stays in the accumulator, the
+// 8-bit remainders r are packed four to a register (32 VGPRs), so that u.u = 2^-22 (256 (G0 + q) + r) carries 2^-22
+// absolute precision on a quantity of magnitude <= D/4 -- the arithmetic class of the float64 path at ~2.4x its rate.
+// d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED values in float64, so d^2 is the exact
+// squared distance of two slightly (<= 2^-32 s) moved points.
+// Same tile, staging and wave layout as k_svm_gemm_i8_256; the K loop runs over (pair, K-step).
+// ------------------------------------------------------------------------------------------
+constexpr int kDigPairs = 10;
+constexpr uint64_t kDigI = 0x0102103210ull;     // nibble p: sample digit of pair p   (0 = most significant)
+constexpr uint64_t kDigJ = 0x0010120123ull;     // nibble p: SV digit of pair p
+
+struct DigArgs {
+    const int8_t* sv; int64_t sv_plane;       // SV digit planes, bytes between planes (Mpad * Dq)
+    const int8_t* x;  int64_t x_plane;        // sample digit planes, bytes between planes
+    int64_t ld;                               // bytes per row (both operands)
+    int KT;
+    int64_t N; int64_t Mpad; int ST, FT;      // ST / FT count 128-row tiles like GemmArgs
+    const int32_t* tile_exact; int want;
+    const double* x_nsq; const double* sv_nsq;
+    const double* W;
+    double gs;                                // gamma * s^2
+    double* partial; int64_t Npart;
+};
+
+template <int PT>
+__global__ __launch_bounds__(512, 2) void k_svm_gemm_dig(DigArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int FT2 = (a.FT + 1) >> 1;
+    const int XPX = (FT2 + 7) >> 3;
+    const int ftile = (slot % XPX) * 8 + xcd;
+    const int stile = slot / XPX;
+    if (ftile >= FT2) return;
+    if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kBig;
+    const int64_t m0 = (int64_t)stile * kBig;
+
+    double* svw = reinterpret_cast<double*>(smem + 2 * kBigStageBytes);    // [256][1+PT]; rows past Mpad carry W = 0
+    const double* etab = svw + kBig * (1 + PT);
+    exp_tab_init(svw + kBig * (1 + PT), tid);
+    for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        const bool in = m0 + m < a.Mpad;
+        svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_nsq[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
+    }
+
+    const int8_t* gsv[4];
+    const int8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        int64_t mr = m0 + r; mr = mr < a.Mpad ? mr : a.Mpad - 1;
+        gsv[q] = a.sv + mr * a.ld + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld + c * 16;
+    }
+    // staging cursor: (pair ps, K-step ks), one step ahead of the compute cursor
+    int ps = 0, ks = 0;
+    int64_t so = (int64_t)((kDigJ >> 0) & 15) * a.sv_plane, xo = (int64_t)((kDigI >> 0) & 15) * a.x_plane;
+    auto stage = [&](int buf) {
+        unsigned char* base = smem + buf * kBigStageBytes;
+        const int64_t ko = (int64_t)ks * kStepBytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gsv[q] + so + ko, base + (wave * 4 + q) * 1024);
+            glds16(gx[q] + xo + ko, base + kBig * kStepBytes + (wave * 4 + q) * 1024);
+        }
+        if (++ks == a.KT) {
+            ks = 0; ++ps;
+            so = (int64_t)((kDigJ >> (4 * ps)) & 15) * a.sv_plane;
+            xo = (int64_t)((kDigI >> (4 * ps)) & 15) * a.x_plane;
+        }
+    };
+
+    int aoff[4], asw[4], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int ra = wr * 128 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        boff[t] = kBig * kStepBytes + rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    // one K-step: wait for its stage, start the next one, 32 MFMAs with the fragment reads of sub-step kk+1 under those of kk
+    int tb = 0;                                        // stage buffer of the step being computed
+    auto kstep = [&](bool more) {
+        __syncthreads();                               // DMA of this step landed and visible; other buffer free
+        if (more) stage(tb ^ 1);
+        const unsigned char* sb = smem + tb * kBigStageBytes;
+        v4i af[2][4], bf[2][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) af[0][u] = *reinterpret_cast<const v4i*>(sb + aoff[u] + ((chalf ^ asw[u]) << 4));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bf[0][u] = *reinterpret_cast<const v4i*>(sb + boff[u] + ((chalf ^ bsw[u]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int ch = 2 * (kk + 1) + chalf;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    af[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(sb + aoff[u] + ((ch ^ asw[u]) << 4));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    bf[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(sb + boff[u] + ((ch ^ bsw[u]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tb ^= 1;
+    };
+    auto shift8 = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
+    };
+    stage(0);
+    // groups g = 3 (pairs 0-3), g = 2 (4-6), g = 1 (7-8): the remainders do not exist yet, so they cost no registers here
+    for (int t = 0; t < 4 * a.KT; ++t) kstep(true);
+    shift8();
+    for (int t = 0; t < 3 * a.KT; ++t) kstep(true);
+    shift8();
+    for (int t = 0; t < 2 * a.KT; ++t) kstep(true);
+    int rem[32];                                       // 8-bit remainders of the split before the top group, four to a register
+#pragma unroll
+    for (int r = 0; r < 32; ++r) rem[r] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = acc[i][j][r];
+                rem[(i * 2 + j) * 4 + (r >> 2)] |= (v & 255) << (8 * (r & 3));
+                acc[i][j][r] = v >> 8;
+            }
+    // group g = 0 (pair 9)
+    for (int t = 0; t < a.KT; ++t) kstep(t + 1 < a.KT);
+
+    // ---- float64 epilogue: one 64-sample quarter (= one wave column wc) at a time through LDS as float64 ----
+    // u.u = 2^-22 (256 acc + rem);  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u.u);  a.gs = gamma s^2
+    double* gd = reinterpret_cast<double*>(smem);      // [256 SVs][64 samples]
+    const int nq = tid & 63, qd = tid >> 6;            // sample column of the quarter, SV group (32 rows)
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wc == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                        const int nn = j * 32 + (lane & 31);
+                        const int rb = (rem[(i * 2 + j) * 4 + (r >> 2)] >> (8 * (r & 3))) & 255;
+                        gd[ml * 64 + nn] = ((double)acc[i][j][r] * 256.0 + (double)rb) * 0x1p-22;
+                    }
+        }
+        __syncthreads();
+        const int64_t n = f0 + pass * 64 + nq;
+        const int64_t nc = n < a.N ? n : a.N - 1;
+        const double xt = a.x_nsq[nc];
+        double S[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = 0.0;
+#pragma unroll 2
+        for (int mm = 0; mm < 32; ++mm) {
+            const int ml = qd * 32 + mm;
+            const double* e = svw + ml * (1 + PT);
+            double d2 = xt + e[0] - 2.0 * gd[ml * 64 + nq];
+            d2 = d2 > 0.0 ? d2 : 0.0;
+            const double kv = rml_exp_neg(-a.gs * d2, etab);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+        }
+        __syncthreads();                               // G quarter consumed: reuse its LDS for the exchange
+        double* x8 = gd;                               // [8 groups][64][PT]
+#pragma unroll
+        for (int p = 0; p < PT; ++p) x8[(qd * 64 + nq) * PT + p] = S[p];
+        __syncthreads();
+        if (qd == 0 && n < a.N) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                double t = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) t += x8[(g * 64 + nq) * PT + p];
+                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
+                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+            }
+        }
+    }
+}
+
+// digit planes of float32 rows: one workgroup per row, a thread takes 4 consecutive features per step.
+// ok[row] = every feature is finite and inside the model's fixed-point range.
+__global__ __launch_bounds__(256) void k_digit_rows(const float* f32, int64_t ld, int64_t D, int64_t Dq, int64_t plane, int8_t* dig,
+                                                    double* nsq, int32_t* ok, double c0, double k31, const int32_t* skip_if_set) {
+    if (skip_if_set && *skip_if_set) return;
+    __shared__ double redn[4];
+    __shared__ int redo[4];
+    const int64_t b = blockIdx.x;
+    double nn = 0.0; int good = 1;
+    for (int64_t i4 = (int64_t)threadIdx.x * 4; i4 < Dq; i4 += 1024) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t idx = i4 + e;
+            uint32_t packed = 0;
+            if (idx < D) {
+                const double t = rint(((double)f32[b * ld + idx] - c0) * k31);
+                const bool in = t >= -2147483648.0 && t <= 2139062143.0;       // NaN fails both
+                good &= in ? 1 : 0;
+                const int I = in ? (int)t : 0;
+                const double u = (double)I * 0x1p-31;
+                nn = fma(u, u, nn);
+                packed = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;           // bytes = balanced digits a0 (top) .. a3
+            }
+            pk[e] = packed;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int sh = 8 * (3 - d);
+            const uint32_t w = ((pk[0] >> sh) & 255u) | (((pk[1] >> sh) & 255u) << 8) | (((pk[2] >> sh) & 255u) << 16) | (((pk[3] >> sh) & 255u) << 24);
+            *reinterpret_cast<uint32_t*>(dig + (int64_t)d * plane + b * Dq + i4) = w;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { nn += __shfl_xor(nn, off); good &= __shfl_xor(good, off); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { redn[wave] = nn; redo[wave] = good; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nsq[b] = (redn[0] + redn[1]) + (redn[2] + redn[3]);
+        ok[b] = redo[0] & redo[1] & redo[2] & redo[3];
     }
 }
 
@@ -640,6 +1229,35 @@ __global__ __launch_bounds__(256) void k_tile_flags(const int32_t* flags, int64_
         for (int g = 0; g < group; ++g) if (ft0 + g < FT) tile_exact[ft0 + g] = e;
         if (!e && all_exact) atomicAnd(all_exact, 0);
     }
+}
+
+// second decision, once the digit planes of a chunk exist: a tile group that is not on the code grid (tile_exact == 0) goes
+// to the multi-digit int8 GEMM (tile_exact = 2) when every one of its rows fits the model's fixed-point range
+__global__ __launch_bounds__(256) void k_tile_dig(const int32_t* dflags, int64_t N, int FT, int32_t* tile_exact, const int32_t* skip_if_set) {
+    if (skip_if_set && *skip_if_set) return;
+    const int ft0 = blockIdx.x * 2;
+    const int64_t r = (int64_t)ft0 * kTile + threadIdx.x;
+    const int mine = (r < N) ? (dflags[r] != 0) : 1;
+    const int e = __syncthreads_and(mine);
+    if (threadIdx.x == 0 && e && tile_exact[ft0] == 0) {
+        tile_exact[ft0] = 2;
+        if (ft0 + 1 < FT) tile_exact[ft0 + 1] = 2;
+    }
+}
+
+// the multi-digit kernel for the general tiles of a chunk of n rows?  RML_DIGITS = 0 never, 1 always (when the model allows),
+// default: when the launch has tiles for at least half a round of one workgroup per CU (below that the float64 MFMA kernel's
+// 128 x 128 tiles fill the machine better)
+inline bool use_dig_gemm(const rml_svm* m, int policy, int64_t n, int num_cu) {
+    if (!m->dig_ok) return false;
+    if (policy == RML_PATH_DIGITS) return true;
+    if (policy != RML_PATH_AUTO) return false;
+    const char* env = getenv("RML_DIGITS");
+    const int knob = env ? atoi(env) : -1;
+    if (knob == 0) return false;
+    if (knob == 1) return true;
+    const int64_t wgs = ((n + kBig - 1) / kBig) * ((m->Mpad + kBig - 1) / kBig);
+    return wgs * 2 >= (int64_t)num_cu;
 }
 
 // does the 256x256 kernel take the exact tiles of a chunk of n rows against this model?  (enough tiles for ~2.5 rounds of
@@ -843,7 +1461,7 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     // RML_GEMM_LDS_EXTRA pads the request (experiment knob: > 8 KB leaves one GEMM workgroup per CU, so that the
     // HBM-bound projection of the next chunk keeps its wave slots while the two overlap)
     static const size_t lds_extra = [] { const char* e = getenv("RML_GEMM_LDS_EXTRA"); long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 * 1024 ? v : 0); }();
-    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + m->PT) * sizeof(double) + lds_extra;
+    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + m->PT) * sizeof(double) + kExpTabBytes + lds_extra;
     const int FT8 = (int)round_up(ga.FT, 8);
     dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
 #define RML_GEMM_CASE(PTV)                                                                                         \
@@ -870,9 +1488,41 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
 }
 
 int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
-    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double);
+    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
     const int FT2 = (ga.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
     dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
+    // RML_GEMM_RING=1: the 5-slot operand-stage ring (k_svm_gemm_i8_256r); read per call, tests and A/B runs flip it
+    const char* re = getenv("RML_GEMM_RING");
+    const int ring = re ? atoi(re) : 0;
+    if (ring == 3 && m->PT == 3) {      // experiment arm: staggered issue in the two-stage kernel
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_svm_gemm_i8_256<3, 1>), grid, block, lds, st, ga);
+        RML_HIP(hipGetLastError());
+        return RML_OK;
+    }
+    if ((ring == 1 || ring == 2) && m->PT <= 6) {
+#define RML_RING_CASE(PTV)                                                                                         \
+    case PTV: {                                                                                                    \
+        if (ring == 1) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256r<PTV, 0>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            hipLaunchKernelGGL((k_svm_gemm_i8_256r<PTV, 0>), grid, block, (size_t)kRingSlots * kOpStageBytes, st, ga); \
+        } else {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256r<PTV, 1>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            hipLaunchKernelGGL((k_svm_gemm_i8_256r<PTV, 1>), grid, block, (size_t)kRingSlots * kOpStageBytes, st, ga); \
+        }                                                                                                          \
+    } break;
+        switch (m->PT) {
+            RML_RING_CASE(1)
+            RML_RING_CASE(3)
+            RML_RING_CASE(6)
+            default: break;
+        }
+#undef RML_RING_CASE
+        RML_HIP(hipGetLastError());
+        return RML_OK;
+    }
 #define RML_BIG_CASE(PTV)                                                                                          \
     case PTV: {                                                                                                    \
         static bool attr_done = false;                                                                             \
@@ -894,6 +1544,27 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
+int launch_gemm_dig(const rml_svm* m, const DigArgs& da, hipStream_t st) {
+    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
+    const int FT2 = (da.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
+    dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
+#define RML_DIG_CASE(PTV)                                                                                          \
+    case PTV: {                                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_dig<PTV>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        hipLaunchKernelGGL((k_svm_gemm_dig<PTV>), grid, block, lds, st, da);                                       \
+    } break;
+    switch (m->PT) {
+        RML_DIG_CASE(1)
+        RML_DIG_CASE(3)
+        RML_DIG_CASE(6)
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the multi-digit kernel");
+    }
+#undef RML_DIG_CASE
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 // Rows per chunk of the chunked front doors.  With an exact model the chunk is sized for the 256x256 kernel: among
 // 8192..32768 rows the size whose tile count fills whole rounds of one workgroup per CU best (>= 2.5 rounds); otherwise
 // `fallback` (the round-1 choice for the 128x128 kernel).  RML_CHUNK overrides.
@@ -903,11 +1574,11 @@ int64_t pick_chunk_env(int64_t fallback) {
     return v >= 128 ? round_up(v, kTile) : fallback;
 }
 
-int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu) {
+int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu, bool dig = false) {
     const int64_t env = pick_chunk_env(0);
     int64_t ch = fallback;
     if (env) ch = env;
-    else if (m->exact && use_big_gemm(m, 32768, num_cu)) {
+    else if (dig || (m->exact && use_big_gemm(m, 32768, num_cu))) {
         const int64_t st2 = (m->Mpad + kBig - 1) / kBig;
         double best = 0.0;
         for (int64_t c = 8192; c <= 32768; c += 2048) {
@@ -924,10 +1595,11 @@ int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu)
 struct ChunkWs {
     uint8_t* q; float* f32; int32_t* isum; int64_t* isq; double* nsq; int32_t* flags;
     int32_t* tile_exact; int32_t* all_exact; double* partial;
+    int8_t* dig; int64_t dig_plane; double* dnsq; int32_t* dflags;      // multi-digit operand of the general rows (or NULL)
     size_t bytes;
 };
 
-ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32) {
+ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32, bool need_dig = false) {
     ChunkWs w{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return base ? base + o : (unsigned char*)nullptr; };
@@ -940,6 +1612,11 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     w.tile_exact = (int32_t*)take((size_t)(CH / kTile + 1) * 4);
     w.all_exact = (int32_t*)take(256);
     w.partial = (double*)take((size_t)(m->Mpad / kTile) * CH * m->PT * 8);
+    w.dig_plane = CH * m->Dq;
+    w.dig = (int8_t*)take(need_dig ? (size_t)4 * CH * m->Dq : 0);
+    w.dnsq = (double*)take(need_dig ? (size_t)CH * 8 : 0);
+    w.dflags = (int32_t*)take(need_dig ? (size_t)CH * 4 : 0);
+    if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; }
     w.bytes = off;
     return w;
 }
@@ -960,7 +1637,8 @@ struct DecisionOut {
 // GEMM(s) + finish for one chunk whose operands are already in place.
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
-              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true) {
+              bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true,
+              bool dig_ready = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -970,10 +1648,14 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
     const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, ctx->num_cu);
+    // general tiles whose rows fit the model's fixed-point range go to the multi-digit int8 kernel (digit planes in w.dig)
+    const bool run_dig = dig_ready && w.dig && run_gen && !gen_f32 && !kmat && m->dig_ok;
     if (!tiles_done) {
-        const int group = big ? 2 : 1;
+        const int group = (big || run_dig) ? 2 : 1;
         hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, flags, n, FT,
                            run_i8 ? (run_gen ? 0 : 2) : 1, (int)m->exact, w.tile_exact, (int32_t*)nullptr, group);
+        if (run_dig)
+            hipLaunchKernelGGL(k_tile_dig, dim3((FT + 1) / 2), dim3(256), 0, st, w.dflags, n, FT, w.tile_exact, (const int32_t*)nullptr);
     }
     GemmArgs ga{};
     // all_exact_known: every row is on the code grid by construction (uint8 volumes): no tile predicate at all
@@ -986,6 +1668,15 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
         int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st));
+        if (rc) return rc;
+    }
+    if (run_dig) {
+        DigArgs da{};
+        da.sv = m->sv_dig; da.sv_plane = m->Mpad * m->Dq; da.x = w.dig; da.x_plane = w.dig_plane; da.ld = m->Dq;
+        da.KT = (int)(m->Kq / kStepBytes); da.N = n; da.Mpad = m->Mpad; da.ST = ST; da.FT = FT;
+        da.tile_exact = w.tile_exact; da.want = 2; da.x_nsq = w.dnsq; da.sv_nsq = m->sv_dig_nsq; da.W = m->W;
+        da.gs = m->gamma * m->dig_s * m->dig_s; da.partial = w.partial; da.Npart = n;
+        int rc = launch_gemm_dig(m, da, st);
         if (rc) return rc;
     }
     if (run_gen) {
@@ -1083,6 +1774,43 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
     // the int8 MFMA accumulates sum (a-128)(b-128) in int32: |.| <= 128^2 * K must stay below 2^31
     if (m->Kq >= 131072) exact = false;
     m->exact = exact;
+    // multi-digit frame for general rows: u = (v - c0) / s with s the power of two >= the SV value range (SVs then sit in
+    // [-1/2, 1/2] + rounding of c0; rows may leave the SV range by s/2 on either side before they fall back to float64) and
+    // c0 the mid-range on a grid of s/256 (so that v - c0 is exact in float64 for float32 v).  Four digit groups share one
+    // int32 accumulator: 4 * 128^2 * K < 2^31.
+    std::vector<int8_t> svd;
+    std::vector<double> dnsq;
+    if (kernel == RML_KERNEL_RBF && m->Kq < 32768 && m->PT <= 6) {
+        double lo = sv[0], hi = sv[0];
+        bool finite = true;
+        for (size_t i = 0; i < (size_t)M * D; ++i) { const double v = sv[i]; finite &= std::isfinite(v); lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        if (finite && hi > lo) {
+            int e = 0;
+            (void)frexp(hi - lo, &e);                             // hi - lo = f 2^e, f in [0.5, 1)
+            double sd = ldexp(1.0, e);
+            if (ldexp(1.0, e - 1) == hi - lo) sd = hi - lo;       // an exact power of two is its own scale
+            const double c0 = nearbyint(0.5 * (lo + hi) / sd * 256.0) / 256.0 * sd;
+            const double k31 = 2147483648.0 / sd;
+            svd.assign((size_t)4 * m->Mpad * m->Dq, 0);
+            dnsq.assign(m->Mpad, 0.0);
+            const size_t plane = (size_t)m->Mpad * m->Dq;
+            bool ok = true;
+            for (int64_t r = 0; r < M && ok; ++r) {
+                double nn = 0.0;
+                for (int64_t d = 0; d < D; ++d) {
+                    const double t = nearbyint((sv[(size_t)r * D + d] - c0) * k31);
+                    if (!(t >= -2147483648.0 && t <= 2139062143.0)) { ok = false; break; }
+                    const int32_t I = (int32_t)t;
+                    const double u = (double)I * 0x1p-31;
+                    nn += u * u;
+                    const uint32_t pk = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;     // bytes = balanced digits, a0 on top
+                    for (int dg = 0; dg < 4; ++dg) svd[(size_t)dg * plane + (size_t)r * m->Dq + d] = (int8_t)((pk >> (8 * (3 - dg))) & 255u);
+                }
+                dnsq[r] = nn;
+            }
+            if (ok) { m->dig_ok = true; m->dig_c0 = c0; m->dig_s = sd; }
+        }
+    }
     int rc = RML_OK;
     do {
         if ((rc = dev_upload(&m->W, W))) break;
@@ -1091,6 +1819,10 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
         if (exact) {
             if ((rc = dev_upload(&m->sv_q, svq))) break;
             if ((rc = dev_upload(&m->sv_term_q, term))) break;
+        }
+        if (m->dig_ok) {
+            if ((rc = dev_upload(&m->sv_dig, svd))) break;
+            if ((rc = dev_upload(&m->sv_dig_nsq, dnsq))) break;
         }
         std::vector<double> ic(intercept, intercept + m->P);
         if ((rc = dev_upload(&m->intercept, ic))) break;
@@ -1110,7 +1842,7 @@ extern "C" int rml_svm_free(rml_ctx* ctx, rml_svm* m) {
     if (!m) return RML_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {m->sv_f32, m->sv_nsq, m->sv_q, m->sv_term_q, m->W, m->intercept, m->calib, m->platt};
+    void* bufs[] = {m->sv_f32, m->sv_nsq, m->sv_q, m->sv_term_q, m->W, m->intercept, m->calib, m->platt, m->sv_dig, m->sv_dig_nsq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete m;
     return RML_OK;
@@ -1131,7 +1863,9 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (N == 0) return RML_OK;
     RML_REQUIRE(feat || feat_q, RML_ERR_INVALID, "rml_svm_decision: need feat or feat_q");
     RML_REQUIRE(!feat || ld_feat >= m->D, RML_ERR_INVALID, "rml_svm_decision: ld_feat < D");
-    RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_F64, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
+    RML_REQUIRE(path >= RML_PATH_AUTO && path <= RML_PATH_DIGITS, RML_ERR_INVALID, "rml_svm_decision: bad path %d", path);
+    RML_REQUIRE(path != RML_PATH_DIGITS || m->dig_ok, RML_ERR_STATE, "rml_svm_decision: multi-digit path requested but the model has no digit frame "
+                "(RBF kernel, D < 32768 and at most 6 class pairs)");
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_svm_decision: model has no calibrators");
     RML_REQUIRE(path != RML_PATH_I8 || m->exact, RML_ERR_STATE, "rml_svm_decision: exact path requested but the model is not on the code grid");
     if (!feat) {
@@ -1145,14 +1879,20 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     if (N == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rml_ctx_guard guard(ctx, st);           // shared workspace
-    const int64_t CH = feat ? std::min<int64_t>(round_up(N, kTile), 8192) : pick_chunk(m, N, 8192, ctx->num_cu);
+    // float rows of a model that is not on the code grid: the multi-digit kernel when the batch fills enough 256 x 256 tiles
+    // (chunks sized for whole rounds of one workgroup per CU, like the exact 256 x 256 kernel's)
+    const bool dig = feat != nullptr && !m->exact && use_dig_gemm(m, path, N, ctx->num_cu);
+    const int64_t CH = feat ? (dig ? pick_chunk(m, N, 8192, ctx->num_cu, true) : std::min<int64_t>(round_up(N, kTile), 8192))
+                            : pick_chunk(m, N, 8192, ctx->num_cu);
     const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
-    ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32);
+    // a model on the code grid can meet general rows as well (mixed batches): digit planes then ride along with the codes
+    const bool need_dig = feat != nullptr && (dig || (m->exact && use_dig_gemm(m, path, N, ctx->num_cu)));
+    ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32, need_dig);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, probe.bytes, &ws);
     if (rc) return rc;
-    ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, need_f32);
+    ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, need_f32, need_dig);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
     const int policy = path;
     for (int64_t r0 = 0; r0 < N; r0 += CH) {
@@ -1160,8 +1900,12 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
         if (feat) {
             hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)n), dim3(256), 0, st, feat + r0 * ld_feat, ld_feat, m->D,
                                (float)m->code_scale, w.f32, m->Df, w.nsq, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags);
+            if (need_dig)
+                hipLaunchKernelGGL(k_digit_rows, dim3((unsigned)n), dim3(256), 0, st, w.f32, m->Df, m->D, m->Dq, w.dig_plane, w.dig, w.dnsq,
+                                   w.dflags, m->dig_c0, 2147483648.0 / m->dig_s, (const int32_t*)nullptr);
             RML_HIP(hipGetLastError());
-            rc = run_chunk(ctx, m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st);
+            rc = run_chunk(ctx, m, policy, n, need_q ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out.at(r0, m->C, m->P), st,
+                           false, nullptr, 0, false, true, need_dig);
         } else {
             rc = run_chunk(ctx, m, RML_PATH_I8, n, feat_q + r0 * ld_q, ld_q, row_isum + r0, row_isq + r0, row_flags ? row_flags + r0 : nullptr,
                            nullptr, nullptr, w, out.at(r0, m->C, m->P), st);
@@ -1239,14 +1983,18 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
+    // rows off the code grid: the multi-digit int8 kernel (256 x 256 tiles: chunks sized for whole rounds) where the model has a
+    // digit frame and the batch is large enough, the float64 MFMA kernel otherwise
+    const bool use_dig = vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
     const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
+                       : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
-    ChunkWs probe = carve(m, CH, nullptr, grid_ok, true);
+    ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig);
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
     if (rc) return rc;
-    ChunkWs w2[2] = {carve(m, CH, static_cast<unsigned char*>(ws), grid_ok, true),
-                     carve(m, CH, static_cast<unsigned char*>(ws) + probe.bytes, grid_ok, true)};
+    ChunkWs w2[2] = {carve(m, CH, static_cast<unsigned char*>(ws), grid_ok, true, use_dig),
+                     carve(m, CH, static_cast<unsigned char*>(ws) + probe.bytes, grid_ok, true, use_dig)};
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
     const int64_t frame_elems = (int64_t)X * Y * Z;
     hipStream_t aux = ctx->aux_stream;
@@ -1304,7 +2052,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            const int group = (!small_gemm && use_big_gemm(m, n, ctx->num_cu)) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, ctx->num_cu))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
@@ -1325,11 +2073,20 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, of, st);
         if (!grid_ok) { rml_prof_mark(ctx, st); if (ctx->profiling) ctx->prof_frames += n; }
         if (rc) return rc;
+        if (use_dig) {
+            // digit planes of the float rows (skipped with the float rows when every tile is exact); with an exact model the
+            // general tiles are re-decided here, otherwise run_chunk decides
+            hipLaunchKernelGGL(k_digit_rows, dim3((unsigned)n), dim3(256), 0, st, w.f32, m->Df, m->D, m->Dq, w.dig_plane, w.dig, w.dnsq,
+                               w.dflags, m->dig_c0, 2147483648.0 / m->dig_s, of.skip_if_set);
+            if (grid_ok)
+                hipLaunchKernelGGL(k_tile_dig, dim3((FT + 1) / 2), dim3(256), 0, st, w.dflags, n, FT, w.tile_exact, of.skip_if_set);
+            RML_HIP(hipGetLastError());
+        }
         RML_HIP(hipEventRecord(ev_proj[c & 1], st));
         RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
-                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm);
+                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;

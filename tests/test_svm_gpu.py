@@ -101,6 +101,91 @@ def test_general_float_rows_vs_oracle(rml):
     assert np.abs(proba - wantp).max() <= TOL
 
 
+def _irregular_rows(rng, X, kind):
+    """Rows off the code grid the way the reference produces them: spline-resampled (train.py:96-144 zoom / rotate give
+    arbitrary float32 values, a few slightly outside [0, 1] before the clamp), sparse noise (train.py:146-160), and
+    values that are tiny next to the range (the spline tails)."""
+    X = X.astype(np.float32).copy()
+    if kind == "smooth":
+        X = X * np.float32(0.9990234375) + rng.normal(0, 1e-3, X.shape).astype(np.float32) * (X > 0)
+    elif kind == "noise":
+        mask = rng.random(X.shape) < 0.05
+        X = np.clip(X + mask * rng.normal(0, 0.05, X.shape).astype(np.float32), 0, 1).astype(np.float32)
+    elif kind == "tails":
+        X = X + (rng.random(X.shape) < 0.3) * rng.uniform(-3e-5, 3e-5, X.shape).astype(np.float32)
+    return X.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["svm_small.npz", "svm_walabot.npz"])
+@pytest.mark.parametrize("kind", ["smooth", "noise", "tails"])
+@pytest.mark.parametrize("model_on_grid", [True, False])
+def test_multi_digit_path_vs_oracle(rml, name, kind, model_on_grid):
+    """RML_PATH_DIGITS: general rows as four int8 digits of a 32-bit fixed-point value, ten exact digit-plane GEMMs
+    (csrc/svm.hip k_svm_gemm_dig) against the float64 oracle on the same float32 rows: decision values within 1e-5
+    (measured ~1e-8), labels bit-exact, at D = 368 and D = 10 010 (the Walabot grid)."""
+    g = load_golden(name)
+    m = svm_model_arrays(g)
+    rng = np.random.default_rng(11)
+    sv = m["sv"]
+    if not model_on_grid:
+        sv = _irregular_rows(rng, sv, "smooth").astype(np.float64)
+    svc = rml.GpuSVC(sv, m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["classes"],
+                     calib_a=m["calib_a"], calib_b=m["calib_b"], path="digits")
+    assert svc.exact == model_on_grid
+    X = _irregular_rows(rng, np.tile(_test_rows(g, name), (3, 1))[:300], kind)
+    want = O.svm_decision_ovo(X, sv, m["dual_coef"], m["intercept"], m["n_support"], m["gamma"])
+    svc.decision_function_shape = "ovo"
+    got = svc.decision_function(X)
+    err = float(np.abs(got - want).max())
+    print("digits %s %s grid=%s: max |dec - oracle| = %.2e" % (name, kind, model_on_grid, err))
+    assert err <= 1e-6, err
+    C = len(m["classes"])
+    np.testing.assert_array_equal(svc.predict(X), m["classes"][O.svm_vote_labels(want, C)])
+    proba = rml.GpuCalibratedClassifier(svc).predict_proba(X)
+    wantp = O.calibrated_proba(O.ovr_decision_function(want, C), m["calib_a"], m["calib_b"])
+    assert np.abs(proba - wantp).max() <= TOL
+    # and the float64 MFMA path agrees with it to the digit path's own resolution
+    f64 = svc._decide(svc._rows(X), path="f64")[0].cpu().numpy()
+    assert np.abs(got - f64).max() <= 1e-6
+
+
+def test_multi_digit_rows_outside_the_fixed_point_range_fall_back(rml):
+    """A tile with a row outside the model's fixed-point frame (|v - c0| >= s) is decided by the float64 kernel; the other
+    tiles of the batch stay on the digit kernel; every row is right either way."""
+    g = load_golden("svm_small.npz")
+    m = svm_model_arrays(g)
+    svc = rml.GpuSVC(m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["classes"], path="digits")
+    rng = np.random.default_rng(3)
+    X = _irregular_rows(rng, np.tile(_test_rows(g, "svm_small.npz"), (9, 1))[:700], "smooth")
+    X[5, 7] = 3.5            # first 256-row group: out of range -> float64 kernel
+    X[600, 0] = np.float32(-0.4)   # still inside [-1, 1) * s around c0
+    want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"])
+    svc.decision_function_shape = "ovo"
+    got = svc.decision_function(X)
+    assert np.abs(got - want).max() <= 1e-6
+    assert np.abs(got[:256] - want[:256]).max() <= 1e-9        # that group went through float64 products
+
+
+def test_multi_digit_adversarial_low_digits(rml):
+    """Worst case for the dropped digit pairs (i + j >= 4): every low digit at its extreme and aligned in sign.  The
+    documented bound on |d(u.u)| is 3 * 2^-46 * 2^14 * D; the decision values must still be inside 1e-5 here."""
+    D, M, N = 4096, 256, 256
+    rng = np.random.default_rng(7)
+    # values whose fixed-point digits below the top one are all +127 / -128 (c0 = 0.5, s = 1 for SVs spanning [0, 1])
+    base = rng.integers(1, 120, (M + N, D)).astype(np.float64) / 256.0          # top digit
+    low = (127 * 2.0 ** -15 + 127 * 2.0 ** -23 + 127 * 2.0 ** -31)
+    vals = base + low
+    sv = vals[:M].copy(); sv[0, 0] = 0.0; sv[0, 1] = 1.0                           # pin the range to [0, 1]
+    X = vals[M:].astype(np.float32)
+    ns = np.array([M // 2, M - M // 2], dtype=np.int32)
+    dc = rng.uniform(-10, 10, (1, M))
+    svc = rml.GpuSVC(sv, dc, np.array([0.1]), ns, 0.01, np.arange(2), path="digits")
+    want = O.svm_decision_ovo(X, sv, dc, np.array([0.1]), ns, 0.01)
+    svc.decision_function_shape = "ovo"
+    got = svc._decide(svc._rows(X))[0].cpu().numpy()
+    assert np.abs(got - want).max() <= TOL, np.abs(got - want).max()
+
+
 def test_non_grid_model_uses_f64_path(rml):
     g = load_golden("svm_small.npz")
     m = svm_model_arrays(g)
@@ -442,15 +527,21 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     C = len(m["classes"])
     want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
     outs = {}
-    for big in ("0", "1"):
-        monkeypatch.setenv("RML_GEMM_BIG", big)
+    for big in ("0", "1", "ring"):
+        # "ring": the 256 x 256 kernel with the 5-slot operand-stage ring and counted vmcnt (k_svm_gemm_i8_256r)
+        monkeypatch.setenv("RML_GEMM_BIG", "1" if big == "ring" else big)
+        monkeypatch.setenv("RML_GEMM_RING", "1" if big == "ring" else "0")
         svc.decision_function_shape = "ovo"
         got = svc.decision_function(X)
         got = got.reshape(len(X), -1)
         ref = want if C > 2 else -want
         assert np.abs(got - ref).max() <= _tol(m, ref), big
         outs[big] = (got, svc.predict(X), rml.GpuCalibratedClassifier(svc).predict_proba(X))
+    monkeypatch.setenv("RML_GEMM_RING", "0")
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
+    # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
+    np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
+    np.testing.assert_array_equal(outs["1"][2], outs["ring"][2])
     # exact tiles give the same integers on both kernels; only the order of the float64 sums over SV tiles differs
     assert np.abs(outs["0"][0] - outs["1"][0]).max() <= 1e-9 * max(1.0, float(np.abs(want).max()))
     assert np.abs(outs["0"][2] - outs["1"][2]).max() <= 1e-9
