@@ -642,37 +642,84 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The same tile with a deeper staging ring (round 3).  Two 64 KiB stages give the DMA of step k+1 exactly one step of
-// compute to land in, and between the end of one burst and the next barrier nothing is in flight: ~32 KiB on average, which
-// at the loaded L2 latency (~2 us) is ~19 B/clk per CU where the MFMAs want 32.  Here the ring unit is one OPERAND stage
-// (256 rows x 128 B = 32 KiB) and all 160 KiB of LDS are ring: 5 slots, operand-stage n (n = 2k: SVs of step k, 2k+1:
-// samples of step k) lives in slot n % 5.  At the barrier of step k the two slots of step k-1 are free and take stages
-// 2k+3 and 2k+4, so a stage has 1.5 steps to land and 64-96 KiB are in flight for most of a step.  Waves wait with a counted
-// s_waitcnt vmcnt(4) (everything but the newest stage, 4 DMA instructions per wave) and meet at a raw s_barrier --
-// __syncthreads() would drain the DMA queue.  The per-SV epilogue table moves out of the K loop's LDS: it is loaded after
-// the loop into slot 4 (the epilogue's G image takes slots 0-3).
+// k_svm_gemm_ring<PT, DIG>: the 256 x 256 tile with a 5-slot operand-stage ring and interleaved DMA issue (round 3).
+//
+// What limited the two-stage kernel above (A/B in one process, tools/gemm_ab.py, 16 384 x 2 562 x 20 480): all 64 DMA
+// instructions of a stage leave in one burst after the barrier; the burst fills the CU's VMEM queue, every wave sits in its
+// in-order issue stage until its eight instructions are accepted (~100 cycles each) and no MFMA is issued meanwhile:
+// step = burst (~800-1000 cycles) + 2048 MFMA cycles.  Spreading the instructions between the MFMAs hides their issue under
+// the SIMD partner's matrix work, but in a two-stage scheme a late issue is a late landing (measured slower in round 2).
+// So the ring: the unit is one OPERAND stage (256 rows x 128 B = 32 KiB), all 160 KiB of LDS are ring, operand-stage n
+// (n = 2t: SV rows of step t, 2t+1: sample rows of step t) lives in slot n % 5.  Step t sends the sample stage of step t+1 in
+// its first half and the SV stage of step t+2 in its second half, one DMA instruction after every four MFMAs, into the
+// two slots step t-1 has just released: every stage has 1 to 1.5 steps to land.  Waves wait with a counted
+// s_waitcnt vmcnt(4) (everything but the newest stage) and meet at a raw s_barrier -- __syncthreads() would drain the queue.
+// Measured: burst issue into the ring 0.99 ms (worse than two stages: 0.87), interleaved 0.80 ms = 2.15 PetaOP/s.
+// The per-SV epilogue table is loaded after the K loop into slot 4 (the epilogue's G image takes slots 0-3).
+//
+// Tile order: block b runs on XCD b % 8 (observed, used for speed only).  The tiles are laid out as a sequence
+// [group of 8 sample tiles][SV tile][sample tile of the group] and XCD x takes the x-th eighth of it (+-1 tile): the ~32
+// tiles resident on an XCD are 8 sample tiles x 4 SV tiles sharing K-slices through that XCD's L2, and every XCD gets the
+// same number of tiles whatever the batch (the previous map gave XCD x the sample tiles x, x+8, ...: 69 sample tiles ->
+// nine on five XCDs, eight on three, i.e. a fourth round on five eighths of the chip).
+//
+// DIG = 1: general rows as four balanced int8 digits of a 32-bit fixed-point value (SURVEY 8 a-5 for data that is not on
+// the code grid: train.py:496-517 augmentation, a non-unit proj_zoom of predict.py:109-116, the reference's generated_data
+// pickles).  Every value v (sample feature or SV component) is read as u = (v - c0) / s in [-1, 1) (c0, s per model; s a
+// power of two, so float32 inputs >= s 2^-8 are represented exactly and smaller ones to 2^-32 s), I = rint(u 2^31), split
+// I = a0 2^24 + a1 2^16 + a2 2^8 + a3 with a_i in [-128, 127].  Then  u_x . u_s = 2^-14 sum_{i,j} 2^-8(i+j) (a_i^x . a_j^s)
+// and every digit-plane product is an exact int32 GEMM (|.| <= 2^14 K < 2^29).  The ten pairs with i + j <= 3 are kept (the
+// dropped ones weigh 2^-46 per digit product: typical 1e-8 on u.u), grouped by g = i + j and accumulated from
+// the least significant group up IN THE SAME int32 accumulator: after a group the accumulator is divided by 256 with
+// rounding, (acc + 128) >> 8, and the next group accumulates on top (4 x 2^28.3 < 2^31).  Before the top group the running
+// value is split acc = 256 q + r: q stays, the 8-bit remainders r are packed four to a register (32 VGPRs), so that
+// u.u = 2^-22 (256 (G0 + q) + r) carries 2^-23 absolute precision on a quantity of magnitude <= D/4 -- the arithmetic class
+// of the float64 path at ~2.8x its rate.  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED
+// values in float64.  The K loop runs over (pair, K-step); the DMA cursors run one and two steps ahead across pair boundaries.
 // ------------------------------------------------------------------------------------------
 constexpr int kOpStageBytes = kBig * kStepBytes;          // 32 KiB
 constexpr int kRingSlots = 5;
+constexpr int kDigPairs = 10;
+constexpr uint64_t kDigI = 0x0102103210ull;     // nibble p: sample digit of pair p   (0 = most significant)
+constexpr uint64_t kDigJ = 0x0010120123ull;     // nibble p: SV digit of pair p; pairs 0-3: g = 3, 4-6: g = 2, 7-8: g = 1, 9: g = 0
 
-// ILV = 1: the eight DMA instructions a wave issues per step are spread between its MFMA groups instead of going out in one
-// burst after the barrier.  A burst fills the CU's VMEM queue (64 KiB from 8 waves at once), every wave then sits in its
-// in-order issue stage for ~800-1000 cycles and no MFMA is issued meanwhile: step = burst + 2048 MFMA cycles.  Spread out, a
-// DMA instruction's issue time hides under the other wave's MFMAs -- which the two-stage kernel cannot afford (a late issue
-// is a late landing there: measured slower), and the ring can: the sample stage of step k+1 goes out in the first half of
-// step k, the SV stage of step k+2 in the second half.
-template <int PT, int ILV>
-__global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
+struct RingArgs {
+    const uint8_t* sv; const uint8_t* x;       // operand bases (digit plane 0)
+    int64_t ld_sv, ld_x;                       // bytes per row
+    int64_t sv_plane, x_plane;                 // DIG: bytes between digit planes
+    int KT;                                    // K-steps (per digit pair)
+    int64_t N, Mpad, sv_rows; int ST, FT;      // ST / FT count 128-row tiles like GemmArgs
+    const int32_t* tile_exact; int want;
+    const int32_t* x_isum; const int64_t* x_isq;   // exact path row statistics
+    const double* x_nsq;                            // DIG: ||u_x||^2
+    const double* sv_term;                          // exact: per-SV term; DIG: ||u_s||^2
+    const double* W;
+    double gs; int kernel;
+    double* partial; int64_t Npart;
+};
+
+// ring tile of block b: false = nothing to do
+__device__ __forceinline__ bool ring_tile(int b, int FT2, int ST2, int& ftile, int& stile) {
+    const int T = FT2 * ST2, q = T >> 3, r = T & 7;
+    const int xcd = b & 7, k = b >> 3;
+    if (k >= q + (xcd < r ? 1 : 0)) return false;
+    const int pos = xcd * q + (xcd < r ? xcd : r) + k;
+    const int G = 8 * ST2, fg = pos / G, rem = pos - fg * G;
+    const int left = FT2 - 8 * fg, scnt = left < 8 ? left : 8;
+    stile = rem / scnt;
+    ftile = fg * 8 + (rem - stile * scnt);
+    return true;
+}
+inline unsigned ring_grid(int FT2, int ST2) { const int T = FT2 * ST2; return (unsigned)(8 * ((T + 7) / 8)); }
+
+template <int PT, int DIG>
+__global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int FT2 = (a.FT + 1) >> 1;
-    const int XPX = (FT2 + 7) >> 3;
-    const int ftile = (slot % XPX) * 8 + xcd;
-    const int stile = slot / XPX;
-    if (ftile >= FT2) return;
+    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves; wave tile = 128 SVs x 64 samples
+    const int FT2 = (a.FT + 1) >> 1, ST2 = (int)((a.Mpad + kBig - 1) / kBig);
+    int ftile, stile;
+    if (!ring_tile(blockIdx.x, FT2, ST2, ftile, stile)) return;
     if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
     const int64_t f0 = (int64_t)ftile * kBig;
     const int64_t m0 = (int64_t)stile * kBig;
@@ -689,20 +736,29 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
         int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
         gx[q] = a.x + xr * a.ld_x + c * 16;
     }
-    // issue cursor: next operand stage n to issue and its slot
-    int ni = 0, si = 0;
-    const int nstages = 2 * a.KT;
-    auto issue = [&]() {
-        unsigned char* base = smem + si * kOpStageBytes + wave * 4096;
-        const int64_t ko = (int64_t)(ni >> 1) * kStepBytes;
-        if (ni & 1) {
+    // DMA cursors: byte offset (digit plane + K-step) of the next sample stage / SV stage to send, and their ring slots
+    const int64_t kbytes = (int64_t)a.KT * kStepBytes;
+    int64_t ox = 0, os = 0;                            // offsets within the current pair
+    int64_t px = 0, ps = 0;                            // plane offsets of the current pair
+    int qx = 0, qs = 0;                                // pair indices (DIG)
+    if constexpr (DIG) { px = (int64_t)(kDigI & 15) * a.x_plane; ps = (int64_t)(kDigJ & 15) * a.sv_plane; }
+    auto adv_x = [&]() {
+        ox += kStepBytes;
+        if constexpr (DIG) { if (ox == kbytes) { ox = 0; ++qx; px = (int64_t)((kDigI >> (4 * qx)) & 15) * a.x_plane; } }
+    };
+    auto adv_s = [&]() {
+        os += kStepBytes;
+        if constexpr (DIG) { if (os == kbytes) { os = 0; ++qs; ps = (int64_t)((kDigJ >> (4 * qs)) & 15) * a.sv_plane; } }
+    };
+    auto burst_s = [&](int slot) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) glds16(gx[q] + ko, base + q * 1024);
-        } else {
+        for (int q = 0; q < 4; ++q) glds16(gsv[q] + ps + os, smem + slot * kOpStageBytes + wave * 4096 + q * 1024);
+        adv_s();
+    };
+    auto burst_x = [&](int slot) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) glds16(gsv[q] + ko, base + q * 1024);
-        }
-        ++ni; si = si + 1 == kRingSlots ? 0 : si + 1;
+        for (int q = 0; q < 4; ++q) glds16(gx[q] + px + ox, smem + slot * kOpStageBytes + wave * 4096 + q * 1024);
+        adv_x();
     };
 
     int aoff[4], asw[4], boff[2], bsw[2];
@@ -726,55 +782,18 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    issue(); issue(); issue();                          // SV_0, X_0, SV_1
-    int sa = 0;                                         // slot of the SV stage of the step being computed
-    if constexpr (ILV == 0) {
-    for (int kt = 0; kt < a.KT; ++kt) {
-        // stages 2kt and 2kt+1 landed: everything this wave issued except the newest stage (2kt+2, when it exists)
-        if (kt + 1 < a.KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int TT = (DIG ? kDigPairs : 1) * a.KT;       // steps in all
+    burst_s(0); burst_x(1);                            // SV_0, X_0
+    if (TT > 1) burst_s(2);                            // SV_1
+    int sa = 0;                                        // slot of the SV stage of the step being computed
+    int sx = 3, ss = 4;                                // slots of the two stages step 0 sends
+    int t = 0;                                         // global step
+    auto step = [&]() {
+        const bool hx = t + 1 < TT, hs = t + 2 < TT;
+        // stages 2t and 2t+1 landed: everything this wave sent except the newest stage (the SV stage of step t+1)
+        if (hx) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                   // ... for every wave's pieces; and step kt-1 is consumed by everyone
-        asm volatile("" ::: "memory");
-        if (ni < nstages) issue();
-        if (ni < nstages) issue();
-        const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
-        const unsigned char* pa = smem + sa * kOpStageBytes;
-        const unsigned char* pb = smem + sbx * kOpStageBytes;
-        sa = sa + 2 >= kRingSlots ? sa + 2 - kRingSlots : sa + 2;
-        v4i af[2][4], bf[2][2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((chalf ^ asw[t]) << 4));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((chalf ^ bsw[t]) << 4));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
-                const int ch = 2 * (kk + 1) + chalf;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((ch ^ asw[t]) << 4));
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((ch ^ bsw[t]) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    } else {
-    // interleaved issue: step kt sends the sample stage of step kt+1 (slot (2kt+3) % 5) in its first half and the SV stage of
-    // step kt+2 (slot (2kt+4) % 5) in its second half, one DMA instruction after every four MFMAs
-    int sx = 3, ss = 4;                                 // slots of those two stages at kt = 0
-    auto step = [&](int kt, auto hx_, auto hs_) {
-        constexpr bool HX = decltype(hx_)::value, HS = decltype(hs_)::value;
-        if constexpr (HX) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                  // ... for every wave's pieces; and step t-1 is consumed by everyone
         asm volatile("" ::: "memory");
         const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
         const unsigned char* pa = smem + sa * kOpStageBytes;
@@ -784,22 +803,22 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
         unsigned char* dsv = smem + ss * kOpStageBytes + wave * 4096;
         sx = sx + 2 >= kRingSlots ? sx + 2 - kRingSlots : sx + 2;
         ss = ss + 2 >= kRingSlots ? ss + 2 - kRingSlots : ss + 2;
-        const int64_t kox = (int64_t)(kt + 1) * kStepBytes, kos = (int64_t)(kt + 2) * kStepBytes;
+        const int64_t offx = px + ox, offs = ps + os;
         v4i af[2][4], bf[2][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((chalf ^ asw[t]) << 4));
+        for (int u = 0; u < 4; ++u) af[0][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((chalf ^ asw[u]) << 4));
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((chalf ^ bsw[t]) << 4));
+        for (int u = 0; u < 2; ++u) bf[0][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((chalf ^ bsw[u]) << 4));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (kk < 3) {
                 const int ch = 2 * (kk + 1) + chalf;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pa + aoff[t] + ((ch ^ asw[t]) << 4));
+                for (int u = 0; u < 4; ++u)
+                    af[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((ch ^ asw[u]) << 4));
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(pb + boff[t] + ((ch ^ bsw[t]) << 4));
+                for (int u = 0; u < 2; ++u)
+                    bf[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((ch ^ bsw[u]) << 4));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -811,20 +830,50 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 const int g = 2 * kk + half;            // DMA instruction 0..7 of this step
-                if (g < 4) { if constexpr (HX) glds16(gx[g] + kox, dx + g * 1024); }
-                else       { if constexpr (HS) glds16(gsv[g - 4] + kos, dsv + (g - 4) * 1024); }
+                if (g < 4) { if (hx) glds16(gx[g] + offx, dx + g * 1024); }
+                else       { if (hs) glds16(gsv[g - 4] + offs, dsv + (g - 4) * 1024); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (hx) adv_x();
+        if (hs) adv_s();
+        ++t;
     };
-    using T_ = std::true_type; using F_ = std::false_type;
-    int kt = 0;
-    for (; kt + 2 < a.KT; ++kt) step(kt, T_{}, T_{});
-    if (kt + 1 < a.KT) { step(kt, T_{}, F_{}); ++kt; }
-    if (kt < a.KT) step(kt, F_{}, F_{});
+
+    int rem[DIG ? 32 : 1];                             // DIG: 8-bit remainders of the split before the top group
+    if constexpr (DIG) {
+        auto shift8 = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
+        };
+        // groups g = 3 (pairs 0-3), g = 2 (4-6), g = 1 (7-8): the remainders do not exist yet, so they cost no registers here
+        for (int n = 4 * a.KT; n > 0; --n) step();
+        shift8();
+        for (int n = 3 * a.KT; n > 0; --n) step();
+        shift8();
+        for (int n = 2 * a.KT; n > 0; --n) step();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) rem[r] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int v = acc[i][j][r];
+                    rem[(i * 2 + j) * 4 + (r >> 2)] |= (v & 255) << (8 * (r & 3));
+                    acc[i][j][r] = v >> 8;
+                }
+        for (int n = a.KT; n > 0; --n) step();         // group g = 0 (pair 9)
+    } else {
+        for (int n = a.KT; n > 0; --n) step();
     }
 
-    // ---- epilogue (as k_svm_gemm_i8_256; the SV table is loaded now, into slot 4) ----
+    // ---- fused float64 epilogue; the per-SV table is loaded now, into slot 4 ----
     const bool rbf = (a.kernel == RML_KERNEL_RBF);
     double* svw = reinterpret_cast<double*>(smem + 4 * kOpStageBytes);     // [256][1+PT] + exp table
     const double* etab = svw + kBig * (1 + PT);
@@ -835,287 +884,113 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256r(GemmArgs a) {
         const bool in = m0 + m < a.Mpad;
         svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
     }
-    int* gl = reinterpret_cast<int*>(smem);
-    const int nl = tid & 127, h = tid >> 7;
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
-        if ((wc >> 1) == pass) {
+    if constexpr (DIG) {
+        // one 64-sample quarter (= one wave column wc) at a time through LDS as float64:
+        // u.u = 2^-22 (256 acc + rem);  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u.u);  a.gs = gamma s^2
+        double* gd = reinterpret_cast<double*>(smem);      // [256 SVs][64 samples]
+        const int nq = tid & 63, qd = tid >> 6;            // sample column of the quarter, SV group (32 rows)
+        for (int pass = 0; pass < 4; ++pass) {
+            __syncthreads();
+            if (wc == pass) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                        const int nn = (wc & 1) * 64 + j * 32 + (lane & 31);
-                        gl[ml * kTile + nn] = acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-        const int64_t n = f0 + pass * kTile + nl;
-        const int64_t nc = n < a.N ? n : a.N - 1;
-        const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
-        double S[PT];
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                            const int nn = j * 32 + (lane & 31);
+                            const int rb = (rem[(i * 2 + j) * 4 + (r >> 2)] >> (8 * (r & 3))) & 255;
+                            gd[ml * 64 + nn] = ((double)acc[i][j][r] * 256.0 + (double)rb) * 0x1p-22;
+                        }
+            }
+            __syncthreads();
+            const int64_t n = f0 + pass * 64 + nq;
+            const int64_t nc = n < a.N ? n : a.N - 1;
+            const double xt = a.x_nsq[nc];
+            double S[PT];
 #pragma unroll
-        for (int p = 0; p < PT; ++p) S[p] = 0.0;
-        const int* gcol = gl + nl;
+            for (int p = 0; p < PT; ++p) S[p] = 0.0;
 #pragma unroll 2
-        for (int mm = 0; mm < 64; ++mm) {
-            const int ml = h * 64 + mm;
-            const double* e = svw + ml * (1 + PT);
-            const double g = (double)gcol[ml * kTile];
-            double kv;
-            if (rbf) {
-                double d2 = xt + e[0] - 2.0 * g;
+            for (int mm = 0; mm < 32; ++mm) {
+                const int ml = qd * 32 + mm;
+                const double* e = svw + ml * (1 + PT);
+                double d2 = xt + e[0] - 2.0 * gd[ml * 64 + nq];
                 d2 = d2 > 0.0 ? d2 : 0.0;
-                kv = rml_exp_neg(-a.gs * d2, etab);
-            } else {
-                kv = (g + xt + e[0]) * a.gs;
+                const double kv = rml_exp_neg(-a.gs * d2, etab);
+#pragma unroll
+                for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
             }
+            __syncthreads();                               // G quarter consumed: reuse its LDS for the exchange
+            double* x8 = gd;                               // [8 groups][64][PT]
 #pragma unroll
-            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
-        }
-        __syncthreads();
-        double* x4 = reinterpret_cast<double*>(smem);  // [4][128][PT]
+            for (int p = 0; p < PT; ++p) x8[(qd * 64 + nq) * PT + p] = S[p];
+            __syncthreads();
+            if (qd == 0 && n < a.N) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) x4[(h * kTile + nl) * PT + p] = S[p];
-        __syncthreads();
-        if (h == 0 && n < a.N) {
+                for (int p = 0; p < PT; ++p) {
+                    double tsum = 0.0;
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                double t = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
-                t += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
-                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
-                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                    for (int g = 0; g < 8; ++g) tsum += x8[(g * 64 + nq) * PT + p];
+                    a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = tsum;
+                    if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                }
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// General rows on the int8 matrix cores: "multi-digit" exact products (SURVEY 8 a-5 for data that is not on the code
-// grid: train.py:496-517 augmentation, a non-unit proj_zoom of predict.py:109-116, the reference's generated_data pickles).
-//
-// Every value v (sample feature or SV component) is read as the 32-bit fixed-point number u = (v - c0) / s in [-1, 1)
-// (c0, s per model; s a power of two, so float32 inputs >= s 2^-8 are represented exactly and smaller ones to 2^-32 s),
-// I = rint(u 2^31), split into four BALANCED int8 digits  I = a0 2^24 + a1 2^16 + a2 2^8 + a3,  a_i in [-128, 127].  Then
-//     u_x . u_s = 2^-14 sum_{i,j} 2^-8(i+j) (a_i^x . a_j^s)
-// and every digit-plane product is an exact int32 GEMM on v_mfma_i32_32x32x32_i8 (|.| <= 2^14 K < 2^29).  The ten pairs with
-// i + j <= 3 are kept (the dropped ones weigh 2^-46 per digit product: typical 1e-8 on u.u), grouped by
-// g = i + j and accumulated from the least significant group up IN THE SAME int32 accumulator: after a group the
-// accumulator is divided by 256 with rounding, (acc + 128) >> 8, and keeps accumulating the next group on top (4 x 2^28.3
-// < 2^31).  Before the most significant group the running value is split acc = 256 q + r: q stays in the accumulator, the
-// 8-bit remainders r are packed four to a register (32 VGPRs), so that u.u = 2^-22 (256 (G0 + q) + r) carries 2^-22
-// absolute precision on a quantity of magnitude <= D/4 -- the arithmetic class of the float64 path at ~2.4x its rate.
-// d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED values in float64, so d^2 is the exact
-// squared distance of two slightly (<= 2^-32 s) moved points.
-// Same tile, staging and wave layout as k_svm_gemm_i8_256; the K loop runs over (pair, K-step).
-// ------------------------------------------------------------------------------------------
-constexpr int kDigPairs = 10;
-constexpr uint64_t kDigI = 0x0102103210ull;     // nibble p: sample digit of pair p   (0 = most significant)
-constexpr uint64_t kDigJ = 0x0010120123ull;     // nibble p: SV digit of pair p
-
-struct DigArgs {
-    const int8_t* sv; int64_t sv_plane;       // SV digit planes, bytes between planes (Mpad * Dq)
-    const int8_t* x;  int64_t x_plane;        // sample digit planes, bytes between planes
-    int64_t ld;                               // bytes per row (both operands)
-    int KT;
-    int64_t N; int64_t Mpad; int ST, FT;      // ST / FT count 128-row tiles like GemmArgs
-    const int32_t* tile_exact; int want;
-    const double* x_nsq; const double* sv_nsq;
-    const double* W;
-    double gs;                                // gamma * s^2
-    double* partial; int64_t Npart;
-};
-
-template <int PT>
-__global__ __launch_bounds__(512, 2) void k_svm_gemm_dig(DigArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int FT2 = (a.FT + 1) >> 1;
-    const int XPX = (FT2 + 7) >> 3;
-    const int ftile = (slot % XPX) * 8 + xcd;
-    const int stile = slot / XPX;
-    if (ftile >= FT2) return;
-    if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
-    const int64_t f0 = (int64_t)ftile * kBig;
-    const int64_t m0 = (int64_t)stile * kBig;
-
-    double* svw = reinterpret_cast<double*>(smem + 2 * kBigStageBytes);    // [256][1+PT]; rows past Mpad carry W = 0
-    const double* etab = svw + kBig * (1 + PT);
-    exp_tab_init(svw + kBig * (1 + PT), tid);
-    for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
-        int m = idx / (1 + PT), c = idx - m * (1 + PT);
-        const bool in = m0 + m < a.Mpad;
-        svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_nsq[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
-    }
-
-    const int8_t* gsv[4];
-    const int8_t* gx[4];
+    } else {
+        int* gl = reinterpret_cast<int*>(smem);
+        const int nl = tid & 127, h = tid >> 7;
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if ((wc >> 1) == pass) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int s = (wave * 4 + q) * 64 + lane;
-        int r = s >> 3;
-        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
-        int64_t mr = m0 + r; mr = mr < a.Mpad ? mr : a.Mpad - 1;
-        gsv[q] = a.sv + mr * a.ld + c * 16;
-        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
-        gx[q] = a.x + xr * a.ld + c * 16;
-    }
-    // staging cursor: (pair ps, K-step ks), one step ahead of the compute cursor
-    int ps = 0, ks = 0;
-    int64_t so = (int64_t)((kDigJ >> 0) & 15) * a.sv_plane, xo = (int64_t)((kDigI >> 0) & 15) * a.x_plane;
-    auto stage = [&](int buf) {
-        unsigned char* base = smem + buf * kBigStageBytes;
-        const int64_t ko = (int64_t)ks * kStepBytes;
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            glds16(gsv[q] + so + ko, base + (wave * 4 + q) * 1024);
-            glds16(gx[q] + xo + ko, base + kBig * kStepBytes + (wave * 4 + q) * 1024);
-        }
-        if (++ks == a.KT) {
-            ks = 0; ++ps;
-            so = (int64_t)((kDigJ >> (4 * ps)) & 15) * a.sv_plane;
-            xo = (int64_t)((kDigI >> (4 * ps)) & 15) * a.x_plane;
-        }
-    };
-
-    int aoff[4], asw[4], boff[2], bsw[2];
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        int ra = wr * 128 + t * 32 + (lane & 31);
-        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int rb = wc * 64 + t * 32 + (lane & 31);
-        boff[t] = kBig * kStepBytes + rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
-    }
-    const int chalf = lane >> 5;
-
-    v16i acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    // one K-step: wait for its stage, start the next one, 32 MFMAs with the fragment reads of sub-step kk+1 under those of kk
-    int tb = 0;                                        // stage buffer of the step being computed
-    auto kstep = [&](bool more) {
-        __syncthreads();                               // DMA of this step landed and visible; other buffer free
-        if (more) stage(tb ^ 1);
-        const unsigned char* sb = smem + tb * kBigStageBytes;
-        v4i af[2][4], bf[2][2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) af[0][u] = *reinterpret_cast<const v4i*>(sb + aoff[u] + ((chalf ^ asw[u]) << 4));
-#pragma unroll
-        for (int u = 0; u < 2; ++u) bf[0][u] = *reinterpret_cast<const v4i*>(sb + boff[u] + ((chalf ^ bsw[u]) << 4));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
-                const int ch = 2 * (kk + 1) + chalf;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    af[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(sb + aoff[u] + ((ch ^ asw[u]) << 4));
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    bf[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(sb + boff[u] + ((ch ^ bsw[u]) << 4));
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                            const int nn = (wc & 1) * 64 + j * 32 + (lane & 31);
+                            gl[ml * kTile + nn] = acc[i][j][r];
+                        }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            const int64_t n = f0 + pass * kTile + nl;
+            const int64_t nc = n < a.N ? n : a.N - 1;
+            const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+            double S[PT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tb ^= 1;
-    };
-    auto shift8 = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
-    };
-    stage(0);
-    // groups g = 3 (pairs 0-3), g = 2 (4-6), g = 1 (7-8): the remainders do not exist yet, so they cost no registers here
-    for (int t = 0; t < 4 * a.KT; ++t) kstep(true);
-    shift8();
-    for (int t = 0; t < 3 * a.KT; ++t) kstep(true);
-    shift8();
-    for (int t = 0; t < 2 * a.KT; ++t) kstep(true);
-    int rem[32];                                       // 8-bit remainders of the split before the top group, four to a register
-#pragma unroll
-    for (int r = 0; r < 32; ++r) rem[r] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int v = acc[i][j][r];
-                rem[(i * 2 + j) * 4 + (r >> 2)] |= (v & 255) << (8 * (r & 3));
-                acc[i][j][r] = v >> 8;
-            }
-    // group g = 0 (pair 9)
-    for (int t = 0; t < a.KT; ++t) kstep(t + 1 < a.KT);
-
-    // ---- float64 epilogue: one 64-sample quarter (= one wave column wc) at a time through LDS as float64 ----
-    // u.u = 2^-22 (256 acc + rem);  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u.u);  a.gs = gamma s^2
-    double* gd = reinterpret_cast<double*>(smem);      // [256 SVs][64 samples]
-    const int nq = tid & 63, qd = tid >> 6;            // sample column of the quarter, SV group (32 rows)
-    for (int pass = 0; pass < 4; ++pass) {
-        __syncthreads();
-        if (wc == pass) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                        const int nn = j * 32 + (lane & 31);
-                        const int rb = (rem[(i * 2 + j) * 4 + (r >> 2)] >> (8 * (r & 3))) & 255;
-                        gd[ml * 64 + nn] = ((double)acc[i][j][r] * 256.0 + (double)rb) * 0x1p-22;
-                    }
-        }
-        __syncthreads();
-        const int64_t n = f0 + pass * 64 + nq;
-        const int64_t nc = n < a.N ? n : a.N - 1;
-        const double xt = a.x_nsq[nc];
-        double S[PT];
-#pragma unroll
-        for (int p = 0; p < PT; ++p) S[p] = 0.0;
+            for (int p = 0; p < PT; ++p) S[p] = 0.0;
+            const int* gcol = gl + nl;
 #pragma unroll 2
-        for (int mm = 0; mm < 32; ++mm) {
-            const int ml = qd * 32 + mm;
-            const double* e = svw + ml * (1 + PT);
-            double d2 = xt + e[0] - 2.0 * gd[ml * 64 + nq];
-            d2 = d2 > 0.0 ? d2 : 0.0;
-            const double kv = rml_exp_neg(-a.gs * d2, etab);
+            for (int mm = 0; mm < 64; ++mm) {
+                const int ml = h * 64 + mm;
+                const double* e = svw + ml * (1 + PT);
+                const double g = (double)gcol[ml * kTile];
+                double kv;
+                if (rbf) {
+                    double d2 = xt + e[0] - 2.0 * g;
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    kv = rml_exp_neg(-a.gs * d2, etab);
+                } else {
+                    kv = (g + xt + e[0]) * a.gs;
+                }
 #pragma unroll
-            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
-        }
-        __syncthreads();                               // G quarter consumed: reuse its LDS for the exchange
-        double* x8 = gd;                               // [8 groups][64][PT]
+                for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+            }
+            __syncthreads();
+            double* x4 = reinterpret_cast<double*>(smem);  // [4][128][PT]
 #pragma unroll
-        for (int p = 0; p < PT; ++p) x8[(qd * 64 + nq) * PT + p] = S[p];
-        __syncthreads();
-        if (qd == 0 && n < a.N) {
+            for (int p = 0; p < PT; ++p) x4[(h * kTile + nl) * PT + p] = S[p];
+            __syncthreads();
+            if (h == 0 && n < a.N) {
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                double t = 0.0;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) t += x8[(g * 64 + nq) * PT + p];
-                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
-                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                for (int p = 0; p < PT; ++p) {
+                    double tsum = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
+                    tsum += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
+                    a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = tsum;
+                    if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                }
             }
         }
     }
@@ -1487,50 +1362,54 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
+template <int DIG>
+int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
+    const int FT2 = (ra.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
+    dim3 grid(ring_grid(FT2, ST2)), block(512);
+    const size_t lds = (size_t)kRingSlots * kOpStageBytes;
+#define RML_RING_CASE(PTV)                                                                                         \
+    case PTV: {                                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_ring<PTV, DIG>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        hipLaunchKernelGGL((k_svm_gemm_ring<PTV, DIG>), grid, block, lds, st, ra);                                 \
+    } break;
+    switch (m->PT) {
+        RML_RING_CASE(1)
+        RML_RING_CASE(3)
+        RML_RING_CASE(6)
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 256x256 kernel");
+    }
+#undef RML_RING_CASE
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+    // RML_GEMM_RING (read per call: tests and A/B runs flip it): unset / 1 = k_svm_gemm_ring (5-slot operand-stage ring,
+    // interleaved DMA issue), 0 = the two-stage kernel, 3 = the two-stage kernel with staggered issue (experiment arm)
+    const char* re = getenv("RML_GEMM_RING");
+    const int ring = re ? atoi(re) : 1;
+    if (ring != 0 && ring != 3) {
+        RingArgs ra{};
+        ra.sv = ga.sv; ra.x = ga.x; ra.ld_sv = ga.ld_sv; ra.ld_x = ga.ld_x; ra.KT = ga.KT;
+        ra.N = ga.N; ra.Mpad = ga.Mpad; ra.sv_rows = ga.sv_rows; ra.ST = ga.ST; ra.FT = ga.FT;
+        ra.tile_exact = ga.tile_exact; ra.want = ga.want; ra.x_isum = ga.x_isum; ra.x_isq = ga.x_isq;
+        ra.sv_term = ga.sv_term; ra.W = ga.W; ra.gs = ga.gs; ra.kernel = ga.kernel; ra.partial = ga.partial; ra.Npart = ga.Npart;
+        return launch_gemm_ring<0>(m, ra, st);
+    }
     const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
     const int FT2 = (ga.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
     dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
-    // RML_GEMM_RING=1: the 5-slot operand-stage ring (k_svm_gemm_i8_256r); read per call, tests and A/B runs flip it
-    const char* re = getenv("RML_GEMM_RING");
-    const int ring = re ? atoi(re) : 0;
-    if (ring == 3 && m->PT == 3) {      // experiment arm: staggered issue in the two-stage kernel
+    if (ring == 3 && m->PT == 3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((k_svm_gemm_i8_256<3, 1>), grid, block, lds, st, ga);
         RML_HIP(hipGetLastError());
         return RML_OK;
     }
-    if ((ring == 1 || ring == 2) && m->PT <= 6) {
-#define RML_RING_CASE(PTV)                                                                                         \
-    case PTV: {                                                                                                    \
-        if (ring == 1) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256r<PTV, 0>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-            hipLaunchKernelGGL((k_svm_gemm_i8_256r<PTV, 0>), grid, block, (size_t)kRingSlots * kOpStageBytes, st, ga); \
-        } else {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256r<PTV, 1>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-            hipLaunchKernelGGL((k_svm_gemm_i8_256r<PTV, 1>), grid, block, (size_t)kRingSlots * kOpStageBytes, st, ga); \
-        }                                                                                                          \
-    } break;
-        switch (m->PT) {
-            RML_RING_CASE(1)
-            RML_RING_CASE(3)
-            RML_RING_CASE(6)
-            default: break;
-        }
-#undef RML_RING_CASE
-        RML_HIP(hipGetLastError());
-        return RML_OK;
-    }
 #define RML_BIG_CASE(PTV)                                                                                          \
     case PTV: {                                                                                                    \
-        static bool attr_done = false;                                                                             \
-        if (!attr_done) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<PTV>),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-            attr_done = true;                                                                                      \
-        }                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<PTV>),                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
         hipLaunchKernelGGL((k_svm_gemm_i8_256<PTV>), grid, block, lds, st, ga);                                    \
     } break;
     switch (m->PT) {
@@ -1540,27 +1419,6 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
         default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 256x256 kernel");
     }
 #undef RML_BIG_CASE
-    RML_HIP(hipGetLastError());
-    return RML_OK;
-}
-
-int launch_gemm_dig(const rml_svm* m, const DigArgs& da, hipStream_t st) {
-    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
-    const int FT2 = (da.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
-    dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
-#define RML_DIG_CASE(PTV)                                                                                          \
-    case PTV: {                                                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_dig<PTV>),                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-        hipLaunchKernelGGL((k_svm_gemm_dig<PTV>), grid, block, lds, st, da);                                       \
-    } break;
-    switch (m->PT) {
-        RML_DIG_CASE(1)
-        RML_DIG_CASE(3)
-        RML_DIG_CASE(6)
-        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the multi-digit kernel");
-    }
-#undef RML_DIG_CASE
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
@@ -1671,12 +1529,13 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         if (rc) return rc;
     }
     if (run_dig) {
-        DigArgs da{};
-        da.sv = m->sv_dig; da.sv_plane = m->Mpad * m->Dq; da.x = w.dig; da.x_plane = w.dig_plane; da.ld = m->Dq;
-        da.KT = (int)(m->Kq / kStepBytes); da.N = n; da.Mpad = m->Mpad; da.ST = ST; da.FT = FT;
-        da.tile_exact = w.tile_exact; da.want = 2; da.x_nsq = w.dnsq; da.sv_nsq = m->sv_dig_nsq; da.W = m->W;
-        da.gs = m->gamma * m->dig_s * m->dig_s; da.partial = w.partial; da.Npart = n;
-        int rc = launch_gemm_dig(m, da, st);
+        RingArgs ra{};
+        ra.sv = reinterpret_cast<const uint8_t*>(m->sv_dig); ra.x = reinterpret_cast<const uint8_t*>(w.dig);
+        ra.ld_sv = m->Dq; ra.ld_x = m->Dq; ra.sv_plane = m->Mpad * m->Dq; ra.x_plane = w.dig_plane;
+        ra.KT = (int)(m->Kq / kStepBytes); ra.N = n; ra.Mpad = m->Mpad; ra.sv_rows = m->Mpad; ra.ST = ST; ra.FT = FT;
+        ra.tile_exact = w.tile_exact; ra.want = 2; ra.x_nsq = w.dnsq; ra.sv_term = m->sv_dig_nsq; ra.W = m->W;
+        ra.gs = m->gamma * m->dig_s * m->dig_s; ra.kernel = RML_KERNEL_RBF; ra.partial = w.partial; ra.Npart = n;
+        int rc = launch_gemm_ring<1>(m, ra, st);
         if (rc) return rc;
     }
     if (run_gen) {

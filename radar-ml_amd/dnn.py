@@ -91,6 +91,65 @@ class Classifier(_module_base()):
                  for fc in (self.fc1, self.fc2, self.fc3)]
         return convs, dense
 
+    def set_keras_weights(self, convs, dense):
+        """Inverse of :meth:`keras_weights`: load parameters that come in Keras layout -- conv kernels (kh, kw, cin, cout),
+        dense kernels (in, out), the three branches in input order xz, yz, xy -- i.e. the arrays a maintainer gets from the
+        reference's trained model (``tf.keras.models.load_model(...)``, dnn.py:364-370, then ``layer.get_weights()`` per
+        layer).  The flatten order needs no permutation: features() already flattens NHWC like Keras."""
+        import torch
+        if len(convs) != len(self.branches) or len(dense) != 3:
+            raise ValueError("expected %d conv branches of (k1, b1, k2, b2) and 3 dense (kernel, bias) pairs" % len(self.branches))
+
+        def put(param, arr, what):
+            t = torch.as_tensor(np.asarray(arr), dtype=param.dtype)
+            if tuple(t.shape) != tuple(param.shape):
+                raise ValueError("%s: Keras array gives %s, the layer holds %s" % (what, tuple(t.shape), tuple(param.shape)))
+            param.copy_(t.to(param.device))
+
+        with torch.no_grad():
+            for bi, (br, (k1, b1, k2, b2)) in enumerate(zip(self.branches, convs)):
+                for conv, k, b, nm in ((br[0].conv, k1, b1, "conv1"), (br[1].conv, k2, b2, "conv2")):
+                    k = np.asarray(k)
+                    if k.ndim != 4:
+                        raise ValueError("branch %d %s kernel: expected (kh, kw, cin, cout)" % (bi, nm))
+                    put(conv.weight, k.transpose(3, 2, 0, 1), "branch %d %s kernel" % (bi, nm))
+                    put(conv.bias, b, "branch %d %s bias" % (bi, nm))
+            for fc, (k, b), nm in zip((self.fc1, self.fc2, self.fc3), dense, ("dense", "dense_1", "dense_2")):
+                put(fc.weight, np.asarray(k).T, nm + " kernel")
+                put(fc.bias, b, nm + " bias")
+        return self
+
+    def set_keras_weight_list(self, weights, order="depth"):
+        """Load the flat list ``model.get_weights()`` returns for the reference's functional model (dnn.py:55-91).
+        Keras lists a functional model's layers by graph depth, so the three first convolutions (xz, yz, xy) come before
+        the three second ones: ``order="depth"``; ``order="branch"`` takes [xz conv1, xz conv2, yz conv1, ...] instead.
+        (No TensorFlow here to confirm the order on a live model -- the shapes are checked, the order is the caller's.)"""
+        w = [np.asarray(a) for a in weights]
+        nb = len(self.branches)
+        if len(w) != 4 * nb + 6:
+            raise ValueError("expected %d arrays (kernel + bias of %d convolutions and 3 dense layers), got %d" % (4 * nb + 6, 2 * nb, len(w)))
+        if order == "depth":
+            convs = [(w[2 * b], w[2 * b + 1], w[2 * nb + 2 * b], w[2 * nb + 2 * b + 1]) for b in range(nb)]
+        elif order == "branch":
+            convs = [tuple(w[4 * b:4 * b + 4]) for b in range(nb)]
+        else:
+            raise ValueError("order must be 'depth' or 'branch'")
+        d = w[4 * nb:]
+        return self.set_keras_weights(convs, [(d[0], d[1]), (d[2], d[3]), (d[4], d[5])])
+
+    def evaluate(self, inputs, y, batch_size=8192, autocast_dtype=None):
+        """Keras ``model.evaluate([xz, yz, xy], y)`` of the compiled classifier (dnn.py:88-90: sparse categorical
+        cross-entropy + accuracy): returns (loss, accuracy), the means over all samples, dropout inactive."""
+        p = self.predict(inputs, batch_size=batch_size, autocast_dtype=autocast_dtype).astype(np.float64)
+        yi = np.asarray(y).reshape(-1).astype(np.int64)
+        if len(yi) != len(p):
+            raise ValueError("evaluate: %d label(s) for %d sample(s)" % (len(yi), len(p)))
+        if len(yi) == 0:
+            return 0.0, 0.0
+        # Keras clips the probabilities to [1e-7, 1 - 1e-7] before the log (backend.sparse_categorical_crossentropy)
+        pt = np.clip(p[np.arange(len(yi)), yi], 1e-7, 1.0 - 1e-7)
+        return float(-np.log(pt).mean()), float((p.argmax(axis=1) == yi).mean())
+
     # ---- fused HIP trunk -------------------------------------------------------------------------------
     def _packed_trunk_weights(self):
         """conv weights in the layout of rml_dnn_trunk, cached and re-packed whenever a convolution parameter was written

@@ -94,6 +94,79 @@ class Discriminator(_nn().Module):
         return self.fc3(h)
 
 
+    # ---- Keras layout in / out -------------------------------------------------------------------------
+    def _conv_bn_pairs(self):
+        out = []
+        for br in self.branches:
+            layers = list(br)
+            out.append([(layers[i].conv, layers[i + 1]) for i in range(0, len(layers), 3)])
+        return out
+
+    def keras_weights(self):
+        """The parameters AND BatchNorm statistics in Keras layout, float64 numpy:
+        ``(branches, dense)`` with branches[b] = [(kernel (kh,kw,cin,cout), bias, gamma, beta, moving_mean, moving_variance)] x 3
+        and dense = [(kernel (in,out), bias, gamma, beta, moving_mean, moving_variance)] x 2 + [(kernel, bias)] --
+        what ``layer.get_weights()`` of the reference's c_model / d_model holds layer by layer (sgan.py:132-199;
+        Keras BatchNormalization lists gamma, beta, moving_mean, moving_variance)."""
+        def a(t):
+            return t.detach().double().cpu().numpy()
+
+        def bn4(bn):
+            return a(bn.weight), a(bn.bias), a(bn.running_mean), a(bn.running_var)
+        branches = [[(a(conv.weight.permute(2, 3, 1, 0)), a(conv.bias)) + bn4(bn) for conv, bn in pairs] for pairs in self._conv_bn_pairs()]
+        dense = [(a(self.fc1.weight.t()), a(self.fc1.bias)) + bn4(self.bn1), (a(self.fc2.weight.t()), a(self.fc2.bias)) + bn4(self.bn2),
+                 (a(self.fc3.weight.t()), a(self.fc3.bias))]
+        return branches, dense
+
+    def set_keras_weights(self, branches, dense):
+        """Inverse of :meth:`keras_weights`: what a maintainer pulls out of a trained ``c_model_XXXX.h5`` (sgan.py:496-500)
+        goes in here; the moving statistics land in the BatchNorm buffers, so inference (``predict`` / ``evaluate``)
+        reproduces the Keras model."""
+        import torch
+        pairs = self._conv_bn_pairs()
+        if len(branches) != len(pairs) or len(dense) != 3:
+            raise ValueError("expected %d branches of 3 (conv + batch-norm) tuples and 3 dense tuples" % len(pairs))
+
+        def put(dst, arr, what):
+            t = torch.as_tensor(np.asarray(arr), dtype=dst.dtype)
+            if tuple(t.shape) != tuple(dst.shape):
+                raise ValueError("%s: Keras array gives %s, the layer holds %s" % (what, tuple(t.shape), tuple(dst.shape)))
+            dst.copy_(t.to(dst.device))
+
+        def put_bn(bn, g, b, mean, var, what):
+            put(bn.weight, g, what + " gamma"); put(bn.bias, b, what + " beta")
+            put(bn.running_mean, mean, what + " moving_mean"); put(bn.running_var, var, what + " moving_variance")
+
+        with torch.no_grad():
+            for bi, (prs, given) in enumerate(zip(pairs, branches)):
+                if len(given) != len(prs):
+                    raise ValueError("branch %d: expected %d (conv + batch-norm) tuples" % (bi, len(prs)))
+                for li, ((conv, bn), (k, b, g, be, mu, var)) in enumerate(zip(prs, given)):
+                    what = "branch %d layer %d" % (bi, li)
+                    put(conv.weight, np.asarray(k).transpose(3, 2, 0, 1), what + " kernel")
+                    put(conv.bias, b, what + " bias")
+                    put_bn(bn, g, be, mu, var, what)
+            for fc, bn, tup, nm in ((self.fc1, self.bn1, dense[0], "dense"), (self.fc2, self.bn2, dense[1], "dense_1")):
+                k, b, g, be, mu, var = tup
+                put(fc.weight, np.asarray(k).T, nm + " kernel"); put(fc.bias, b, nm + " bias")
+                put_bn(bn, g, be, mu, var, nm)
+            k, b = dense[2]
+            put(self.fc3.weight, np.asarray(k).T, "dense_2 kernel"); put(self.fc3.bias, b, "dense_2 bias")
+        return self
+
+
+def class_weight_to_sample_weight(y, class_weight):
+    """``train_on_batch(..., class_weight=w)`` as Keras applies it (sgan.py:529-530 passes the data set's class weights to
+    the d update): the target is cast to an integer class, ``int(y)`` truncating toward zero -- the smoothed real labels in
+    [0.7, 1.2) of sgan.py:396-398 therefore select class 0 or 1 -- and that class's weight becomes the sample's weight
+    (classes missing from the dict weigh 1)."""
+    yi = np.trunc(np.asarray(y, dtype=np.float64).reshape(-1)).astype(np.int64)
+    w = np.ones(len(yi), dtype=np.float32)
+    for cls, val in dict(class_weight).items():
+        w[yi == int(cls)] = float(val)
+    return w
+
+
 def custom_activation(logits):
     """sgan.py:125-129: sum(exp)/(sum(exp)+1) = sigmoid(logsumexp(logits))."""
     import torch
@@ -280,9 +353,15 @@ class DiscriminatorTrainer:
         acc = (logits.argmax(dim=-1) == yt).float().mean()
         return (float(loss), float(acc)) if sync else (loss, acc)
 
-    def train_on_batch_d(self, x, y, sample_weight=None, sync=True):
-        """d_model.train_on_batch([xz,yz,xy], y[, weights]) -> loss (float, or a 0-d CUDA tensor with ``sync=False``)."""
+    def train_on_batch_d(self, x, y, sample_weight=None, sync=True, class_weight=None):
+        """d_model.train_on_batch([xz,yz,xy], y[, class_weight=w_classes]) -> loss (float, or a 0-d CUDA tensor with
+        ``sync=False``).  ``class_weight`` (sgan.py:529-530) becomes a per-sample weight the way Keras does it
+        (:func:`class_weight_to_sample_weight`)."""
         import torch
+        if class_weight is not None:
+            if sample_weight is not None:
+                raise ValueError("give class_weight or sample_weight, not both")
+            sample_weight = class_weight_to_sample_weight(y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else y, class_weight)
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).float()
         sw = None if sample_weight is None else torch.as_tensor(np.asarray(sample_weight)).to(self.device)
         if self.use_graph:
@@ -308,6 +387,22 @@ class DiscriminatorTrainer:
                     lg = self.model(*xs)
                 outs.append(torch.softmax(lg.float(), dim=-1).cpu())
         return torch.cat(outs).numpy()
+
+
+def _evaluate_c(trainer, x, y, batch_size=4096):
+    """c_model.evaluate([xz, yz, xy], y) (sgan.py:491: ``_, acc = c_model.evaluate(...)``): (sparse categorical
+    cross-entropy, accuracy) over all samples, inference mode (BatchNorm moving statistics, no dropout)."""
+    p = trainer.predict(x, batch_size=batch_size).astype(np.float64)
+    yi = np.asarray(y).reshape(-1).astype(np.int64)
+    if len(yi) != len(p):
+        raise ValueError("evaluate: %d label(s) for %d sample(s)" % (len(yi), len(p)))
+    if len(yi) == 0:
+        return 0.0, 0.0
+    pt = np.clip(p[np.arange(len(yi)), yi], 1e-7, 1.0 - 1e-7)
+    return float(-np.log(pt).mean()), float((p.argmax(axis=1) == yi).mean())
+
+
+DiscriminatorTrainer.evaluate = _evaluate_c
 
 
 def define_discriminator(xz_shape=(128, 128, 1), yz_shape=(128, 128, 1), xy_shape=(128, 128, 1), n_classes=3, device=None):

@@ -265,3 +265,112 @@ def test_parameter_counts_match_the_model_summaries_exactly(mods):
     with torch.no_grad():
         h = d.branches[0](x[0])
     assert tuple(h.shape) == (2, 32, 16, 16) and d(*x).shape == (2, 3)          # 128 -> 64 -> 32 -> 16 per branch
+
+
+def test_keras_layout_weights_round_trip_and_flat_list(mods):
+    """set_keras_weights is the inverse of keras_weights (conv kernels (kh,kw,cin,cout), dense kernels (in,out)); the flat
+    ``model.get_weights()`` list loads in both layer orders; a wrong shape is refused.  The arrays are also run through the
+    NumPy restatement of the Keras layers (oracle_np.dnn_forward), which reads them in Keras layout on its own."""
+    import oracle_np as O
+    dnn, _, _ = mods
+    rng = np.random.default_rng(12)
+    h, w = 12, 10
+    torch.manual_seed(1)
+    src = dnn.Classifier([(h, w, 1)] * 3, 3).eval()
+    for mod in src.modules():
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)):
+            torch.nn.init.normal_(mod.bias, 0.0, 0.1)
+    convs, dense = src.keras_weights()
+    x = [rng.uniform(-1, 1, (5, h, w, 1)).astype(np.float32) for _ in range(3)]
+    want = src.predict(x, autocast_dtype=None)
+    torch.manual_seed(2)
+    dst = dnn.Classifier([(h, w, 1)] * 3, 3).eval()
+    assert np.abs(dst.predict(x, autocast_dtype=None) - want).max() > 1e-3          # different weights to start with
+    dst.set_keras_weights(convs, dense)
+    np.testing.assert_array_equal(dst.predict(x, autocast_dtype=None), want)
+    assert np.abs(want - O.dnn_forward(*[a[..., 0] for a in x], convs, dense)).max() < 1e-5
+    flat_depth = [a for b in convs for a in b[:2]] + [a for b in convs for a in b[2:]] + [a for kb in dense for a in kb]
+    flat_branch = [a for b in convs for a in b] + [a for kb in dense for a in kb]
+    for flat, order in ((flat_depth, "depth"), (flat_branch, "branch")):
+        torch.manual_seed(3)
+        m = dnn.Classifier([(h, w, 1)] * 3, 3).eval().set_keras_weight_list(flat, order=order)
+        np.testing.assert_array_equal(m.predict(x, autocast_dtype=None), want)
+    with pytest.raises(ValueError):
+        dst.set_keras_weights([(c[0].transpose(3, 2, 0, 1), c[1], c[2], c[3]) for c in convs], dense)       # torch layout: refused
+    with pytest.raises(ValueError):
+        dst.set_keras_weight_list(flat_depth[:-1])
+
+
+def test_keras_layout_known_answer_through_the_importer(mods):
+    """Hand-derived answer that only holds if (kh, kw, cin, cout) / (in, out) are read as Keras writes them.
+    4x4 all-ones planes; conv1 kernel (3,3,1,64) = 1 on channel 0 only; TF 'same' stride 2 gives channel 0 =
+    [[9, 6], [6, 4]] (pad bottom/right).  conv2 kernel (3,3,64,32): k2[ky, kx, 0, 0] = 10 ky + kx + 1, everything else 0:
+    the single 1x1 output of channel 0 reads taps (0..1, 0..1) of the 2x2 image plus the zero pad:
+    1*9 + 2*6 + 11*6 + 12*4 = 135.  Dense kernels (in, out): dense[0][0][0, 1] = 2 routes feature 0 (branch xz, channel 0) to
+    unit 1 -> 270; dense_1 passes unit 1 to unit 2; dense_2 kernel [2, :] = (0, 1, 0) and bias (0, 0, 269): logits (0, 270, 269)."""
+    dnn, _, _ = mods
+    m = dnn.Classifier([(4, 4, 1)] * 3, 3).eval()
+    k1 = np.zeros((3, 3, 1, 64)); k1[:, :, 0, 0] = 1.0
+    k2 = np.zeros((3, 3, 64, 32))
+    for ky in range(3):
+        for kx in range(3):
+            k2[ky, kx, 0, 0] = 10 * ky + kx + 1
+    z1, z2 = np.zeros(64), np.zeros(32)
+    convs = [(k1, z1, k2, z2), (np.zeros_like(k1), z1, np.zeros_like(k2), z2), (np.zeros_like(k1), z1, np.zeros_like(k2), z2)]
+    d0 = np.zeros((96, 64)); d0[0, 1] = 2.0
+    d1 = np.zeros((64, 64)); d1[1, 2] = 1.0
+    d2 = np.zeros((64, 3)); d2[2, 1] = 1.0
+    m.set_keras_weights(convs, [(d0, np.zeros(64)), (d1, np.zeros(64)), (d2, np.array([0.0, 0.0, 269.0]))])
+    x = [torch.ones(1, 1, 4, 4) for _ in range(3)]
+    with torch.no_grad():
+        f = m.features(*x)[0].numpy()
+        lg = m.logits(*x)[0].numpy()
+    assert f.shape == (96,) and f[0] == 135.0 and np.count_nonzero(f) == 1
+    np.testing.assert_array_equal(lg, [0.0, 270.0, 269.0])
+    p = m.predict([np.ones((1, 4, 4, 1), np.float32)] * 3, autocast_dtype=None)[0]
+    assert abs(p[1] - 1.0 / (1.0 + np.exp(-1.0))) < 1e-6 and p[0] < 1e-30
+    loss, acc = m.evaluate([np.ones((2, 4, 4, 1), np.float32)] * 3, [1, 2])
+    assert acc == 0.5 and abs(loss - 0.5 * (np.log1p(np.exp(-1.0)) + np.log1p(np.exp(1.0)))) < 1e-6
+
+
+def test_discriminator_keras_weights_evaluate_and_class_weight(mods):
+    """sgan: Keras-layout export / import with the BatchNorm moving statistics (gamma, beta, moving_mean, moving_variance),
+    c_model.evaluate (sgan.py:491), and class_weight on the d update (sgan.py:529-530) as Keras turns it into sample weights."""
+    _, sgan, _ = mods
+    torch.manual_seed(0)
+    src = sgan.Discriminator(((16, 16, 1),) * 3, 3)
+    tr = sgan.DiscriminatorTrainer(src, amp_dtype=None, ddp=False)
+    rng = np.random.default_rng(4)
+    x = [rng.uniform(-1, 1, (8, 16, 16, 1)).astype(np.float32) for _ in range(3)]
+    y = rng.integers(0, 3, 8)
+    for _ in range(3):                                   # move the BatchNorm statistics and the parameters off their defaults
+        tr.train_on_batch_c(x, y)
+    branches, dense = src.keras_weights()
+    assert branches[0][0][0].shape == (3, 3, 1, 128) and len(branches[0][0]) == 6 and dense[0][0].shape == (384, 64) and len(dense[2]) == 2
+    want = tr.predict(x)
+    torch.manual_seed(5)
+    dst = sgan.Discriminator(((16, 16, 1),) * 3, 3).set_keras_weights(branches, dense)
+    tr2 = sgan.DiscriminatorTrainer(dst, amp_dtype=None, ddp=False)
+    np.testing.assert_array_equal(tr2.predict(x), want)
+    loss, acc = tr2.evaluate(x, y)
+    p = want.astype(np.float64)
+    assert abs(loss + np.log(np.clip(p[np.arange(8), y], 1e-7, 1 - 1e-7)).mean()) < 1e-12
+    assert acc == float((p.argmax(1) == y).mean())
+    with pytest.raises(ValueError):
+        dst.set_keras_weights(branches[:2], dense)
+    # class_weight -> sample weights: int(y) truncates the smoothed labels (0.7..1.2 -> class 0 or 1)
+    yr = np.array([[0.71], [0.99], [1.0], [1.19], [0.3], [1.05], [0.85], [1.1]])
+    w = sgan.class_weight_to_sample_weight(yr, {0: 1.0, 1: 2.5, 2: 4.0})
+    np.testing.assert_array_equal(w, [1.0, 1.0, 2.5, 2.5, 1.0, 2.5, 1.0, 2.5])
+    torch.manual_seed(7)
+    a = sgan.Discriminator(((16, 16, 1),) * 3, 3); b = sgan.Discriminator(((16, 16, 1),) * 3, 3)
+    b.load_state_dict(a.state_dict())
+    ta = sgan.DiscriminatorTrainer(a, amp_dtype=None, ddp=False); tb = sgan.DiscriminatorTrainer(b, amp_dtype=None, ddp=False)
+    a.drop.p = b.drop.p = 0.0                            # dropout off: the two updates must be identical
+    la = ta.train_on_batch_d(x, yr, class_weight={0: 1.0, 1: 2.5, 2: 4.0})
+    lb = tb.train_on_batch_d(x, yr, sample_weight=w)
+    assert la == lb
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    with pytest.raises(ValueError):
+        ta.train_on_batch_d(x, yr, sample_weight=w, class_weight={0: 1.0})

@@ -528,7 +528,8 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
     outs = {}
     for big in ("0", "1", "ring"):
-        # "ring": the 256 x 256 kernel with the 5-slot operand-stage ring and counted vmcnt (k_svm_gemm_i8_256r)
+        # "ring": the 256 x 256 tile with the 5-slot operand-stage ring, counted vmcnt and interleaved DMA issue
+        # (k_svm_gemm_ring, the default); "1": the two-stage 256 x 256 kernel; "0": the 128 x 128 kernel
         monkeypatch.setenv("RML_GEMM_BIG", "1" if big == "ring" else big)
         monkeypatch.setenv("RML_GEMM_RING", "1" if big == "ring" else "0")
         svc.decision_function_shape = "ovo"
@@ -537,7 +538,7 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
         ref = want if C > 2 else -want
         assert np.abs(got - ref).max() <= _tol(m, ref), big
         outs[big] = (got, svc.predict(X), rml.GpuCalibratedClassifier(svc).predict_proba(X))
-    monkeypatch.setenv("RML_GEMM_RING", "0")
+    monkeypatch.delenv("RML_GEMM_RING")
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
     # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
     np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
