@@ -67,61 +67,89 @@ class DataGenerator(object):
         self.balance = balance
         self.device = device
 
-    def _augment(self, x_batch, y_batch, class_weights):
-        """train.py:84-185 ``augment``: the draws here, in the reference's order; the arrays on the GPU."""
+    # -- the random draws, on the host, in the reference's order ---------------------------------------------
+    def _draw_jobs(self, x_batch, y_batch, class_weights):
+        """train.py:84-185 ``augment`` as a job list: [(kind, sample index, one parameter per projection)] and the labels.
+        Order of the draws = order of the reference's calls: per sample and repetition the angles of the rotated tuple (one
+        ``np.random.uniform`` per projection), the factor of the zoomed tuple (one per tuple), the noise of the noisy tuple (one
+        ``Generator(PCG64()).normal`` per projection)."""
         rg = np.random.Generator(np.random.PCG64())                     # train.py:85
-        jobs = []                   # (kind, sample index, per-projection parameters)
-        aug_y = []
+        jobs, labels = [], []
         for si, (xb, yb) in enumerate(zip(x_batch, y_batch)):
             for _ in range(int(np.round(class_weights[yb]))):
                 if self.rotation_range is not None:
-                    ang = [np.random.uniform(-1 * self.rotation_range, self.rotation_range) for _ in xb]     # one per projection
-                    jobs.append(("rotate", si, ang)); aug_y.append(yb)
+                    jobs.append(("rotate", si, [np.random.uniform(-1 * self.rotation_range, self.rotation_range) for _ in xb]))
+                    labels.append(yb)
                 if self.zoom_range is not None:
-                    zf = np.random.uniform(1.0 - self.zoom_range, 1.0 + self.zoom_range)                     # one per tuple
-                    jobs.append(("zoom", si, [zf] * len(xb))); aug_y.append(yb)
+                    zf = np.random.uniform(1.0 - self.zoom_range, 1.0 + self.zoom_range)
+                    jobs.append(("zoom", si, [zf] * len(xb)))
+                    labels.append(yb)
                 if self.noise_sd is not None:
-                    nz = [rg.normal(scale=self.noise_sd) for _ in xb]                                         # one per projection
-                    jobs.append(("noise", si, nz)); aug_y.append(yb)
-        if not jobs:
-            return [], np.array(aug_y)
-        nproj = len(x_batch[0])
+                    jobs.append(("noise", si, [rg.normal(scale=self.noise_sd) for _ in xb]))
+                    labels.append(yb)
+        return jobs, labels
+
+    def _run_jobs(self, x_batch, jobs, to_host):
+        """The array work of a job list on the GPU.  Planes are batched per (projection, kind, plane shape): samples of
+        different radar arenas may sit in one data set (the reference augments every sample on its own and only
+        ``process_samples`` brings them to a common size).  Returns per job a tuple of planes: numpy arrays of the input's
+        dtype (``to_host``) or CUDA float32 tensors."""
+        nproj = len(x_batch[0]) if len(x_batch) else 0
         outs = [[None] * nproj for _ in jobs]
         for pi in range(nproj):
-            for kind in ("rotate", "zoom", "noise"):
-                idx = [j for j, job in enumerate(jobs) if job[0] == kind]
-                if not idx:
-                    continue
+            groups = {}
+            for j, (kind, si, _) in enumerate(jobs):
+                groups.setdefault((kind, tuple(np.shape(x_batch[si][pi]))), []).append(j)
+            for (kind, shape), idx in groups.items():
                 planes = np.stack([np.asarray(x_batch[jobs[j][1]][pi], dtype=np.float32) for j in idx])
                 if kind == "rotate":
-                    par = np.stack([rotation_params(jobs[j][2][pi], planes.shape[1:]) for j in idx])
+                    par = np.stack([rotation_params(jobs[j][2][pi], shape) for j in idx])
                 else:
                     par = np.array([jobs[j][2][pi] for j in idx], dtype=np.float64)
-                res = augment_planes(planes, kind, par, self.device).cpu().numpy()
+                res = augment_planes(planes, kind, par, self.device)
+                if to_host:
+                    res = res.cpu().numpy()
                 for k, j in enumerate(idx):
-                    outs[j][pi] = res[k]
-        return [tuple(o) for o in outs], np.array(aug_y)
+                    plane = res[k]
+                    if to_host:
+                        plane = plane.astype(np.asarray(x_batch[jobs[j][1]][pi]).dtype, copy=False)
+                    outs[j][pi] = plane
+        return [tuple(o) for o in outs]
 
-    def flow(self, x, y, batch_size=32, save_to_dir=None, save_prefix='./datasets/augment'):
-        """Yield batches of augmented radar data, forever (train.py:52-83, 187-214); the caller breaks the loop."""
-        c = collections.Counter(y)
-        mc = c.most_common()
-        if self.balance:
-            class_weights = {k: mc[0][1] / cnt for k, cnt in mc}
-        else:
-            class_weights = {k: 1 for k, _ in mc}
-        batch = 0
+    def _augment(self, x_batch, y_batch, class_weights):
+        jobs, labels = self._draw_jobs(x_batch, y_batch, class_weights)
+        if not jobs:
+            return [], np.array(labels)
+        return self._run_jobs(x_batch, jobs, to_host=True), np.array(labels)
+
+    def _class_weights(self, y):
+        """Repetitions per class (train.py:187-196): with ``balance`` the most frequent class counts once and the others
+        count (its size / their size), rounded when used; without it every class counts once."""
+        counts = collections.Counter(y).most_common()
+        top = counts[0][1]
+        return {cls: (top / n if self.balance else 1) for cls, n in counts}
+
+    def flow(self, x, y, batch_size=32):
+        """Generator protocol of train.py:52-83: walks ``x`` / ``y`` in slices of ``batch_size`` (the last one shorter), yields
+        ``(augmented tuples, augmented labels)`` per slice and starts over when the data set is exhausted -- it never stops, the
+        caller counts the batches (train.py:508-515).  (The reference can also dump every input batch to a pickle on the way;
+        that debugging aid is not part of the path.)"""
+        weights = self._class_weights(y)
+        n = len(x)
         while True:
-            for pos in range(0, len(x), batch_size):
-                remaining = len(x) - pos
-                end = remaining if remaining < batch_size else batch_size
-                x_batch = x[pos:pos + end]
-                y_batch = y[pos:pos + end]
-                yield self._augment(x_batch, y_batch, class_weights)
-                if save_to_dir is not None:
-                    import os
-                    import pickle
-                    fname = f'batch_{str(batch)}_{str(pos)}.pickle'
-                    with open(os.path.join(save_prefix, fname), 'wb') as fp:
-                        pickle.dump({'x_batch': x_batch, 'y_batch': y_batch}, fp)
-            batch += 1
+            for lo in range(0, n, batch_size):
+                hi = min(lo + batch_size, n)
+                yield self._augment(x[lo:hi], y[lo:hi], weights)
+
+    def augment_dataset(self, x, y):
+        """One pass of ``flow`` over the whole data set (what an epoch of train.py:506-515 appends to the training set) as ONE
+        batched device job: the draws are made for every sample first, in the order the reference makes them batch by batch
+        (its ``np.random.uniform`` stream simply continues across batches; its noise generator is a fresh, unseeded
+        ``Generator(PCG64())`` per batch, here one per call), then every (projection, kind, shape) group is one ``rml_augment``
+        launch and the results stay on the GPU.  Returns ``(tuples of CUDA float32 planes, labels as numpy)``; feed the planes
+        to ``process_samples`` / the SVM front doors without a host round trip."""
+        weights = self._class_weights(y)
+        jobs, labels = self._draw_jobs(x, y, weights)
+        if not jobs:
+            return [], np.array(labels)
+        return self._run_jobs(x, jobs, to_host=False), np.array(labels)

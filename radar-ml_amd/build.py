@@ -37,13 +37,14 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, variant=None, defines=()):
+def build(force=False, verbose=False, variant=None, defines=(), only=()):
     """Compile every csrc/*.hip for gfx950 into one shared library.  Returns its path.
-    ``variant``/``defines`` build an experimental copy libradarml_hip_<variant>.so with extra -D flags."""
+    ``variant``/``defines`` build an experimental copy libradarml_hip_<variant>.so with extra -D flags; with ``only`` (source
+    file names) just those sources are compiled with the flags and the other objects come from the main build."""
     global LIB
     if variant:
         lib_out = os.path.join(HERE, "libradarml_hip_%s.so" % variant)
-        return _build(lib_out, os.path.join(HERE, "build", variant), verbose, ["-D" + d for d in defines])
+        return _build(lib_out, os.path.join(HERE, "build", variant), verbose, ["-D" + d for d in defines], only=tuple(only))
     global FORCE_ALL
     if not force and not is_stale():
         return LIB
@@ -51,8 +52,9 @@ def build(force=False, verbose=False, variant=None, defines=()):
     return _build(LIB, os.path.join(HERE, "build"), verbose, [])
 
 
-def _build(LIB, objdir, verbose, extra):
+def _build(LIB, objdir, verbose, extra, only=()):
     os.makedirs(objdir, exist_ok=True)
+    maindir = os.path.join(HERE, "build")
     hipcc = _hipcc()
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra)
     objs = []
@@ -63,6 +65,9 @@ def _build(LIB, objdir, verbose, extra):
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if only and os.path.basename(src) not in only:
+            objs.append(os.path.join(maindir, os.path.basename(src) + ".o"))     # unchanged source: the main build's object
+            continue
         objs.append(obj)
         # per-object staleness: project.hip alone takes minutes, the others seconds
         if same_flags and not FORCE_ALL and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
@@ -89,6 +94,8 @@ def _build(LIB, objdir, verbose, extra):
 if __name__ == "__main__":
     if "--variant" in sys.argv:
         i = sys.argv.index("--variant")
-        print(build(variant=sys.argv[i + 1], defines=sys.argv[i + 2:], verbose=True))
+        rest = sys.argv[i + 2:]
+        only = [a for a in rest if a.endswith(".hip")]
+        print(build(variant=sys.argv[i + 1], defines=[a for a in rest if not a.endswith(".hip")], only=only, verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -108,10 +108,13 @@ def _as_device_volumes(a, device=None):
     return t.to(device=device, non_blocking=True).contiguous(), _lib.VOL_U8
 
 
-def _slice_indices(ijk, B, X, Y, Z, dev):
+def _slice_indices(ijk, B, X, Y, Z, dev, validate=True):
     """ijk as (B,3) or (B,T,3) (numpy / torch, any integer dtype) -> (contiguous int32 CUDA tensor (B*T,3), T).
     Raises like the reference's NumPy indexing would: one (i,j,k) (or T of them) per frame, every index within
-    [-size, size) (Python negative-index wrap) -- the kernel never sees an index it would have to clamp."""
+    [-size, size) (Python negative-index wrap) -- the kernel never sees an index it would have to clamp.  The range check
+    runs on the caller's integers BEFORE the int32 cast (an int64 index must not wrap into range); host arrays are checked
+    on the host, device tensors cost one synchronising read-back.  ``validate=False``: indices this package derived itself
+    (derive_targets) -- in range by construction, no host synchronisation on the asynchronous path."""
     torch = _torch()
     t = torch.as_tensor(np.asarray(ijk) if not isinstance(ijk, torch.Tensor) else ijk)
     if t.ndim == 1 and B == 1:
@@ -123,12 +126,16 @@ def _slice_indices(ijk, B, X, Y, Z, dev):
     T = 1 if t.ndim == 2 else int(t.shape[1])
     if T < 1:
         raise ValueError("ijk holds no target")
+    if t.dtype.is_floating_point or t.dtype == torch.bool:
+        raise IndexError("ijk must hold integers")
+    if validate:
+        flat = t.reshape(-1, 3)
+        size = torch.tensor([X, Y, Z], dtype=flat.dtype, device=flat.device)
+        bad = ((flat >= size) | (flat < -size)).any(dim=0).cpu().numpy()       # in the caller's dtype, where the tensor lives
+        for ax in range(3):
+            if bad[ax]:
+                raise IndexError("index out of bounds for axis %d with size %d" % (ax, (X, Y, Z)[ax]))
     t = t.to(device=dev, dtype=torch.int32).reshape(-1, 3).contiguous()
-    size = torch.tensor([X, Y, Z], dtype=torch.int32, device=dev)
-    bad = ((t >= size) | (t < -size)).any(dim=0).cpu().numpy()
-    for ax in range(3):
-        if bad[ax]:
-            raise IndexError("index out of bounds for axis %d with size %d" % (ax, (X, Y, Z)[ax]))
     return t, T
 
 
@@ -201,10 +208,12 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
     ijk_t = None
     T = 1
     if m == _lib.MODE_SLICE:
+        derived = False
         if ijk is None:
             # no SDK targets: derive the strongest return(s) per frame on the GPU (common.py:49-80), then slice there
             ijk = derive_targets(v, num_targets)
-        ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev)
+            derived = True
+        ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
     R = B * T                           # output rows
     feat = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=dev)
     if feat.shape[0] != R or feat.shape[1] < D or feat.device != dev:

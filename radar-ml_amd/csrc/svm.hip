@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 // 574 us vs 501 us on 8192 x 2560: that was the GRID, not the tile -- 32 x 10 = 320 workgroups on 256 CUs are two rounds
 // with the second one a quarter full.  It is therefore only used when the launch has enough tiles for >= ~2.5 rounds
 // (rml_project_svm sizes its chunks for it), and the 128x128 kernel keeps the small batches.
-// Sample tiles are paired: tile_exact[] is evaluated per 256 samples (k_tile_flags group = 2), partial slot 2*stile carries the
-// sum over the 256 SV rows and slot 2*stile+1 is zeroed.
+// Sample tiles are paired: tile_exact[] is evaluated per 256 samples (k_tile_flags group = 2); the partial slots 2*stile and
+// 2*stile+1 carry the two 128-row halves, summed exactly like the 128x128 kernel sums them.
 // ------------------------------------------------------------------------------------------
 constexpr int kBig = 256;
 constexpr int kBigStageBytes = 2 * kBig * kStepBytes;     // 64 KiB: [SV 256 x 128 B][samples 256 x 128 B]
@@ -631,11 +631,10 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
         if (h == 0 && n < a.N) {
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                double t = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
-                t += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
-                // two 128-row SV tiles per block: slot 2*stile carries the sum, 2*stile+1 (when it exists) is zero
-                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = t;
-                if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                // one partial per 128 SV rows, summed like the 128 x 128 kernel sums them (see k_svm_gemm_ring)
+                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
+                if (2 * stile + 1 < a.ST)
+                    a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
             }
         }
     }
@@ -670,18 +669,21 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
 // I = a0 2^24 + a1 2^16 + a2 2^8 + a3 with a_i in [-128, 127].  Then  u_x . u_s = 2^-14 sum_{i,j} 2^-8(i+j) (a_i^x . a_j^s)
 // and every digit-plane product is an exact int32 GEMM (|.| <= 2^14 K < 2^29).  The ten pairs with i + j <= 3 are kept (the
 // dropped ones weigh 2^-46 per digit product: typical 1e-8 on u.u), grouped by g = i + j and accumulated from
-// the least significant group up IN THE SAME int32 accumulator: after a group the accumulator is divided by 256 with
-// rounding, (acc + 128) >> 8, and the next group accumulates on top (4 x 2^28.3 < 2^31).  Before the top group the running
-// value is split acc = 256 q + r: q stays, the 8-bit remainders r are packed four to a register (32 VGPRs), so that
-// u.u = 2^-22 (256 (G0 + q) + r) carries 2^-23 absolute precision on a quantity of magnitude <= D/4 -- the arithmetic class
-// of the float64 path at ~2.8x its rate.  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED
+// the least significant group up IN THE SAME int32 accumulator: after g = 3 and g = 2 the accumulator is divided by 256 with
+// rounding, (acc + 128) >> 8, and the next group accumulates on top (4 x 2^28.3 < 2^31), which leaves R1 = G1 + G2/2^8 + G3/2^16.
+// The top group G0 needs its own 32 bits (u.u = 2^-14 (G0 + R1/256) is a 38-bit quantity): it is computed FIRST and parked in a
+// per-workgroup HBM scratch tile (256 KiB, written once, read once in the epilogue by the lane that wrote it: L2 traffic that
+// is nothing next to ten K loops) -- a second accumulator set or packed remainders in registers pushed the kernel over 256
+// VGPRs and the spills landed in the K loop.  u.u carries 2^-23 absolute precision on a quantity of magnitude <= D/4 -- the
+// arithmetic class of the float64 path at ~3x its rate.  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED
 // values in float64.  The K loop runs over (pair, K-step); the DMA cursors run one and two steps ahead across pair boundaries.
 // ------------------------------------------------------------------------------------------
 constexpr int kOpStageBytes = kBig * kStepBytes;          // 32 KiB
 constexpr int kRingSlots = 5;
 constexpr int kDigPairs = 10;
-constexpr uint64_t kDigI = 0x0102103210ull;     // nibble p: sample digit of pair p   (0 = most significant)
-constexpr uint64_t kDigJ = 0x0010120123ull;     // nibble p: SV digit of pair p; pairs 0-3: g = 3, 4-6: g = 2, 7-8: g = 1, 9: g = 0
+constexpr uint64_t kDigI = 0x1021032100ull;     // nibble p: sample digit of pair p   (0 = most significant)
+constexpr uint64_t kDigJ = 0x0101201230ull;     // nibble p: SV digit of pair p; pair 0: g = 0, 1-4: g = 3, 5-7: g = 2, 8-9: g = 1
+constexpr int kDigStashBytes = kBig * kBig * 4;  // the parked top-group accumulators of one workgroup
 
 struct RingArgs {
     const uint8_t* sv; const uint8_t* x;       // operand bases (digit plane 0)
@@ -696,6 +698,7 @@ struct RingArgs {
     const double* W;
     double gs; int kernel;
     double* partial; int64_t Npart;
+    int32_t* stash;                            // DIG: gridDim.x * 256 KiB of scratch for the top digit group
 };
 
 // ring tile of block b: false = nothing to do
@@ -742,20 +745,20 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     int64_t px = 0, ps = 0;                            // plane offsets of the current pair
     int qx = 0, qs = 0;                                // pair indices (DIG)
     if constexpr (DIG) { px = (int64_t)(kDigI & 15) * a.x_plane; ps = (int64_t)(kDigJ & 15) * a.sv_plane; }
-    auto adv_x = [&]() {
+    auto adv_x = [&]() __attribute__((always_inline)) {
         ox += kStepBytes;
         if constexpr (DIG) { if (ox == kbytes) { ox = 0; ++qx; px = (int64_t)((kDigI >> (4 * qx)) & 15) * a.x_plane; } }
     };
-    auto adv_s = [&]() {
+    auto adv_s = [&]() __attribute__((always_inline)) {
         os += kStepBytes;
         if constexpr (DIG) { if (os == kbytes) { os = 0; ++qs; ps = (int64_t)((kDigJ >> (4 * qs)) & 15) * a.sv_plane; } }
     };
-    auto burst_s = [&](int slot) {
+    auto burst_s = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16(gsv[q] + ps + os, smem + slot * kOpStageBytes + wave * 4096 + q * 1024);
         adv_s();
     };
-    auto burst_x = [&](int slot) {
+    auto burst_x = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16(gx[q] + px + ox, smem + slot * kOpStageBytes + wave * 4096 + q * 1024);
         adv_x();
@@ -788,11 +791,25 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     int sa = 0;                                        // slot of the SV stage of the step being computed
     int sx = 3, ss = 4;                                // slots of the two stages step 0 sends
     int t = 0;                                         // global step
-    auto step = [&]() {
+    // Fragment registers: two sets.  The loop is ROTATED by one MFMA group: the last sub-step (kk = 3) of a step is issued
+    // after the next step's barrier, right behind that step's first fragment reads.  After a barrier all eight waves read
+    // fragments at once (128 KiB per step through a 256 B/clk LDS = ~500 cycles in which, unrotated, no wave has an MFMA to
+    // issue); the deferred group is matrix work that needs no LDS.
+    v4i af[2][4], bf[2][2];
+    auto mfma_half = [&](int set, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set][i], bf[set][j], acc[i][j], 0, 0, 0);
+    };
+    auto step = [&](auto first_) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_)::value;      // first step of a segment: no deferred group pending
         const bool hx = t + 1 < TT, hs = t + 2 < TT;
-        // stages 2t and 2t+1 landed: everything this wave sent except the newest stage (the SV stage of step t+1)
-        if (hx) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stages 2t and 2t+1 landed: everything this wave sent except the newest stage (the SV stage of step t+1); and this
+        // wave's fragment reads of step t-1 are complete (their slots are released at the barrier)
+        if (hx) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // ... for every wave's pieces; and step t-1 is consumed by everyone
         asm volatile("" ::: "memory");
         const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
@@ -804,34 +821,32 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
         sx = sx + 2 >= kRingSlots ? sx + 2 - kRingSlots : sx + 2;
         ss = ss + 2 >= kRingSlots ? ss + 2 - kRingSlots : ss + 2;
         const int64_t offx = px + ox, offs = ps + os;
-        v4i af[2][4], bf[2][2];
+        auto reads = [&](int set, int kk) __attribute__((always_inline)) {
+            const int ch = 2 * kk + chalf;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) af[0][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((chalf ^ asw[u]) << 4));
+            for (int u = 0; u < 4; ++u) af[set][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((ch ^ asw[u]) << 4));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) bf[0][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((chalf ^ bsw[u]) << 4));
+            for (int u = 0; u < 2; ++u) bf[set][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((ch ^ bsw[u]) << 4));
+        };
+        auto dma = [&](int g) __attribute__((always_inline)) {                         // DMA instruction 0..7 of this step
+            if (g < 4) { if (hx) glds16(gx[g] + offx, dx + g * 1024); }
+            else       { if (hs) glds16(gsv[g - 4] + offs, dsv + (g - 4) * 1024); }
+        };
+        // group r of the step: r = 0 is the deferred kk = 3 of the previous step (set 1), r = 1..3 are kk = 0..2 of this one
+        reads(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
-                const int ch = 2 * (kk + 1) + chalf;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    af[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((ch ^ asw[u]) << 4));
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    bf[(kk + 1) & 1][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((ch ^ bsw[u]) << 4));
+        for (int r = 0; r < 4; ++r) {
+            const int set = (r + 1) & 1;                // r = 0 -> set 1 (deferred), r = 1 -> set 0 (kk = 0), ...
+            if (r >= 1) {
+                reads(r & 1, r);                        // fragments of kk = r into the set the previous group has just used
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int i = 2 * half; i < 2 * half + 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                if (!(FIRST && r == 0)) mfma_half(set, half);
                 __builtin_amdgcn_sched_barrier(0);
-                const int g = 2 * kk + half;            // DMA instruction 0..7 of this step
-                if (g < 4) { if (hx) glds16(gx[g] + offx, dx + g * 1024); }
-                else       { if (hs) glds16(gsv[g - 4] + offs, dsv + (g - 4) * 1024); }
+                dma(2 * r + half);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -839,38 +854,56 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
         if (hs) adv_s();
         ++t;
     };
+    auto flush = [&]() __attribute__((always_inline)) {                               // the deferred kk = 3 of a segment's last step
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(1, 0); mfma_half(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto segment = [&](int nsteps) __attribute__((always_inline)) {
+        step(std::true_type{});
+        for (int n = nsteps - 1; n > 0; --n) step(std::false_type{});
+        flush();
+    };
 
-    int rem[DIG ? 32 : 1];                             // DIG: 8-bit remainders of the split before the top group
+    // DIG: the top group's accumulators are parked in this workgroup's scratch tile, 16 bytes per lane and store, coalesced
+    v4i* stash = nullptr;
     if constexpr (DIG) {
-        auto shift8 = [&]() {
+        stash = reinterpret_cast<v4i*>(a.stash) + (int64_t)blockIdx.x * (kDigStashBytes / 16) + tid;
+        segment(a.KT);                                 // pair 0: g = 0
+        {
+            v4i* sp = stash;                           // a running pointer: 32 hoisted 64-bit addresses would be spilled
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
-        };
-        // groups g = 3 (pairs 0-3), g = 2 (4-6), g = 1 (7-8): the remainders do not exist yet, so they cost no registers here
-        for (int n = 4 * a.KT; n > 0; --n) step();
-        shift8();
-        for (int n = 3 * a.KT; n > 0; --n) step();
-        shift8();
-        for (int n = 2 * a.KT; n > 0; --n) step();
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        v4i v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+                        *sp = v;
+                        sp += 512;
+                        asm volatile("" : "+v"(sp));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) rem[r] = 0;
+                        for (int r = 0; r < 4; ++r) acc[i][j][4 * r4 + r] = 0;
+                    }
+        }
+        // stores and DMA loads share the VM counter and may complete out of order with respect to each other: drain once, so
+        // that the counted waits of the next segment see DMA instructions only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // groups g = 3 (pairs 1-4), g = 2 (5-7), g = 1 (8-9); after g = 3 and g = 2 the accumulator is divided by 256 with rounding
+#pragma nounroll                                       // one copy of the step bodies for the three groups (instruction cache)
+        for (int g = 0; g < 3; ++g) {
+            segment((4 - g) * a.KT);
+            if (g < 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int v = acc[i][j][r];
-                    rem[(i * 2 + j) * 4 + (r >> 2)] |= (v & 255) << (8 * (r & 3));
-                    acc[i][j][r] = v >> 8;
-                }
-        for (int n = a.KT; n > 0; --n) step();         // group g = 0 (pair 9)
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
+            }
+        }
     } else {
-        for (int n = a.KT; n > 0; --n) step();
+        segment(a.KT);
     }
 
     // ---- fused float64 epilogue; the per-SV table is loaded now, into slot 4 ----
@@ -886,22 +919,29 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     }
     if constexpr (DIG) {
         // one 64-sample quarter (= one wave column wc) at a time through LDS as float64:
-        // u.u = 2^-22 (256 acc + rem);  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u.u);  a.gs = gamma s^2
+        // u.u = 2^-22 (256 G0 + R1), G0 from the scratch tile;  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u.u);  a.gs = gamma s^2
         double* gd = reinterpret_cast<double*>(smem);      // [256 SVs][64 samples]
         const int nq = tid & 63, qd = tid >> 6;            // sample column of the quarter, SV group (32 rows)
         for (int pass = 0; pass < 4; ++pass) {
             __syncthreads();
             if (wc == pass) {
+                const v4i* sp = stash;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                            const int nn = j * 32 + (lane & 31);
-                            const int rb = (rem[(i * 2 + j) * 4 + (r >> 2)] >> (8 * (r & 3))) & 255;
-                            gd[ml * 64 + nn] = ((double)acc[i][j][r] * 256.0 + (double)rb) * 0x1p-22;
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const v4i g0 = *sp;
+                            sp += 512;
+                            asm volatile("" : "+v"(sp));
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int r = 4 * r4 + rr;
+                                const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                                const int nn = j * 32 + (lane & 31);
+                                gd[ml * 64 + nn] = ((double)g0[rr] * 256.0 + (double)acc[i][j][r]) * 0x1p-22;
+                            }
                         }
             }
             __syncthreads();
@@ -986,10 +1026,11 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
             if (h == 0 && n < a.N) {
 #pragma unroll
                 for (int p = 0; p < PT; ++p) {
-                    double tsum = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
-                    tsum += x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
-                    a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = tsum;
-                    if (2 * stile + 1 < a.ST) a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = 0.0;
+                    // one partial per 128 SV rows, each the sum of two 64-row in-lane chains: the very values, in the very order,
+                    // the 128 x 128 kernel writes for these rows -- decision values do not depend on which kernel ran
+                    a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
+                    if (2 * stile + 1 < a.ST)
+                        a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
                 }
             }
         }
@@ -1454,6 +1495,7 @@ struct ChunkWs {
     uint8_t* q; float* f32; int32_t* isum; int64_t* isq; double* nsq; int32_t* flags;
     int32_t* tile_exact; int32_t* all_exact; double* partial;
     int8_t* dig; int64_t dig_plane; double* dnsq; int32_t* dflags;      // multi-digit operand of the general rows (or NULL)
+    int32_t* stash;                                                     // scratch tiles of k_svm_gemm_ring<.., 1>
     size_t bytes;
 };
 
@@ -1474,7 +1516,8 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     w.dig = (int8_t*)take(need_dig ? (size_t)4 * CH * m->Dq : 0);
     w.dnsq = (double*)take(need_dig ? (size_t)CH * 8 : 0);
     w.dflags = (int32_t*)take(need_dig ? (size_t)CH * 4 : 0);
-    if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; }
+    w.stash = (int32_t*)take(need_dig ? (size_t)ring_grid((int)((CH + kBig - 1) / kBig), (int)((m->Mpad + kBig - 1) / kBig)) * kDigStashBytes : 0);
+    if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; w.stash = nullptr; }
     w.bytes = off;
     return w;
 }
@@ -1534,7 +1577,7 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         ra.ld_sv = m->Dq; ra.ld_x = m->Dq; ra.sv_plane = m->Mpad * m->Dq; ra.x_plane = w.dig_plane;
         ra.KT = (int)(m->Kq / kStepBytes); ra.N = n; ra.Mpad = m->Mpad; ra.sv_rows = m->Mpad; ra.ST = ST; ra.FT = FT;
         ra.tile_exact = w.tile_exact; ra.want = 2; ra.x_nsq = w.dnsq; ra.sv_term = m->sv_dig_nsq; ra.W = m->W;
-        ra.gs = m->gamma * m->dig_s * m->dig_s; ra.kernel = RML_KERNEL_RBF; ra.partial = w.partial; ra.Npart = n;
+        ra.gs = m->gamma * m->dig_s * m->dig_s; ra.kernel = RML_KERNEL_RBF; ra.partial = w.partial; ra.Npart = n; ra.stash = w.stash;
         int rc = launch_gemm_ring<1>(m, ra, st);
         if (rc) return rc;
     }

@@ -35,10 +35,12 @@ def gather_labels(local, n_frames=None, group=None):
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
     local = local.contiguous()
-    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    try:
+    # the collective is chosen from the backend up front, the same on every rank (a fallback taken by some ranks only would
+    # desynchronise them): RCCL ("nccl") has the flat single-buffer form; gloo gathers into a list
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
-    except RuntimeError:                    # a backend without the flat form (gloo on CUDA tensors): list form, same result
+    else:
         parts = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(parts, local, group=group)
         out = torch.cat(parts, dim=0)

@@ -210,9 +210,10 @@ class GpuSVC(_Base):
             want_proba = self.has_calibration
         ijk_t = None
         if mode == "slice":
-            if ijk is None:
+            derived = ijk is None
+            if derived:
                 ijk = derive_targets(v, 1)[:, 0, :]      # DerivedTarget.get_derived_targets on the GPU (common.py:49-80)
-            ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev)
+            ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
             if T > 1:
                 # several targets per frame (predict.py:93-119 classifies every target of one image): slice rows first,
                 # then the SVM on the B*T rows; outputs are (B*T, ...) in frame-major order

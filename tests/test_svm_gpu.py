@@ -543,9 +543,10 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
     np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
     np.testing.assert_array_equal(outs["1"][2], outs["ring"][2])
-    # exact tiles give the same integers on both kernels; only the order of the float64 sums over SV tiles differs
-    assert np.abs(outs["0"][0] - outs["1"][0]).max() <= 1e-9 * max(1.0, float(np.abs(want).max()))
-    assert np.abs(outs["0"][2] - outs["1"][2]).max() <= 1e-9
+    # exact tiles give the same integers on every kernel, and the 256 x 256 kernels write one partial per 128 SV rows summed
+    # like the 128 x 128 kernel's: the decision values do not depend on the tile size (batch size, chunking, ingest dtype)
+    np.testing.assert_array_equal(outs["0"][0], outs["1"][0])
+    np.testing.assert_array_equal(outs["0"][2], outs["1"][2])
     # and on code rows straight from volumes (the fused pipeline's operand), labels identical between the kernels
     if name == "svm_walabot.npz":
         import torch
@@ -557,4 +558,4 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
             res[big] = {k: v.cpu().numpy() for k, v in o.items()}
         for k in ("label_vote", "label_calib"):
             np.testing.assert_array_equal(res["0"][k], res["1"][k])
-        assert np.abs(res["0"]["dec_ovo"] - res["1"]["dec_ovo"]).max() <= 1e-9
+        np.testing.assert_array_equal(res["0"]["dec_ovo"], res["1"]["dec_ovo"])
