@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-walabot", action="store_true", help="skip the secondary Walabot-arena-grid workload")
     ap.add_argument("--no-u8", action="store_true", help="skip the uint8-ingest row (the same frames as 1-byte voxels)")
+    ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
+                    help="u8: the headline step itself runs on uint8 volumes (per-workload profiles: tools/profile_round.sh); "
+                         "the line's value is then the uint8 rate")
     ap.add_argument("--walabot-frames", type=int, default=262144, help="frames per GPU of the 22x31x176 workload")
     ap.add_argument("--no-dnn", action="store_true", help="skip the multi-view CNN inference row (BASELINE configs[3])")
     ap.add_argument("--dnn-frames", type=int, default=65536, help="frames per GPU of the CNN inference row")
@@ -143,6 +146,9 @@ def run_workload(a, env, grid, frames, primary):
     reserve = 6 << 30
     B = int(min(frames, max(128, (free - reserve) // frame_bytes)))
     V, cls = rml.synth_volumes(B, X, Y, Z, seed=a.seed, frame0=rank * frames, device=dev)
+    if a.ingest == "u8":
+        V = V.to(torch.uint8)
+        frame_bytes = X * Y * Z
     lib = _lib.load()
     ctx = _lib.context(dev)
     from radar_ml_amd import dist as rdist
@@ -180,7 +186,7 @@ def run_workload(a, env, grid, frames, primary):
     # ---- the same frames as uint8 volumes (the radar's native magnitudes): a separate
     #      roofline row, 1 byte per voxel.  Same model, same step, labels must be identical. -----------------
     u8 = None
-    if not a.no_u8:
+    if not a.no_u8 and a.ingest != "u8":
         V8 = V.to(torch.uint8)
 
         def step8():
@@ -211,11 +217,11 @@ def run_workload(a, env, grid, frames, primary):
         if world > 1:
             dist.all_reduce(t8, op=dist.ReduceOp.MAX)
         dt8 = float(t8.item())
-        # the two ingests may run on different exact-GEMM tiles (128x128 beside the wave projection, 256x256 here): the int32 dot
-        # products are the same integers, the float64 sums over SV tiles differ in order only
+        # the two ingests may run on different exact-GEMM tiles (128x128 / 256x256): the int32 dot products are the same integers
+        # and every kernel writes one float64 partial per 128 SV rows, summed alike -- the outputs must be the same bits
         lab_same = bool(torch.equal(out8["label_calib"], out["label_calib"]) and torch.equal(out8["label_vote"], out["label_vote"]))
         dec_diff = float((out8["dec_ovo"] - out["dec_ovo"]).abs().max())
-        same = lab_same and dec_diff <= 1e-9
+        same = lab_same and bool(torch.equal(out8["dec_ovo"], out["dec_ovo"])) and bool(torch.equal(out8["proba"], out["proba"]))
         l8 = max(1, nl8.value)
         a8 = ms8.value / l8
         ach8 = (X * Y * Z + 16) * (nf8.value / l8) / (a8 * 1e-3) / 1e9 if a8 > 0 else 0.0
@@ -250,16 +256,19 @@ def run_workload(a, env, grid, frames, primary):
     rpl = 1 if 32 < zq <= 64 else (64 // zq if zq in (16, 32) and Y % (64 // zq) == 0 else 0)
     wave = os.environ.get("RML_WAVEFRAME", "1") != "0" and rpl > 0 and Y // rpl <= 32      # wave_kernel_wanted(share_cu) of csrc/project.hip
     kname = "k_project_wave" if wave else ("k_project_fast" if zq & (zq - 1) == 0 else "k_project_rowgroup")
+    if a.ingest == "u8":
+        kname = "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_frame": alg_bytes_frame}
 
     # ---- the GEMM alone (one pipeline chunk of code rows, nothing else on the GPU) ------------------------
-    #      "alone": the 128x128 kernel the pipeline runs beside the projection; "alone_large_batch": 16 384 code rows through
-    #      rml_svm_decision's own choice (the 256x256 tile), the rate a caller of decision_function on feature rows gets
+    #      "alone": the 128x128 kernel the pipeline runs beside the projection, one pipeline chunk; "alone_large_batch": the code
+    #      rows of (up to) 65 536 frames through rml_svm_decision's own chunking (k_svm_gemm_ring: 256x256 tiles, chunks sized
+    #      for whole rounds of one workgroup per CU), the rate a caller of decision_function on a large batch of rows gets
     if groof is not None:
-        for key, nb in (("alone", int(min(frames_per_launch, B))), ("alone_large_batch", int(min(16384, B)))):
+        for key, nb in (("alone", int(min(frames_per_launch, B))), ("alone_large_batch", int(min(65536, B)))):
             _, q, isum, isq, flags = rml.process_volumes(V[:nb], mode="max", scale=True, codes=True)
             if q.stride(0) % 16 == 0:
                 for _ in range(2):
@@ -273,7 +282,8 @@ def run_workload(a, env, grid, frames, primary):
                 alone_ms = e0.elapsed_time(e1) / 5
                 alone = 2.0 * D * M * nb / (alone_ms * 1e-3) / 1e12
                 groof[key] = {"frames": nb, "ms": round(alone_ms, 4), "achieved": round(alone, 1),
-                              "frac": round(alone / I8_MFMA_PEAK_TOPS, 4)}
+                              "frac": round(alone / I8_MFMA_PEAK_TOPS, 4),
+                              "kernel": "k_svm_gemm_ring<PT,0> + k_svm_finish" if key == "alone_large_batch" else "k_svm_gemm<I8> + k_svm_finish"}
             del q, isum, isq, flags
 
     # ---- configs[1]: the projection kernel alone (HBM-roofline check; float32 feature rows written) ------------
@@ -301,7 +311,7 @@ def run_workload(a, env, grid, frames, primary):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as OC
     npar = min(a.parity if primary else min(a.parity, 1024), B)
-    vh = V[:npar].cpu().numpy()
+    vh = V[:npar].cpu().numpy().astype(np.float32)
     threads = len(os.sched_getaffinity(0))
     xz, yz, xy = OC.project_max(vh, threads=threads)
     fh = OC.features(xz, yz, xy, scale=True)
@@ -345,9 +355,12 @@ def run_workload(a, env, grid, frames, primary):
                        "sample": "%d of the same frames, oracle/oracle.c (max-projection + float64 libsvm loops, OpenMP over frames), "
                                  "%.1f s" % (ncpu, cdt)}
 
+    import zlib
+    all_lab = out["all_labels"] if world > 1 else out["label_calib"]
+    labels_crc = int(zlib.crc32(all_lab.cpu().numpy().astype(np.int32).tobytes()))      # of every frame's label, in global frame order
     value = world * B * a.steps / dt
     res = {
-        "value": round(value, 1), "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "value": round(value, 1), "ms_per_step": round(dt / a.steps * 1e3, 3), "labels_crc32": labels_crc,
         "config": {"workload": "configs[2]: max-projection + RBF-SVM decision_function, 3-class, %d SVs, "
                                "batch %d frames/GPU of %dx%dx%d f32 resident in HBM" % (M, B, X, Y, Z),
                    "grid": [X, Y, Z], "frames_per_gpu": B, "global_frames": world * B, "n_sv": M, "D": D,
@@ -363,11 +376,41 @@ def run_workload(a, env, grid, frames, primary):
     return res
 
 
+def irregular_rows(rml, torch, feat, grid, seed):
+    """Feature rows off the code grid the way the reference makes them (train.py:84-185, driven at train.py:496-517): every
+    projection of a sample rotated by U(-15, 15) degrees (first third of the rows), zoomed by one U(0.7, 1.3) factor per sample
+    (second third) or hit by sparse Gaussian noise of sd 0.2 (last third) -- order-3 spline resampling and the [0, 1] clamp
+    through rml_augment on the device.  feat: (N, D) float32 CUDA rows in [0, 1] (scaled max-projections)."""
+    X, Y, Z = grid
+    N = feat.shape[0]
+    rng = np.random.default_rng(seed)
+    shapes = ((X, Z), (Y, Z), (X, Y))
+    offs = np.cumsum([0] + [h * w for h, w in shapes])
+    third = (N // 3, 2 * (N // 3))
+    out = torch.empty_like(feat)
+    zf = rng.uniform(0.7, 1.3, N)
+    for pi, (h, w) in enumerate(shapes):
+        planes = feat[:, offs[pi]:offs[pi + 1]].reshape(N, h, w).contiguous()
+        dst = out[:, offs[pi]:offs[pi + 1]]
+        ang = rng.uniform(-15.0, 15.0, third[0])
+        par = np.stack([rml.rotation_params(v, (h, w)) for v in ang]) if third[0] else np.zeros((0, 6))
+        if third[0]:
+            dst[:third[0]] = rml.augment_planes(planes[:third[0]], "rotate", par).reshape(third[0], -1)
+        if third[1] > third[0]:
+            dst[third[0]:third[1]] = rml.augment_planes(planes[third[0]:third[1]], "zoom", zf[third[0]:third[1]]).reshape(third[1] - third[0], -1)
+        if N > third[1]:
+            dst[third[1]:] = rml.augment_planes(planes[third[1]:], "noise", rng.normal(0.0, 0.2, N - third[1])).reshape(N - third[1], -1)
+    return out
+
+
 def run_general(a, env, grid, frames):
-    """The same step on data that is NOT on the integer code grid (what train.py:496-517 augmentation and a non-unit
-    proj_zoom, predict.py:109-116, produce, and what the reference's shipped generated_data pickles hold): volumes and
-    support vectors scaled off the grid, so RML_PATH_AUTO takes the float64-MFMA GEMM (v_mfma_f64_16x16x4_f64) on float32
-    rows.  MFMA-bound: 2*D*M flop per frame against the 78.6 TFLOP/s f64 matrix peak.  Parity vs the float64 C oracle."""
+    """Rows that are NOT on the integer code grid -- what train.py:496-517 augmentation, a non-unit proj_zoom
+    (predict.py:109-116) and the reference's shipped generated_data pickles hold: the projections of the synthetic frames are
+    rotated / zoomed / noised by rml_augment (spline resampling: arbitrary float32 values), the support vectors likewise, and
+    the step is clf.predict_proba on those rows (rml_svm_decision).  RML_PATH_AUTO takes the multi-digit int8 kernel
+    (k_svm_gemm_ring<PT, 1>: four balanced int8 digits per value, ten exact digit-plane products); the float64-MFMA kernel
+    (v_mfma_f64_16x16x4_f64) is timed beside it.  Also the fused front door on off-grid VOLUMES (projection -> float rows ->
+    digit planes -> GEMM).  Parity vs the float64 C oracle on the very rows."""
     import torch
     import torch.distributed as dist
     rml, _lib, dev, rank, world = env["rml"], env["lib_mod"], env["dev"], env["rank"], env["world"]
@@ -379,74 +422,101 @@ def run_general(a, env, grid, frames):
     if world > 1:
         dist.broadcast_object_list(obj, src=0)
     model = obj[0]
-    off = np.float64(0.9990234375)                                  # 1 - 2^-10: every non-zero value leaves the code grid
-    sv = sv_f64(model) * off
+    sv_rows = torch.from_numpy(sv_f64(model).astype(np.float32)).to(dev)
+    sv = irregular_rows(rml, torch, sv_rows, grid, a.seed + 11).cpu().numpy().astype(np.float64)
+    del sv_rows
     svc = rml.GpuSVC(sv, model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], model["classes"],
                      calib_a=model["calib_a"], calib_b=model["calib_b"])
     assert not svc.exact
     M = int(sv.shape[0])
     B = int(frames)
     V, _ = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 3, frame0=rank * B, device=dev)
-    V.mul_(float(off))
+    rows = irregular_rows(rml, torch, rml.process_volumes(V, mode="max", scale=True), grid, a.seed + 12 + rank)
+    off_grid = float((torch.round(rows[:256] * 255.0) / 255.0 != rows[:256]).float().mean())
     lib = _lib.load()
     ctx = _lib.context(dev)
     from radar_ml_amd import dist as rdist
 
-    def step():
-        o = svc.decide_volumes(V, mode="max", scale=True, want_proba=True)
+    def timed(fn, steps):
+        for _ in range(max(1, a.warmup)):
+            o = fn()
+        torch.cuda.synchronize(dev)
         if world > 1:
-            o["all_labels"] = rdist.gather_labels(o["label_calib"])
-        return o
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return o, float(tm.item())
 
-    for _ in range(max(1, a.warmup)):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    lib.rml_profile_enable(ctx, 1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    nl, ms, ops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    lib.rml_profile_read_gemm(ctx, ctypes.byref(nl), ctypes.byref(ms), ctypes.byref(ops))
-    lib.rml_profile_enable(ctx, 0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def step_rows(path):
+        def f():
+            ovo, ovr, vote, proba, lab = svc._decide(rows, want_proba=True, path=path)
+            if world > 1:
+                rdist.gather_labels(lab)
+            return {"dec_ovo": ovo, "label_vote": vote, "proba": proba, "label_calib": lab}
+        return f
+
+    out, dt = timed(step_rows("auto"), a.steps)
+    out64, dt64 = timed(step_rows("f64"), max(1, a.steps // 4))
+    # the fused front door on volumes whose values left the grid (uniform 1 - 2^-10 scale + noise on the returns)
+    V.mul_(0.9990234375)
+    V.add_(torch.randn_like(V) * 0.05 * (V > 0))
+    outv, dtv = timed(lambda: svc.decide_volumes(V, mode="max", scale=True, want_proba=True), max(1, a.steps // 2))
     if rank != 0:
         return None
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as OC
     npar = min(1024, B)
-    vh = V[:npar].cpu().numpy()
     threads = len(os.sched_getaffinity(0))
-    xz, yz, xy = OC.project_max(vh, threads=threads)
-    fh = OC.features(xz, yz, xy, scale=True)
+    # rows from all three kinds (rotated / zoomed / noised)
+    pick = np.concatenate([np.arange(0, npar // 3), B // 3 + np.arange(0, npar // 3), B - (npar - 2 * (npar // 3)) + np.arange(0, npar - 2 * (npar // 3))])
+    fh = rows[torch.as_tensor(pick, device=dev)].cpu().numpy()
     ref = OC.svm(fh, sv, model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
                  model["calib_a"], model["calib_b"], threads=threads)
-    F64_PEAK = 78.6                                                 # MI355X f64 matrix peak, TFLOP/s
-    ach = ops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    vh = V[:256].cpu().numpy()
+    xz, yz, xy = OC.project_max(vh, threads=threads)
+    refv = OC.svm(OC.features(xz, yz, xy, scale=True), sv, model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
+                  model["calib_a"], model["calib_b"], threads=threads)
+
+    def par(o, r, idx):
+        g = {k: o[k][torch.as_tensor(idx, device=dev)].cpu().numpy() for k in ("dec_ovo", "label_vote", "proba", "label_calib")}
+        return {"frames": int(len(idx)), "label_vote_mismatch": int((g["label_vote"] != r["label_vote"]).sum()),
+                "label_calib_mismatch": int((g["label_calib"] != r["label_calib"]).sum()),
+                "dec_ovo_max_abs_err": float(np.abs(g["dec_ovo"] - r["dec_ovo"]).max()),
+                "proba_max_abs_err": float(np.abs(g["proba"] - r["proba"]).max())}
+
+    ops = 2.0 * D * M
     value = world * B * a.steps / dt
+    v64 = world * B * max(1, a.steps // 4) / dt64
+    vv = world * B * max(1, a.steps // 2) / dtv
     return {
-        "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 3), "dtype": "f32 rows, f64 MFMA + f64 epilogue",
-        "workload": "%d frames/GPU of %dx%dx%d f32, every value scaled by 1 - 2^-10 (off the integer grid), %d SVs off the grid "
-                    "as well: RML_PATH_AUTO -> float64 MFMA" % (B, X, Y, Z, M),
-        "roofline": {"bound": "mfma", "kernel": "k_svm_gemm<F64> + k_svm_finish", "achieved": round(ach, 2), "peak": F64_PEAK,
-                     "unit": "TFLOP/s", "frac": round(ach / F64_PEAK, 4), "launches": int(nl.value),
-                     "note": "in situ: 2*D*M flop per frame over the summed GEMM+finish time of every chunk"},
-        "mfma_frac_end_to_end": round(value / world * 2.0 * D * M / 1e12 / F64_PEAK, 4),
-        "parity": {"frames": int(npar),
-                   "label_vote_mismatch": int((out["label_vote"][:npar].cpu().numpy() != ref["label_vote"]).sum()),
-                   "label_calib_mismatch": int((out["label_calib"][:npar].cpu().numpy() != ref["label_calib"]).sum()),
-                   "dec_ovo_max_abs_err": float(np.abs(out["dec_ovo"][:npar].cpu().numpy() - ref["dec_ovo"]).max()),
-                   "proba_max_abs_err": float(np.abs(out["proba"][:npar].cpu().numpy() - ref["proba"]).max())},
+        "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "dtype": "f32 rows -> 4 balanced int8 digits of a 32-bit fixed-point value, i8 MFMA exact int32, f64 epilogue",
+        "workload": "%d rows/GPU of D = %d (max-projections of %dx%dx%d frames, every projection rotated / spline-zoomed / noised by "
+                    "rml_augment: %.0f %% of the values off the code grid), %d SVs augmented the same way; clf.predict_proba on the rows: "
+                    "RML_PATH_AUTO -> multi-digit int8 kernel" % (B, D, X, Y, Z, 100.0 * off_grid, M),
+        "roofline": {"bound": "mfma", "kernel": "k_svm_gemm_ring<PT,1> (+ k_prepare_rows, k_digit_rows, k_svm_finish)",
+                     "achieved": round(value / world * 10.0 * ops / 1e12, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                     "frac": round(value / world * 10.0 * ops / 1e12 / I8_MFMA_PEAK_TOPS, 4),
+                     "note": "ten digit-plane products of 2*D*M int8 ops per row, row preparation inside the timed step"},
+        "parity": par(out, ref, pick),
+        "float64_mfma_path": {"value": round(v64, 1), "unit": "frames/s", "kernel": "k_svm_gemm<F64> (v_mfma_f64_16x16x4_f64)",
+                              "achieved_TFLOPs": round(v64 / world * ops / 1e12, 2), "frac_of_78.6": round(v64 / world * ops / 1e12 / 78.6, 4),
+                              "parity": par(out64, ref, pick),
+                              "max_abs_dec_diff_vs_digits": float((out64["dec_ovo"] - out["dec_ovo"]).abs().max())},
+        "speedup_vs_float64_mfma": round(value / v64, 2),
+        "from_volumes": {"value": round(vv, 1), "unit": "frames/s",
+                         "workload": "the fused front door on the %d volumes scaled by 1 - 2^-10 with N(0, 0.05) noise on the returns "
+                                     "(projection -> float rows -> digit planes -> GEMM)" % B,
+                         "parity": par(outv, refv, np.arange(256))},
     }
 
 
@@ -541,7 +611,8 @@ def run_dnn(a, env):
 
 
 def run_sgan(a, env, n=256, hw=128, steps=None):
-    """BASELINE configs[4]: the SGAN discriminator/classifier train step (c_model + d_model(real) updates, sgan.py:525-532) on
+    """BASELINE configs[4]: the SGAN discriminator/classifier train step (c_model + d_model(real, class-weighted) + d_model(fake)
+    updates, sgan.py:525-532) on
     128x128 projections, fp16 autocast with loss scaling, MIOpen convolutions for layers 2-3 + csrc/bnact.hip for the rest.
     Data parallel when N > 1: every rank trains on its own batch of ``n`` samples (weak scaling) and the gradients are
     all-reduced once per update on one flat 7.4 MB bucket (RCCL over xGMI) between the HIP-graph replay of forward + backward
@@ -559,10 +630,17 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
     g = torch.Generator(device=dev).manual_seed(a.seed + 17 * rank)             # every rank its own shard of the global batch
     x = [torch.rand((n, hw, hw), device=dev, generator=g) * 2 - 1 for _ in range(3)]
     y = torch.randint(0, 3, (n,), device=dev, generator=g)
-    yr = torch.full((n, 1), 0.9, device=dev)
+    # the d updates of sgan.py:529-532: real batch with smoothed positive labels in [0.7, 1.2) (sgan.py:396-398) and the data
+    # set's class weights (class_weight -> per-sample weights the way Keras does it), fake batch (here: another batch of
+    # projections -- the generator is out of scope) with smoothed negative labels in [0, 0.3) (sgan.py:401-403)
+    yr = 0.7 + 0.5 * torch.rand((n, 1), device=dev, generator=g)
+    sw = torch.from_numpy(sgan.class_weight_to_sample_weight(yr.cpu().numpy(), {0: 1.0, 1: 1.37, 2: 2.05})).to(dev)
+    xf = [torch.rand((n, hw, hw), device=dev, generator=g) * 2 - 1 for _ in range(3)]
+    yf = 0.3 * torch.rand((n, 1), device=dev, generator=g)
     for _ in range(6 if on_gpu else 1):
         tr.train_on_batch_c(x, y)
-        tr.train_on_batch_d(x, yr)
+        tr.train_on_batch_d(x, yr, sample_weight=sw)
+        tr.train_on_batch_d(xf, yf)
 
     def fence():
         if on_gpu:
@@ -577,7 +655,8 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         lc, acc = tr.train_on_batch_c(x, y, sync=False)
-        ld = tr.train_on_batch_d(x, yr, sync=False)
+        ld = tr.train_on_batch_d(x, yr, sample_weight=sw, sync=False)
+        lf = tr.train_on_batch_d(xf, yf, sync=False)
     fence()
     dt = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev)
     if world > 1:
@@ -592,14 +671,15 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
         same = all(bool(torch.equal(b, both[0])) for b in both)
     if rank != 0:
         return None
-    return {"metric": "sgan discriminator train step (c + d_real updates)", "value": round(world * 2 * n / dt, 1), "unit": "samples/s",
+    return {"metric": "sgan discriminator train step (c + d_real[class_weight] + d_fake updates, sgan.py:525-532)",
+            "value": round(world * 3 * n / dt, 1), "unit": "samples/s", "updates_per_step": 3,
             "ms_per_step": round(dt * 1e3, 2), "batch_per_gpu": n, "global_batch": world * n, "n_gpus": world,
             "parallelism": "data parallel x%d: one flat-bucket gradient all-reduce (%d parameters) per update"
                            % (world, sum(p.numel() for p in d.parameters())) if world > 1 else "single GPU",
             "replicas_identical": same, "hip_graph": bool(tr.use_graph),
             "dtype": "fp16 autocast (MIOpen convolutions, csrc/bnact.hip batch-norm/activation/pad), fp32 master weights"
                      if on_gpu else "float32 (CPU)",
-            "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4)}
+            "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4), "d_fake_loss": round(float(lf), 4)}
 
 
 def main():
@@ -668,6 +748,12 @@ def main():
                     r["uint8_ingest"]["roofline"]["traffic"] = t["hbm_bytes"]
                     r["uint8_ingest"]["roofline"]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "kernel", "source")}
 
+    if rank == 0 and world > 1:
+        for r in (res, wal):
+            if r is not None:
+                r["roofline"]["traffic_note"] = "not measured at N > 1: the PMC passes run a single-process child; see the N = 1 line"
+                r["cpu_baseline_note"] = "timed at N = 1 only"
+
     gen_row = None
     if not a.no_general:
         gen_row = {}
@@ -719,7 +805,7 @@ def main():
             "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
             "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"], "cpu_baseline": res["cpu_baseline"],
             "parity": res["parity"], "projection_only_configs1": res["projection_only"],
-            "uint8_ingest": res["uint8_ingest"], "model": res["model"],
+            "uint8_ingest": res["uint8_ingest"], "model": res["model"], "labels_crc32": res["labels_crc32"],
         }
         if wal is not None:
             line["walabot_grid"] = wal

@@ -53,7 +53,11 @@ typedef struct rml_svm rml_svm;
 typedef struct rml_linear rml_linear;
 
 /* projection modes */
-#define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V        */
+#define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V.
+                              NaN policy (a pinned deviation from SURVEY 8 a-1', which defines it "as NumPy"): np.max propagates a
+                              NaN, this mode IGNORES it (IEEE maxNum: v_max_f32 / ds_max_f32), i.e. it equals np.fmax.reduce, and a
+                              line of nothing but NaN gives -inf.  Radar magnitudes are integers 0..255 (common.py:30-31): the
+                              reference path never meets one; tests/test_projection_gpu.py pins the behaviour of every kernel */
 #define RML_MODE_SLICE 1   /* reference-faithful plane slices through (i,j,k): predict.py:102-107       */
 #define RML_MODE_SUM   2   /* sum-projection (the reductions of common.py:51-53), float32 accumulation  */
 

@@ -39,6 +39,7 @@ struct ProjParams {
     int X, Y, Z, ZQ;
     const int32_t* ijk;
     int tpf;            // mode SLICE: targets (output rows) per frame; output row b reads frame b / tpf
+    int rpl;            // k_project_wave: real rows per 64-quad virtual row, decided by the launcher (wave_kernel_rpl)
     ProjOut o;
     int vec_ok[3];   // float4 stores allowed for plane pl (16-B aligned base and stride)
 };
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
     // piece and yz keeps its layout (row j' of the view = rows RPL*j' .. of yz).  Only the epilogues know about it: xz folds
     // the RPL lane groups of a virtual row, and xy lane j reads the lane group of its real row.
     const int X = a.X, Yr = a.Y, Zr = a.Z, ZQr = a.ZQ;
-    const int RPL = (ZQr <= 32 && 64 / ZQr >= 2 && Yr % (64 / ZQr) == 0) ? 64 / ZQr : 1;
+    const int RPL = a.rpl;                              // the launcher's decision: kernel and launcher cannot disagree
     const int Y = Yr / RPL, Z = Zr * RPL, ZQ = ZQr * RPL;           // the view the streaming loop works on
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -687,15 +688,22 @@ bool wave_kernel_wanted(int ZQ, int Y, bool share_cu, int64_t B, int num_cu) {
 
 // returns true when the wave-per-frame kernel took the launch
 template <typename VT, int MODE>
-bool try_launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
-    if (!wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0, pp.B, num_cu)) return false;
+bool try_launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
+    if (!wave_kernel_wanted(pp_in.ZQ, pp_in.Y, pp_in.o.share_cu != 0, pp_in.B, num_cu)) return false;
+    ProjParams pp = pp_in;
+    pp.rpl = wave_kernel_rpl(pp.ZQ, pp.Y);
     const char* env = getenv("RML_WAVEFRAME");
     const int knob = env ? atoi(env) : 1;
     const int Y = pp.Y / wave_kernel_rpl(pp.ZQ, pp.Y);  // rows of the view
-    // whole-plane buffers need an even number of planes; beside a GEMM the quarter-plane variant (206 VGPRs) leaves it room
+    // whole-plane buffers need an even number of planes; beside a GEMM the quarter-plane variant (206 VGPRs) leaves it room.
+    // RML_WAVE_G (experiment knob, read per call): 2 = half-plane buffers beside a GEMM (~300 VGPRs: one projection wave and one
+    // 128-VGPR GEMM wave still share a SIMD's 512 registers; twice the bytes in flight per wave of the quarter-plane variant)
     const bool quarter = knob == 2 || (pp.X & 1) || pp.o.share_cu;
+    const char* ge = getenv("RML_WAVE_G");
+    const bool half = quarter && ge && atoi(ge) == 2;
 #define RML_WAVE_CASE(NYV)                                                                     \
-    { if (quarter) launch_wave<VT, MODE, NYV, (NYV + 3) / 4>(pp, num_cu, st);                 \
+    { if (half) launch_wave<VT, MODE, NYV, (NYV + 1) / 2>(pp, num_cu, st);                    \
+      else if (quarter) launch_wave<VT, MODE, NYV, (NYV + 3) / 4>(pp, num_cu, st);            \
       else launch_wave<VT, MODE, NYV, NYV>(pp, num_cu, st); return true; }
     if (Y <= 8) RML_WAVE_CASE(8)
     if (Y <= 16) RML_WAVE_CASE(16)
@@ -1101,7 +1109,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
 }
 
 void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
-    pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.o = o;
+    pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.rpl = 1; pp.o = o;
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
 }

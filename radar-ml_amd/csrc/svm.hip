@@ -1176,15 +1176,18 @@ inline bool use_dig_gemm(const rml_svm* m, int policy, int64_t n, int num_cu) {
     return wgs * 2 >= (int64_t)num_cu;
 }
 
-// does the 256x256 kernel take the exact tiles of a chunk of n rows against this model?  (enough tiles for ~2.5 rounds of
-// one workgroup per CU; RML_GEMM_BIG=0 turns it off, =1 forces it for every n >= 256)
+// does the 256x256 ring kernel take the exact tiles of a chunk of n rows against this model?  It runs at up to 0.6 of the int8
+// peak when its tiles fill whole rounds of one workgroup per CU and proportionally less otherwise; the 128x128 kernel (two
+// workgroups per CU, four times as many tiles) sits at 0.40-0.46 whatever the batch.  So: at least three quarters of a round,
+// and the last round at least three quarters full.  RML_GEMM_BIG=0 turns it off, =1 forces it for every n >= 256.
 inline bool use_big_gemm(const rml_svm* m, int64_t n, int num_cu) {
     const char* env = getenv("RML_GEMM_BIG");          // read per call: tests flip it
     const int knob = env ? atoi(env) : -1;
     if (knob == 0 || m->PT > 6) return false;
     if (knob == 1) return n >= 256;
     const int64_t wgs = ((n + kBig - 1) / kBig) * ((m->Mpad + kBig - 1) / kBig);
-    return wgs * 2 >= (int64_t)num_cu * 5;
+    const int64_t rounds = (wgs + num_cu - 1) / num_cu;
+    return wgs * 4 >= (int64_t)num_cu * 3 && wgs * 4 >= rounds * num_cu * 3;
 }
 
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
@@ -1464,9 +1467,10 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
-// Rows per chunk of the chunked front doors.  With an exact model the chunk is sized for the 256x256 kernel: among
-// 8192..32768 rows the size whose tile count fills whole rounds of one workgroup per CU best (>= 2.5 rounds); otherwise
-// `fallback` (the round-1 choice for the 128x128 kernel).  RML_CHUNK overrides.
+// Rows per chunk of the chunked front doors.  Where the 256x256 ring kernel runs (an exact model, or the multi-digit path) a
+// chunk costs ceil(tiles / CUs) rounds of one workgroup per CU, so the chunk size is chosen for the WHOLE batch: among the
+// multiples of 256 rows in 4096..32768 the one with the fewest rounds in total (full chunks + the remainder) plus a small charge
+// per chunk, the larger chunk on a tie.  Otherwise `fallback`.  RML_CHUNK overrides.
 int64_t pick_chunk_env(int64_t fallback) {
     const char* e = getenv("RML_CHUNK");
     const int64_t v = e ? atoll(e) : 0;
@@ -1479,12 +1483,16 @@ int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu,
     if (env) ch = env;
     else if (dig || (m->exact && use_big_gemm(m, 32768, num_cu))) {
         const int64_t st2 = (m->Mpad + kBig - 1) / kBig;
-        double best = 0.0;
-        for (int64_t c = 8192; c <= 32768; c += 2048) {
-            const int64_t wgs = (c / kBig) * st2, rounds = (wgs + num_cu - 1) / num_cu;
-            if (wgs * 2 < (int64_t)num_cu * 5) continue;
-            const double eff = (double)wgs / (double)(rounds * num_cu);
-            if (eff > best + 0.02) { best = eff; ch = c; }       // a larger chunk has to earn its longer pipeline fill
+        auto rounds = [&](int64_t n) { return n <= 0 ? (int64_t)0 : (((n + kBig - 1) / kBig) * st2 + num_cu - 1) / num_cu; };
+        // cost in units of a twentieth of a round: a chunk also costs its launches and a fill / drain in which the CUs run in
+        // lockstep (measured: 1.97 rounds per launch 0.47-0.51 of peak, 2.99 rounds 0.54-0.58) -- three twentieths per chunk
+        const int64_t total = round_up(rows, kBig);
+        int64_t best = -1;
+        for (int64_t c = 4096; c <= 32768; c += kBig) {
+            const int64_t nfull = total / c, rem = total % c;
+            const int64_t cost = 20 * (nfull * rounds(c) + rounds(rem)) + 3 * (nfull + (rem ? 1 : 0));
+            if (best < 0 || cost <= best) { best = cost; ch = c; }
+            if (c >= total) break;
         }
     }
     return std::min<int64_t>(round_up(rows, kTile), ch);
@@ -1784,7 +1792,7 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     // float rows of a model that is not on the code grid: the multi-digit kernel when the batch fills enough 256 x 256 tiles
     // (chunks sized for whole rounds of one workgroup per CU, like the exact 256 x 256 kernel's)
     const bool dig = feat != nullptr && !m->exact && use_dig_gemm(m, path, N, ctx->num_cu);
-    const int64_t CH = feat ? (dig ? pick_chunk(m, N, 8192, ctx->num_cu, true) : std::min<int64_t>(round_up(N, kTile), 8192))
+    const int64_t CH = feat ? ((dig || m->exact) ? pick_chunk(m, N, 8192, ctx->num_cu, dig) : std::min<int64_t>(round_up(N, kTile), 8192))
                             : pick_chunk(m, N, 8192, ctx->num_cu);
     const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
@@ -1881,7 +1889,9 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // Byte volumes (k_project_u8_max, two workgroups per CU) take the 128x128 GEMM and the small chunks as well: its
     // workgroups fit beside the projection's, the 256x256 kernel's time-slice the CUs with them and three chunks per 65 536
     // frames leave the pipeline mostly filling and draining (64x64x128 uint8, same box: 6.0 -> 6.7-7.1 M frames/s).
-    const bool small_gemm = wave_proj || vdtype == RML_VOL_U8;
+    // RML_PIPE_GEMM (experiment knob): 1 = the 256x256 ring kernel in whole-round chunks for the byte volumes as well
+    const char* pge = getenv("RML_PIPE_GEMM");
+    const bool small_gemm = wave_proj || (vdtype == RML_VOL_U8 && !(pge && atoi(pge) == 1));
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;

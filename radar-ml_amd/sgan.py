@@ -363,7 +363,8 @@ class DiscriminatorTrainer:
                 raise ValueError("give class_weight or sample_weight, not both")
             sample_weight = class_weight_to_sample_weight(y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else y, class_weight)
         yt = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y).to(self.device).float()
-        sw = None if sample_weight is None else torch.as_tensor(np.asarray(sample_weight)).to(self.device)
+        sw = None if sample_weight is None else (sample_weight if isinstance(sample_weight, torch.Tensor)
+                                                 else torch.as_tensor(np.asarray(sample_weight))).to(self.device)
         if self.use_graph:
             tg = (yt,) if sw is None else (yt, sw.float())
             loss, _ = self._graph_step("d" if sw is None else "dw", self.opt_d,

@@ -1,0 +1,64 @@
+"""The N > 1 control flow of bench.py on a real GPU: two ranks on ONE device (RML_BENCH_ONE_DEVICE=1, gloo staging the
+collectives through the host -- RCCL refuses two ranks per device), against the single-process run of the same global batch.
+Frames shard by global frame index, so the gathered labels of the 2-rank job must be the single-process labels; the SGAN
+replicas must stay identical through the flat-bucket all-reduce with HIP-graph replay.  This is the multi-GPU evidence a
+1-GPU box can give; the RCCL run itself is the driver's SCALE bench."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _line(out):
+    for ln in reversed(out.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise AssertionError("no JSON line in:\n" + out[-2000:])
+
+
+def test_two_rank_bench_on_one_device_matches_the_single_process_run():
+    per_rank = 1024
+    common = ["--steps", "2", "--warmup", "1", "--train", "1500", "--no-cpu", "--no-pmc", "--no-u8", "--parity", "256",
+              "--general-frames", "512", "--dnn-frames", "512", "--dnn-parity", "64"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RML_BENCH_ONE_DEVICE", None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", str(2 * per_rank),
+                          "--walabot-frames", str(2 * per_rank)] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=1500)
+    assert one.returncode == 0, one.stderr.decode()[-3000:]
+    l1 = _line(one.stdout.decode())
+    env2 = dict(env, RML_BENCH_ONE_DEVICE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", str(per_rank),
+                          "--walabot-frames", str(per_rank)] + common, cwd=ROOT, env=env2, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=1500)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    l2 = _line(two.stdout.decode())
+    assert l2["n_gpus"] == 2 and l2["config"]["global_frames"] == 2 * per_rank == l1["config"]["global_frames"]
+    # every rank classified its slab of the same global batch: gathered labels == single-process labels, both grids
+    assert l2["labels_crc32"] == l1["labels_crc32"]
+    assert l2["walabot_grid"]["labels_crc32"] == l1["walabot_grid"]["labels_crc32"]
+    for ln in (l1, l2):
+        assert ln["parity"]["label_calib_mismatch"] == 0 and ln["parity"]["label_vote_mismatch"] == 0
+        assert ln["parity"]["dec_ovo_max_abs_err"] <= 1e-5
+        assert ln["general_rows"]["parity"]["label_calib_mismatch"] == 0 and ln["general_rows"]["parity"]["dec_ovo_max_abs_err"] <= 1e-5
+    sg = l2["sgan_train_step"]
+    assert "error" not in sg, sg
+    assert sg["replicas_identical"] is True and sg["hip_graph"] is True and sg["n_gpus"] == 2
+    assert l2["roofline"].get("traffic") is None and "traffic_note" in l2["roofline"]
+    assert l2["dnn_forward"]["parity"]["label_mismatch"] <= 2

@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ------------------------------------------------------------------------------------------------------------------
 # reference-library CPU baseline
 # ------------------------------------------------------------------------------------------------------------------
-def build_sklearn_rbf_model(model, D):
+def build_sklearn_rbf_model(model, D, sv_f64=None):
     """The object the reference pickles -- CalibratedClassifierCV(prefit, sigmoid) around SVC(kernel='rbf') -- carrying the
     bench model's arrays.  (bench.py fits with kernel='precomputed' on the GPU Gram matrix; libsvm's predict needs an RBF
     estimator, so a tiny RBF SVC is fitted for its private state and the fitted arrays are then replaced.)"""
@@ -41,14 +41,15 @@ def build_sklearn_rbf_model(model, D):
     from sklearn.calibration import CalibratedClassifierCV
     classes = np.asarray(model["classes"])
     C = len(classes)
-    sv = (model["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)     # train.py:667
+    # train.py:667 scaling; ``sv_f64``: the same matrix already made (the pool's workers share one memory-mapped copy)
+    sv = sv_f64 if sv_f64 is not None else (model["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
     M = sv.shape[0]
     rng = np.random.default_rng(0)
     Xd = rng.random((4 * C, D))
     yd = np.repeat(classes, 4)
     svc = svm.SVC(kernel="rbf", C=10.0, gamma=float(model["gamma"]), class_weight="balanced")
     svc.fit(Xd, yd)
-    svc.support_vectors_ = np.ascontiguousarray(sv)
+    svc.support_vectors_ = sv if (isinstance(sv, np.ndarray) and sv.flags["C_CONTIGUOUS"] and sv.dtype == np.float64) else np.ascontiguousarray(sv, dtype=np.float64)
     svc.support_ = np.arange(M, dtype=np.int32)
     svc._n_support = np.asarray(model["n_support"], dtype=np.int32)
     svc._dual_coef_ = np.ascontiguousarray(model["dual_coef"], dtype=np.float64)
@@ -140,19 +141,20 @@ def reference_libs_baseline(vh, model, gpu_label_idx, threads, budget_s=25.0, wa
     if pool is not None and pool["value"] > 0:
         return {"value": pool["value"], "unit": "frames/s", "cores": pool["cores"], "kind": "reference-libs",
                 "sample": "%d of the same synthetic frames on %d worker processes (one per core) in %.1f s: %s" % (pool["frames"], pool["cores"], pool["seconds"], what),
-                "label_mismatch_vs_gpu": pool["label_mismatch_vs_gpu"], "workers_late_at_start": pool["workers_late_at_start"],
+                "label_mismatch_vs_gpu": pool["label_mismatch_vs_gpu"], "start_skew_s": pool["start_skew_s"],
                 "single_process": single, "thread_pool": thread_pool}
     return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "reference-libs",
             "sample": "%d of the same synthetic frames on %d threads in %.1f s (the process pool could not be run): %s" % (done, threads, dt2, what),
             "label_mismatch_vs_gpu": mism2, "single_process": single, "thread_pool": thread_pool}
 
 
-def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0, startup_s=20.0):
+def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0, ready_timeout_s=90.0):
     """All host cores the honest way: one PROCESS per core (NumPy ``max`` and ``ndimage.zoom`` hold the GIL, so a thread pool
     measures the interpreter lock, not the machine), each running the reference path on its own slice of the frames.
-    Frames and model sit once in /dev/shm (memory-mapped by the workers); the workers import their libraries and build the
-    scikit-learn object first, then start together at an agreed wall-clock time, and the rate is (frames done by all) /
-    (latest end - common start).  Returns the object or None when the pool could not be run."""
+    Frames and the float64 SV matrix sit once in /dev/shm (memory-mapped by the workers: one copy for all of them); the workers
+    import their libraries and build the scikit-learn object first, report ready, and start together when the parent says
+    go; the rate is (frames done by all) / (latest end - earliest start).  Returns the object or None when the pool could
+    not be run."""
     import tempfile
     classes = np.asarray(model["classes"])
     n = int(len(vh))
@@ -161,25 +163,32 @@ def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0
     procs = []
     try:
         np.save(os.path.join(d, "frames.npy"), np.ascontiguousarray(vh))
-        for k in ("sv_u8", "dual_coef", "intercept", "n_support", "calib_a", "calib_b", "classes"):
+        np.save(os.path.join(d, "sv_f64.npy"), (np.asarray(model["sv_u8"]).astype(np.float32) / np.float32(255.0)).astype(np.float64))
+        for k in ("dual_coef", "intercept", "n_support", "calib_a", "calib_b", "classes"):
             np.save(os.path.join(d, k + ".npy"), np.ascontiguousarray(model[k]))
         np.save(os.path.join(d, "gamma.npy"), np.float64(model["gamma"]))
         per = (n + workers - 1) // workers
-        t_go = time.time() + startup_s
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         for w in range(workers):
             lo, hi = w * per, min(n, (w + 1) * per)
             if lo >= hi:
                 break
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_worker.py"), d, str(lo), str(hi), str(budget_s), repr(t_go)],
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_worker.py"), d, str(w), str(lo), str(hi), str(budget_s)],
                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd="/tmp"))
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(d, "ready_%d" % w)) for w in range(len(procs))) < len(procs):
+            if time.time() - t_wait > ready_timeout_s or any(p.poll() not in (None, 0) for p in procs):
+                return None
+            time.sleep(0.05)
+        with open(os.path.join(d, "go.tmp"), "w") as f:
+            f.write(repr(time.time() + 0.5))
+        os.replace(os.path.join(d, "go.tmp"), os.path.join(d, "go"))
         outs = []
-        deadline = t_go + budget_s + 60.0
+        deadline = time.time() + budget_s + 60.0
         for p in procs:
             try:
                 o, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
             except subprocess.TimeoutExpired:
-                p.kill()
                 return None
             if p.returncode != 0:
                 return None
@@ -191,7 +200,6 @@ def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0
             if p.poll() is None:
                 p.kill()
         shutil.rmtree(d, ignore_errors=True)
-    late = sum(1 for o in outs if o["t0"] - t_go > 0.5)      # workers that were not ready at the common start
     done = sum(o["done"] for o in outs)
     span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
     mism = 0
@@ -199,7 +207,8 @@ def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0
         lab = np.asarray(o["labels"], dtype=np.int64)
         mism += int((lab != classes[gpu_label_idx[o["lo"]:o["lo"] + len(lab)]]).sum())
     return {"value": round(done / span, 2) if span > 0 else 0.0, "unit": "frames/s", "cores": len(outs), "frames": int(done),
-            "seconds": round(span, 2), "workers_late_at_start": late, "label_mismatch_vs_gpu": mism}
+            "seconds": round(span, 2), "start_skew_s": round(max(o["t0"] for o in outs) - min(o["t0"] for o in outs), 3),
+            "label_mismatch_vs_gpu": mism}
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
-    d, lo, hi, budget, t_go = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5])
+    d, wid, lo, hi, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=1)
@@ -27,14 +27,19 @@ def main():
     import oracle_np as O
     import bench_support as BS
     vh = np.load(os.path.join(d, "frames.npy"), mmap_mode="r")
-    model = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r" if k == "sv_u8" else None)
-             for k in ("sv_u8", "dual_coef", "intercept", "n_support", "calib_a", "calib_b", "classes")}
+    sv = np.load(os.path.join(d, "sv_f64.npy"), mmap_mode="r")          # one physical copy for every worker
+    model = {k: np.load(os.path.join(d, k + ".npy")) for k in ("dual_coef", "intercept", "n_support", "calib_a", "calib_b", "classes")}
     model["gamma"] = float(np.load(os.path.join(d, "gamma.npy")))
     D = int(vh.shape[1] * vh.shape[3] + vh.shape[2] * vh.shape[3] + vh.shape[1] * vh.shape[2])
-    cal = BS.build_sklearn_rbf_model(model, D)
+    cal = BS.build_sklearn_rbf_model(model, D, sv_f64=sv)
     BS._reference_path(np.asarray(vh[lo:lo + 1]), cal, O)          # touch every code path once (imports, page-ins)
-    while time.time() < t_go:                                      # common start: the workers' start-up is not the baseline
-        time.sleep(0.005)
+    open(os.path.join(d, "ready_%d" % wid), "w").close()
+    go = os.path.join(d, "go")
+    while not os.path.exists(go):                                  # common start: the workers' start-up is not the baseline
+        time.sleep(0.01)
+    t_go = float(open(go).read())
+    while time.time() < t_go:
+        time.sleep(0.002)
     labels = []
     t0 = time.time()
     pos = lo
