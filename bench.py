@@ -520,6 +520,11 @@ def run_general(a, env, grid, frames):
     }
 
 
+def _top2_margin(p):
+    srt = np.sort(p, axis=1)
+    return srt[:, -1] - srt[:, -2]
+
+
 def run_dnn(a, env):
     """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection (csrc/project.hip) ->
     [-1,1] scaling + Pillow-exact bicubic resize to 80x80 (csrc/resize.hip) -> fused conv trunk (csrc/dnn.hip) -> dense
@@ -605,6 +610,10 @@ def run_dnn(a, env):
                         "algorithmic_flop_per_frame": conv_flop, "traffic": None},
            "parity": {"frames": npar, "proba_max_abs_err_vs_float64_oracle": float(np.abs(got - want).max()),
                       "label_mismatch": int((got.argmax(1) != want.argmax(1)).sum()),
+                      # the rule of tests/test_nn_gpu.py: labels must agree wherever the oracle's top-2 margin exceeds 1e-2
+                      "label_mismatch_where_oracle_margin_gt_1e-2": int(((got.argmax(1) != want.argmax(1)) & (_top2_margin(want) > 1e-2)).sum()),
+                      "rows_inside_the_1e-2_margin": int((_top2_margin(want) <= 1e-2).sum()),
+                      "mean_top2_margin": float(_top2_margin(want).mean()),
                       "note": "parity unpinned by the reference (no weights, no TensorFlow here): random-init weights, "
                               "bf16 GPU chain vs the float64 NumPy restatement of the same chain"}}
     return out

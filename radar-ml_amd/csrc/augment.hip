@@ -134,8 +134,7 @@ extern "C" int rml_augment(rml_ctx* ctx, int op, const float* src, int64_t B, in
     const size_t lds = op == RML_AUG_NOISE ? 0 : (size_t)H * W * sizeof(double);
     RML_REQUIRE(lds <= 150 * 1024, RML_ERR_UNSUPPORTED, "rml_augment: plane too large for the LDS-resident spline filter");
     RML_HIP(hipSetDevice(ctx->device));
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    RML_MAX_DYN_LDS(160 * 1024, &k_augment);
     AugArgs a{src, dst, H, W, op, params};
     hipLaunchKernelGGL(k_augment, dim3((unsigned)B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
     RML_HIP(hipGetLastError());

@@ -365,8 +365,7 @@ int launch_trunk(const TrunkArgs& a, int num_cu, hipStream_t stream) {
     const TrunkLayout L(a.H, a.W, SR, MT);
     if (SR * (a.W / 4) > 16 * MT || L.nt1 > 4 * TPW || L.total > 150 * 1024) return RML_ERR_UNSUPPORTED;
     if (L.total * WPC > 160 * 1024) return RML_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk<SR, INBF, MT, PF, WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    RML_MAX_DYN_LDS(160 * 1024, &k_dnn_trunk<SR, INBF, MT, PF, WPC>);
     const int64_t slots = (int64_t)WPC * num_cu;                                     // workgroups resident at once
     const int64_t gx = slots / 3 > 0 ? slots / 3 : 1;
     hipLaunchKernelGGL((k_dnn_trunk<SR, INBF, MT, PF, WPC>), dim3((unsigned)(a.B < gx ? a.B : gx), 3), dim3(256), L.total, stream, a);
@@ -627,8 +626,7 @@ template <bool INBF>
 int launch_trunk_rf(const TrunkArgs& a, int num_cu, hipStream_t stream) {
     const RfLayout L(a.H, a.W);
     if (L.total > 160 * 1024) return RML_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dnn_trunk_rf<INBF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    RML_MAX_DYN_LDS(160 * 1024, &k_dnn_trunk_rf<INBF>);
     const int64_t need = (a.B + RF_WAVES - 1) / RF_WAVES;
     hipLaunchKernelGGL((k_dnn_trunk_rf<INBF>), dim3((unsigned)(need < num_cu ? need : num_cu)), dim3(64 * RF_WAVES), L.total, stream, a);
     return RML_OK;

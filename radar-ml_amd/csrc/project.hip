@@ -651,12 +651,10 @@ void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
         pad = mine < 82 * 1024 ? 82 * 1024 - mine : 0;
     }
     if (pp.o.skip_if_set) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_wave<VT, MODE, NY, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_wave<VT, MODE, NY, G, true>);
         hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, pad, st, pp);
     } else {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_wave<VT, MODE, NY, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_wave<VT, MODE, NY, G, false>);
         hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, false>), grid, block, pad, st, pp);
     }
 }
@@ -866,12 +864,10 @@ template <int NM>
 void launch_u8_max(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block(kThreads);
     if (pp.o.skip_if_set) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_u8_max<NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_u8_max<NM, true>);
         hipLaunchKernelGGL((k_project_u8_max<NM, true>), grid, block, lds_bytes, st, pp, CPR, S);
     } else {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_u8_max<NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_u8_max<NM, false>);
         hipLaunchKernelGGL((k_project_u8_max<NM, false>), grid, block, lds_bytes, st, pp, CPR, S);
     }
 }
@@ -1032,12 +1028,10 @@ void launch_fast_pred(const ProjParams& pp, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block(kThreads);
     // > 64 KB of dynamic LDS needs the attribute (gfx950 has 160 KB per CU); harmless otherwise
     if (pp.o.skip_if_set) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<VT, MODE, LPR, NM, FULL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_fast<VT, MODE, LPR, NM, FULL, true>);
         hipLaunchKernelGGL((k_project_fast<VT, MODE, LPR, NM, FULL, true>), grid, block, lds_bytes, st, pp);
     } else {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_fast<VT, MODE, LPR, NM, FULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_fast<VT, MODE, LPR, NM, FULL, false>);
         hipLaunchKernelGGL((k_project_fast<VT, MODE, LPR, NM, FULL, false>), grid, block, lds_bytes, st, pp);
     }
 }
@@ -1057,12 +1051,10 @@ template <typename VT, int MODE, int NM>
 void launch_rowgroup(const ProjParams& pp, int R, size_t lds_bytes, hipStream_t st) {
     dim3 grid((unsigned)pp.B), block((unsigned)(R * pp.ZQ));
     if (pp.o.skip_if_set) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<VT, MODE, NM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_rowgroup<VT, MODE, NM, true>);
         hipLaunchKernelGGL((k_project_rowgroup<VT, MODE, NM, true>), grid, block, lds_bytes, st, pp, R);
     } else {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_rowgroup<VT, MODE, NM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+        RML_MAX_DYN_LDS(160 * 1024, &k_project_rowgroup<VT, MODE, NM, false>);
         hipLaunchKernelGGL((k_project_rowgroup<VT, MODE, NM, false>), grid, block, lds_bytes, st, pp, R);
     }
 }

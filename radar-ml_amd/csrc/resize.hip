@@ -254,8 +254,7 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
 
 template <int KS>
 void launch_resize(const ResizeArgs& a, size_t lds, int num_cu, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    RML_MAX_DYN_LDS(160 * 1024, &k_resize<KS>);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resize<KS>, 256, lds) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -64,6 +65,22 @@ struct rml_ctx_guard {
 // records an event on st when profiling is on (no-op otherwise)
 void rml_prof_mark(rml_ctx* ctx, hipStream_t st);
 void rml_prof_mark_gemm(rml_ctx* ctx, hipStream_t st);
+
+// "done once per device" for hipFuncSetAttribute: one process may drive several devices (one context each), and the
+// attribute belongs to the device's copy of the kernel
+struct rml_once_per_device {
+    std::atomic<uint64_t> mask{0};
+    bool first(int dev) { const uint64_t bit = 1ull << (dev & 63); return !(mask.fetch_or(bit) & bit); }
+};
+// allow `bytes` of dynamic LDS for kernel (the variadic part: a template-id may hold commas) on the current device
+#define RML_MAX_DYN_LDS(bytes, ...)                                                                                     \
+    do {                                                                                                                \
+        static rml_once_per_device _once;                                                                               \
+        int _dev = 0;                                                                                                   \
+        (void)hipGetDevice(&_dev);                                                                                      \
+        if (_once.first(_dev))                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+    } while (0)
 
 void rml_set_error(const char* fmt, ...);
 int rml_hip_fail(hipError_t e, const char* what, const char* file, int line);

@@ -460,11 +460,9 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 constexpr int kBig = 256;
 constexpr int kBigStageBytes = 2 * kBig * kStepBytes;     // 64 KiB: [SV 256 x 128 B][samples 256 x 128 B]
 
-// STAG = 1 (round 3): the two waves of a SIMD take turns at the VMEM queue.  Waves 0-3 (one per SIMD) issue their share of
-// stage kt+1 right after the barrier, as before; their SIMD partners, waves 4-7, first run half of their MFMAs and issue
-// their share then.  A burst of all 64 DMA instructions fills the CU's VMEM queue and every wave idles in its in-order issue
-// stage (no MFMA goes out for ~800-1000 cycles per step); with two half bursts one wave of each SIMD always has MFMAs to run.
-template <int PT, int STAG = 0>
+// (Round 3 measured this kernel against three issue schedules, tools/exp/README.md: it stays as the RML_GEMM_RING=0 arm of
+// tools/gemm_ab.py; the default for large batches is k_svm_gemm_ring below.)
+template <int PT>
 __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -540,10 +538,9 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
     // Tried and measured slower: issuing the stage in four slices between the MFMA groups (1.11 ms: it lands later), touching
     // the lines of stage kt+3 with one dword load per lane to make the later DMA an L2 hit (0.99 ms).
     stage(0, 0);
-    const bool late = STAG && __builtin_amdgcn_readfirstlane(tid) >= 256;      // waves 4-7: issue after the first half of the MFMAs
     for (int kt = 0; kt < a.KT; ++kt) {
         __syncthreads();                               // DMA of step kt landed and visible; other buffer free
-        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT && !late) stage(kt + 1, (kt + 1) & 1);
+        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* sb = smem + (kt & 1) * kBigStageBytes;
         // two fragment register sets: reads of sub-step kk+1 are in flight under the MFMAs of kk
         v4i af[2][4], bf[2][2];
@@ -574,10 +571,6 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
 #endif
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (STAG && kk == 1) {
-                if (late && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
     }
 
@@ -1385,12 +1378,7 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
 #define RML_GEMM_CASE(PTV)                                                                                         \
     case PTV: {                                                                                                    \
-        static bool attr_done = false;                                                                             \
-        if (!attr_done) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm<PATH, PTV, KM>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);                     \
-            attr_done = true;                                                                                      \
-        }                                                                                                          \
+        RML_MAX_DYN_LDS(144 * 1024, &k_svm_gemm<PATH, PTV, KM>);                                                   \
         hipLaunchKernelGGL((k_svm_gemm<PATH, PTV, KM>), grid, block, lds, st, ga);                                 \
     } break;
     switch (m->PT) {
@@ -1413,8 +1401,7 @@ int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
     const size_t lds = (size_t)kRingSlots * kOpStageBytes;
 #define RML_RING_CASE(PTV)                                                                                         \
     case PTV: {                                                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_ring<PTV, DIG>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        RML_MAX_DYN_LDS(160 * 1024, &k_svm_gemm_ring<PTV, DIG>);                                                   \
         hipLaunchKernelGGL((k_svm_gemm_ring<PTV, DIG>), grid, block, lds, st, ra);                                 \
     } break;
     switch (m->PT) {
@@ -1430,10 +1417,10 @@ int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
 
 int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     // RML_GEMM_RING (read per call: tests and A/B runs flip it): unset / 1 = k_svm_gemm_ring (5-slot operand-stage ring,
-    // interleaved DMA issue), 0 = the two-stage kernel, 3 = the two-stage kernel with staggered issue (experiment arm)
+    // interleaved DMA issue), 0 = the two-stage kernel of round 2
     const char* re = getenv("RML_GEMM_RING");
     const int ring = re ? atoi(re) : 1;
-    if (ring != 0 && ring != 3) {
+    if (ring != 0) {
         RingArgs ra{};
         ra.sv = ga.sv; ra.x = ga.x; ra.ld_sv = ga.ld_sv; ra.ld_x = ga.ld_x; ra.KT = ga.KT;
         ra.N = ga.N; ra.Mpad = ga.Mpad; ra.sv_rows = ga.sv_rows; ra.ST = ga.ST; ra.FT = ga.FT;
@@ -1444,16 +1431,9 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
     const int FT2 = (ga.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
     dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
-    if (ring == 3 && m->PT == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_svm_gemm_i8_256<3, 1>), grid, block, lds, st, ga);
-        RML_HIP(hipGetLastError());
-        return RML_OK;
-    }
 #define RML_BIG_CASE(PTV)                                                                                          \
     case PTV: {                                                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svm_gemm_i8_256<PTV>),                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        RML_MAX_DYN_LDS(160 * 1024, &k_svm_gemm_i8_256<PTV>);                                                      \
         hipLaunchKernelGGL((k_svm_gemm_i8_256<PTV>), grid, block, lds, st, ga);                                    \
     } break;
     switch (m->PT) {

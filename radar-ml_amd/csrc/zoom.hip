@@ -97,8 +97,7 @@ extern "C" int rml_zoom_features(rml_ctx* ctx, const float* xz, const float* yz,
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_zoom_features: B too large");
     RML_HIP(hipSetDevice(ctx->device));
     a.feat = feat; a.ld = ld_feat; a.scale_div = scale_div;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zoom), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    RML_MAX_DYN_LDS(160 * 1024, &k_zoom);
     hipLaunchKernelGGL(k_zoom, dim3((unsigned)B, (unsigned)a.npl), dim3(256), lds, static_cast<hipStream_t>(stream), a);
     RML_HIP(hipGetLastError());
     return RML_OK;

@@ -22,8 +22,12 @@ def test_dnn_forward_bf16_vs_fp32_cpu(rml):
     got32 = gpu.predict(x, autocast_dtype=None)
     got16 = gpu.predict(x, autocast_dtype="bfloat16")
     assert np.abs(got32 - want).max() < 1e-4
-    assert np.abs(got16 - want).max() < 3e-2                     # bf16 tolerance on probabilities
-    assert (got16.argmax(1) == want.argmax(1)).mean() > 0.97
+    print("dnn bf16 autocast vs fp32 cpu (random init): max |dp| = %.2e, label agreement %.4f"
+          % (np.abs(got16 - want).max(), (got16.argmax(1) == want.argmax(1)).mean()))
+    assert np.abs(got16 - want).max() < DNN_BF16_RANDOM_INIT_TOL    # bf16 tolerance on probabilities
+    srt = np.sort(want, axis=1)
+    confident = (srt[:, -1] - srt[:, -2]) > 5e-3                  # random-init outputs sit near 1/3: compare labels off the ties only
+    np.testing.assert_array_equal(got16.argmax(1)[confident], want.argmax(1)[confident])
 
 
 def test_resize_bit_exact_vs_pillow_golden(rml):
@@ -97,8 +101,71 @@ def test_dnn_predict_volumes_end_to_end(rml):
     want = cpu.predict([np.stack(p)[..., None] for p in planes], autocast_dtype=None)
     got = gpu.predict_volumes(torch.from_numpy(vol).cuda(), batch_size=16).cpu().numpy()
     assert got.shape == want.shape == (24, 3)
-    assert np.abs(got - want).max() < 3e-2
+    print("dnn predict_volumes (fused bf16 chain) vs fp32 cpu chain (random init): max |dp| = %.2e" % np.abs(got - want).max())
+    assert np.abs(got - want).max() < DNN_BF16_RANDOM_INIT_TOL
     assert np.allclose(got.sum(1), 1.0, atol=1e-3)
+
+
+def _train_classifier_with_margins(dnn, steps=160, seed=21):
+    """A Classifier whose outputs are NOT ~1/3 each: trained in float32 on the GPU (plain PyTorch layers) for a few hundred Adam
+    steps on synthetic 3-class radar frames (oracle_np.synth_volumes: class-dependent blob sizes) at the Walabot grid, through
+    the reference's preprocessing (max-projection, [-1, 1] scaling, Pillow bicubic resize to 80 x 80: dnn.py:200-254).
+    Returns (cpu float32 model, held-out volumes, held-out labels)."""
+    import oracle_np as O
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    import radar_ml_amd as rml_
+    torch.manual_seed(seed)
+    model = dnn.define_classifier(device="cuda")
+    vol, cls = O.synth_volumes(seed, 768 + 256, 22, 31, 176)
+    feat = rml_.process_volumes(torch.from_numpy(vol).cuda(), mode="max", scale=False)
+    xz, yz, xy = nc.preprocess_features(feat, (22, 31, 176), (80, 80), out_dtype="float32")
+    xs = [t.reshape(-1, 1, 80, 80) for t in (xz, yz, xy)]
+    y = torch.from_numpy(np.asarray(cls)).cuda().long()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)        # dnn.py:89-90
+    model.train()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for _ in range(steps):
+        idx = torch.randint(0, 768, (64,), device="cuda", generator=g)
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model.logits(*[t[idx] for t in xs]).float(), y[idx])
+        loss.backward()
+        opt.step()
+    model.eval()
+    return model.to("cpu"), vol[768:], np.asarray(cls)[768:]
+
+
+def test_dnn_trained_model_labels_match_the_oracle_where_its_margin_allows(rml):
+    """a-9 on a model with real margins (random-init outputs sit at ~1/3 each and say nothing): the bf16 GPU chain
+    (projection -> resize -> fused trunk -> dense tail) against the float64 NumPy restatement of the Keras layers on the same
+    trained weights: probabilities within DNN_BF16_PROBA_TOL and the SAME LABEL wherever the oracle's top-2 margin exceeds
+    1e-2; the rows inside the margin are counted and reported, not asserted."""
+    import oracle_np as O
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    cpu, vol, cls = _train_classifier_with_margins(dnn)
+    gpu = copy.deepcopy(cpu).to("cuda").eval()
+    planes = [[], [], []]
+    for v in vol:
+        for i, pr in enumerate(O.project_max(v)):
+            planes[i].append(O.pil_resize_bicubic(O.scale_unit_range(pr), (80, 80)))
+    convs, dense = cpu.keras_weights()
+    want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)      # float64
+    got = gpu.predict_volumes(torch.from_numpy(vol).cuda(), batch_size=128).cpu().numpy()
+    srt = np.sort(want, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    confident = margin > 1e-2
+    acc = float((want.argmax(1) == cls).mean())
+    err = float(np.abs(got - want).max())
+    print("trained dnn: oracle accuracy %.3f, mean top-2 margin %.3f, %d of %d rows inside the 1e-2 margin, max |dp| bf16 vs float64 = %.2e"
+          % (acc, float(margin.mean()), int((~confident).sum()), len(margin), err))
+    assert acc > 0.6 and float(margin.mean()) > 0.2                  # the model did learn: outputs are not ~1/3
+    np.testing.assert_array_equal(got.argmax(1)[confident], want.argmax(1)[confident])
+    assert err <= DNN_BF16_PROBA_TOL
+
+
+# measured on MI355X (printed by the tests with -s): |dp| of the bf16 chains against float32 / float64 is <= 4.8e-4 at random
+# init and 3.4e-3 on the trained model; the tolerances are ~2x the measured worst, not the 3e-2 of round 2
+DNN_BF16_PROBA_TOL = 8e-3            # trained model (outputs away from 1/3): measured 3.4e-3
+DNN_BF16_RANDOM_INIT_TOL = 1e-3      # random-init weights: measured 1.6e-4 ... 4.8e-4 over the three chains
 
 
 def test_sgan_step_fp16_tracks_fp32(rml):
@@ -135,16 +202,18 @@ def test_dnn_fused_trunk_vs_fp32_cpu(rml):
         got = gpu.features_fused(*[torch.from_numpy(a).cuda() for a in x]).float().cpu().numpy()
         assert got.shape == want.shape == (37, 38400)
         err = np.abs(got - want)
-        assert err.max() <= 2e-2 + 1e-2 * np.abs(want).max() and err.mean() <= 2e-3      # bf16 storage of activations
+        assert err.max() <= 6e-3 * max(1.0, np.abs(want).max()) and err.mean() <= 4e-4   # bf16 storage: measured 3.0e-3 / 1.8e-4
         got16 = gpu.features_fused(*[torch.from_numpy(a).cuda().to(torch.bfloat16) for a in x]).float().cpu().numpy()
         np.testing.assert_array_equal(got16, got)                 # bf16 planes in == float32 planes rounded on load
         import oracle_np as O                                      # and against the NumPy restatement of the Keras layers
         convs, dense = cpu.keras_weights()
         want_np = O.dnn_conv_features(x[0][:8], x[1][:8], x[2][:8], convs)
-        assert np.abs(got[:8] - want_np).max() <= 2e-2 + 1e-2 * np.abs(want_np).max()
+        assert np.abs(got[:8] - want_np).max() <= 6e-3 * max(1.0, np.abs(want_np).max())
         p_want = cpu.predict([a[..., None] for a in x], autocast_dtype=None)
         p_got = gpu.forward_fused(*[torch.from_numpy(a).cuda() for a in x]).cpu().numpy()
-    assert np.abs(p_got - p_want).max() < 3e-2
+    print("dnn fused trunk: features max err %.3e (max |f| %.2f), mean err %.2e; proba max |dp| %.2e"
+          % (err.max(), np.abs(want).max(), err.mean(), np.abs(p_got - p_want).max()))
+    assert np.abs(p_got - p_want).max() < DNN_BF16_RANDOM_INIT_TOL
     # other sizes: strips of 4 / 2 conv2 rows, a partial last strip (24 rows -> 6 conv2 rows), sgan's 128x128
     for (h_, w_) in ((48, 64), (24, 16), (128, 128), (44, 36), (4, 4)):
         small = dnn.Classifier([(h_, w_, 1)] * 3, 3).eval()
@@ -293,6 +362,32 @@ def test_sgan_trainer_hip_graph_matches_eager(rml):
     assert np.abs(a - b).max() < 2e-2, (a, b)
 
 
+def _sgan_param_class(name):
+    """branches.B.{0,3,6}.conv.weight -> conv1/2/3 kernel; branches.B.{1,4,7}.{weight,bias} -> bn1/2/3 gamma / beta;
+    fc1/fc2/fc3 and the dense batch norms"""
+    parts = name.split(".")
+    if parts[0] == "branches":
+        li, layer = int(parts[2]) // 3 + 1, int(parts[2]) % 3
+        if layer == 0:
+            return "conv%d.kernel" % li
+        return "bn%d.%s" % (li, "gamma" if parts[-1] == "weight" else "beta")
+    if parts[0] in ("fc1", "fc2", "fc3"):
+        return parts[0] + "." + ("kernel" if parts[-1] == "weight" else "bias")
+    if parts[0] in ("bn1", "bn2"):
+        return "dense_" + parts[0] + "." + ("gamma" if parts[-1] == "weight" else "beta")
+    return name
+
+
+# relative gradient error |g16 - g32| / |g32| per parameter class and half-precision type (the test prints what it measures, -s)
+# measured on MI355X (worst over the c and d heads, round 3); the tolerance is twice that, with a floor for the classes whose
+# error is round-off only
+SGAN_GRAD_REL_MEASURED = {
+    "float16": {"bn1.beta": 0.0526, "bn1.gamma": 0.0524, "bn2.beta": 0.0576, "bn2.gamma": 0.0477, "bn3.beta": 0.0639, "bn3.gamma": 0.0461, "conv1.kernel": 0.0514, "conv2.kernel": 0.0460, "conv3.kernel": 0.0450, "dense_bn1.beta": 0.0510, "dense_bn1.gamma": 0.0343, "dense_bn2.beta": 0.0166, "dense_bn2.gamma": 0.0009, "fc1.kernel": 0.0409, "fc2.kernel": 0.0415, "fc3.bias": 0.0007, "fc3.kernel": 0.0013},
+    "bfloat16": {"bn1.beta": 0.2087, "bn1.gamma": 0.2144, "bn2.beta": 0.2126, "bn2.gamma": 0.1983, "bn3.beta": 0.2234, "bn3.gamma": 0.1943, "conv1.kernel": 0.1936, "conv2.kernel": 0.1844, "conv3.kernel": 0.1759, "dense_bn1.beta": 0.1387, "dense_bn1.gamma": 0.1201, "dense_bn2.beta": 0.0727, "dense_bn2.gamma": 0.0089, "fc1.kernel": 0.1688, "fc2.kernel": 0.1426, "fc3.bias": 0.0061, "fc3.kernel": 0.0092},
+}
+SGAN_GRAD_REL_TOL = {amp: {k: max(2.0 * v, {"float16": 0.004, "bfloat16": 0.03}[amp]) for k, v in d.items()} for amp, d in SGAN_GRAD_REL_MEASURED.items()}
+
+
 @pytest.mark.parametrize("amp", ["float16", "bfloat16"])
 def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
     """BASELINE configs[4] at its real size -- 128x128 projections, batch 256 -- not on two loss scalars but on the
@@ -331,12 +426,13 @@ def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
         return float(loss), {k: (p.grad.detach().float() / 256.0) for k, p in model.named_parameters()}
 
     dt = getattr(torch, amp)
-    tol_rel, tol_cos = (0.12, 0.992) if amp == "float16" else (0.5, 0.85)        # about twice the measured worst (printed below)
+    tols = SGAN_GRAD_REL_TOL[amp]                            # per parameter class: ~2x the measured worst (printed below)
     for head in ("c", "d"):
         l32, g32 = grads(ref, None, head)
         l16, g16 = grads(fus, dt, head)
         assert abs(l32 - l16) < (5e-3 if amp == "float16" else 3e-2), (head, l32, l16)
         worst = []
+        by_class = {}
         for k in g32:
             a, b = g32[k].reshape(-1), g16[k].reshape(-1)
             if k.endswith(".conv.bias") or k in ("fc1.bias", "fc2.bias"):
@@ -352,9 +448,13 @@ def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
             rel = float((a - b).norm()) / na
             cos = float(torch.dot(a, b) / (na * float(b.norm()) + 1e-30))
             worst.append((rel, cos, k))
-            assert rel < tol_rel and cos > tol_cos, (head, k, rel, cos)
+            pc = _sgan_param_class(k)
+            by_class[pc] = max(by_class.get(pc, 0.0), rel)
+            assert rel < tols[pc] and cos > 1.0 - 0.6 * tols[pc] ** 2 - 1e-4, (head, k, pc, rel, cos)
         assert len(worst) >= 30
-        print("sgan %s head %s: worst relative gradient error %.4f (%s), worst cosine %.5f" % (amp, head, max(worst)[0], max(worst)[2], min(w[1] for w in worst)))
+        print("sgan %s head %s: worst relative gradient error %.4f (%s), worst cosine %.5f; per class: %s"
+              % (amp, head, max(worst)[0], max(worst)[2], min(w[1] for w in worst),
+                 ", ".join("%s %.4f" % kv for kv in sorted(by_class.items()))))
     # running statistics after the same number of forward passes agree as well (incl. the bias the fused path adds back)
     for (k, a), (_, b) in zip(ref.named_buffers(), fus.named_buffers()):
         if k.endswith("running_mean") or k.endswith("running_var"):
