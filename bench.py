@@ -256,6 +256,8 @@ def run_workload(a, env, grid, frames, primary):
     rpl = 1 if 32 < zq <= 64 else (64 // zq if zq in (16, 32) and Y % (64 // zq) == 0 else 0)
     wave = os.environ.get("RML_WAVEFRAME", "1") != "0" and rpl > 0 and Y // rpl <= 32      # wave_kernel_wanted(share_cu) of csrc/project.hip
     kname = "k_project_wave" if wave else ("k_project_fast" if zq & (zq - 1) == 0 else "k_project_rowgroup")
+    if wave and zq == 44 and 16 < Y <= 32 and os.environ.get("RML_LINPLANE", "1") != "0":
+        kname = "k_project_lin"                          # try_launch_lin of csrc/project_lin.hip
     if a.ingest == "u8":
         kname = "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -1,0 +1,265 @@
+// Declarations shared by the projection translation units (project.hip, project_lin.hip): launch parameters, the reduction
+// operators, the fused feature / code / statistics emitter and the streaming-load helpers (all inline / templates).
+#pragma once
+#include "rml_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace rmlproj {
+
+constexpr int kThreads = 256;
+
+struct ProjParams {
+    const void* V;      // float32 or uint8 voxels (template VT of the kernels)
+    int64_t B;
+    int X, Y, Z, ZQ;
+    const int32_t* ijk;
+    int tpf;            // mode SLICE: targets (output rows) per frame; output row b reads frame b / tpf
+    int rpl;            // k_project_wave: real rows per 64-quad virtual row, decided by the launcher (wave_kernel_rpl)
+    ProjOut o;
+    int vec_ok[3];   // float4 stores allowed for plane pl (16-B aligned base and stride)
+};
+
+template <int MODE> struct Op;
+template <> struct Op<RML_MODE_MAX> {
+    static __device__ __forceinline__ float ident() { return -INFINITY; }
+    static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ void lds_atomic(float* p, float v) {
+        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+template <> struct Op<RML_MODE_SUM> {
+    static __device__ __forceinline__ float ident() { return 0.0f; }
+    static __device__ __forceinline__ float f(float a, float b) { return a + b; }
+    static __device__ __forceinline__ void lds_atomic(float* p, float v) {
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+template <int MODE> __device__ __forceinline__ float4 op4(float4 a, float4 b) {
+    return make_float4(Op<MODE>::f(a.x, b.x), Op<MODE>::f(a.y, b.y), Op<MODE>::f(a.z, b.z), Op<MODE>::f(a.w, b.w));
+}
+
+// Per-thread sink for finished projection values: scaled float store, uint8 code store and
+// the row statistics of the exact-integer SVM path.
+struct Emitter {
+    const ProjParams& a;
+    int64_t b;
+    int32_t isum = 0;
+    uint32_t isq = 0;       // per THREAD: < 66 000 codes of <= 255^2 each (the launchers keep a thread's share far below that)
+    int ok = 1;
+    double nsq = 0.0;
+    bool want_stats;
+
+    __device__ Emitter(const ProjParams& a_, int64_t b_) : a(a_), b(b_) {
+        want_stats = a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.q[0] || a.o.q[1] || a.o.q[2];
+    }
+    __device__ __forceinline__ float scaled(float v) const {
+        // true IEEE division: bit-identical to NumPy's float32 "x / 255." (common.py:148)
+        return (a.o.scale_div > 1.0f) ? __fdiv_rn(v, a.o.scale_div) : v;
+    }
+    __device__ __forceinline__ uint32_t code(float v) {
+        int c = (int)v;
+        bool good = ((float)c == v) && c >= 0 && c <= 255;
+        ok &= good ? 1 : 0;
+        c = good ? c : 0;
+        isum += c;
+        isq += (uint32_t)(c * c);
+        return (uint32_t)(c ^ 0x80);
+    }
+    // already-decided code (rml_quantize_rows)
+    __device__ __forceinline__ void put_code1(int pl, int64_t idx, int c, bool good) {
+        ok &= good ? 1 : 0;
+        c = good ? c : 0;
+        isum += c;
+        isq += (uint32_t)(c * c);
+        if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)(c ^ 0x80);
+    }
+    __device__ __forceinline__ void put1(int pl, int64_t idx, float v) {
+        if (!((a.o.sel >> pl) & 1u)) return;
+        if (a.o.p[pl]) a.o.p[pl][b * a.o.stride[pl] + idx] = scaled(v);
+        if (a.o.row_nsq) { double t = (double)scaled(v); nsq += t * t; }
+        if (want_stats) {
+            uint32_t c = code(v);
+            if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)c;
+        }
+    }
+    // idx is a multiple of 4
+    __device__ __forceinline__ void put4(int pl, int64_t idx, float4 v) {
+        if (!((a.o.sel >> pl) & 1u)) return;
+        if (a.o.p[pl]) {
+            float* dst = a.o.p[pl] + b * a.o.stride[pl] + idx;
+            float4 s = make_float4(scaled(v.x), scaled(v.y), scaled(v.z), scaled(v.w));
+            if (a.o.row_nsq) {
+                nsq += (double)s.x * (double)s.x + (double)s.y * (double)s.y;
+                nsq += (double)s.z * (double)s.z + (double)s.w * (double)s.w;
+            }
+            if (a.vec_ok[pl]) {
+                *reinterpret_cast<float4*>(dst) = s;
+            } else {
+                // rows that are only 4-byte aligned (D = 10 010 floats at the Walabot grid): still ONE 16-byte store -- a global
+                // store needs dword alignment only, and four dword stores at a 16-byte lane stride cost 4x the instructions
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                *reinterpret_cast<f32x4u*>(dst) = f32x4u{s.x, s.y, s.z, s.w};
+            }
+        }
+        if (want_stats) {
+            uint32_t c0 = code(v.x), c1 = code(v.y), c2 = code(v.z), c3 = code(v.w);
+            if (a.o.q[pl]) {
+                uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
+            }
+        }
+    }
+    // next frame of a persistent kernel
+    __device__ __forceinline__ void reset(int64_t b_) { b = b_; isum = 0; isq = 0; ok = 1; nsq = 0.0; }
+    // the same as finish() for kernels in which ONE WAVE owns the frame: no LDS, no barrier
+    __device__ void finish_wave(int lane) {
+        if (a.o.qrow) {
+            for (int64_t c = a.o.qD + lane; c < a.o.qstride; c += 64) a.o.qrow[b * a.o.qstride + c] = 0;
+        }
+        if (a.o.prow) {
+            for (int64_t c = a.o.pD + lane; c < a.o.pstride; c += 64) a.o.prow[b * a.o.pstride + c] = 0.0f;
+        }
+        if (!(a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.row_nsq)) return;
+        int64_t s = isum, q = isq;
+        int g = ok;
+        double nn = nsq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+            g &= __shfl_xor(g, off);
+            nn += __shfl_xor(nn, off);
+        }
+        if (lane == 0) {
+            if (a.o.row_isum) a.o.row_isum[b] = (int32_t)s;
+            if (a.o.row_isq) a.o.row_isq[b] = q;
+            if (a.o.row_flags) a.o.row_flags[b] = (int32_t)g;
+            if (a.o.row_nsq) a.o.row_nsq[b] = nn;
+        }
+    }
+    // block reduction of the statistics (up to 16 waves); red must hold >= 64 int64 slots; all threads call it
+    __device__ void finish(int64_t* red) {
+        if (a.o.qrow) {   // zero the pad columns [qD, qstride) of the code row (i8 value 0)
+            for (int64_t c = a.o.qD + threadIdx.x; c < a.o.qstride; c += blockDim.x) a.o.qrow[b * a.o.qstride + c] = 0;
+        }
+        if (a.o.prow) {   // zero the pad columns [pD, pstride) of the float row
+            for (int64_t c = a.o.pD + threadIdx.x; c < a.o.pstride; c += blockDim.x) a.o.prow[b * a.o.pstride + c] = 0.0f;
+        }
+        if (!(a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.row_nsq)) return;
+        int64_t s = isum, q = isq;
+        int g = ok;
+        double nn = nsq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+            g &= __shfl_xor(g, off);
+            nn += __shfl_xor(nn, off);
+        }
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double* redd = reinterpret_cast<double*>(red + 48);
+        __syncthreads();
+        if (lane == 0) { red[wave * 3 + 0] = s; red[wave * 3 + 1] = q; red[wave * 3 + 2] = g; redd[wave] = nn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t S = 0, Q = 0, G = 1;
+            double NN = 0.0;
+            for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { S += red[w * 3]; Q += red[w * 3 + 1]; G &= red[w * 3 + 2]; NN += redd[w]; }
+            if (a.o.row_isum) a.o.row_isum[b] = (int32_t)S;
+            if (a.o.row_isq) a.o.row_isq[b] = Q;
+            if (a.o.row_flags) a.o.row_flags[b] = (int32_t)G;
+            if (a.o.row_nsq) a.o.row_nsq[b] = NN;
+        }
+    }
+};
+
+// streaming load: every volume byte is read exactly once, so it is marked non-temporal (keeps the
+// support-vector tiles of the concurrently running SVM GEMM resident in L2 / Infinity Cache)
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#ifdef RML_NO_NT
+    return *p;
+#else
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+
+// uint8 volumes (the radar's native 0..255 magnitudes, 4x fewer HBM bytes): a lane's quad is one dword,
+// widened with v_cvt_f32_ubyte0..3; everything downstream is the float path, so the results are identical
+__device__ __forceinline__ float4 ld_stream(const uint32_t* p) {
+#ifdef RML_NO_NT
+    const uint32_t w = *p;
+#else
+    const uint32_t w = __builtin_nontemporal_load(p);
+#endif
+    return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
+}
+template <typename VT> struct Quad;
+template <> struct Quad<float> { typedef float4 T; };
+template <> struct Quad<uint8_t> { typedef uint32_t T; };
+
+// butterfly reduction over the LPR lanes of a row (all lanes end with the result)
+template <int MODE, int LPR> __device__ __forceinline__ float row_reduce(float r) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) r = Op<MODE>::f(r, __shfl_xor(r, off));
+    return r;
+}
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// reduction over the 64 lanes of a wave; the result is wave-uniform (an SGPR)
+template <int MODE> __device__ __forceinline__ float wave_reduce_uniform(float r) {
+    const float id = Op<MODE>::ident();
+    r = Op<MODE>::f(r, dpp_mov<0xB1, 0xF, true>(id, r));    // quad_perm [1,0,3,2]
+    r = Op<MODE>::f(r, dpp_mov<0x4E, 0xF, true>(id, r));    // quad_perm [2,3,0,1]
+    r = Op<MODE>::f(r, dpp_mov<0x141, 0xF, true>(id, r));   // row_half_mirror
+    r = Op<MODE>::f(r, dpp_mov<0x140, 0xF, true>(id, r));   // row_mirror: every lane of a 16-lane row holds the row's result
+    r = Op<MODE>::f(r, dpp_mov<0x142, 0xA, false>(id, r));  // row_bcast15 into rows 1 and 3
+    r = Op<MODE>::f(r, dpp_mov<0x143, 0xC, false>(id, r));  // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- register arrays indexed by the
+// constant stay in registers (a runtime-indexed array would go to scratch)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// acc[lane J] = uniform value (v_writelane_b32 with a constant lane select: one instruction, no compare mask)
+template <int J> __device__ __forceinline__ float park_lane(float acc, float uniform_val) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(uniform_val), "n"(J));
+    return acc;
+}
+
+// max without the v_max_f32 x,x "canonicalise" copy hipcc puts in front of every fmaxf of a loaded value (IEEE mode: it
+// would quiet a signalling NaN; v_max_f32 itself already returns the other operand for ANY NaN, which is the documented NaN
+// policy of the max-projection).  4 VALU less per row of the streaming loop.
+template <int MODE> __device__ __forceinline__ float op_raw(float a, float b) {
+#ifndef RML_NO_RAWMAX
+    if constexpr (MODE == RML_MODE_MAX) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    } else
+#endif
+    {
+        return Op<MODE>::f(a, b);
+    }
+}
+template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b) {
+    return make_float4(op_raw<MODE>(a.x, b.x), op_raw<MODE>(a.y, b.y), op_raw<MODE>(a.z, b.z), op_raw<MODE>(a.w, b.w));
+}
+
+// project_lin.hip: the linear-plane wave-per-frame kernel for rows that do not fill a load instruction (32 < Z/4 < 64); returns
+// true when it took the launch
+bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st);
+
+}  // namespace rmlproj

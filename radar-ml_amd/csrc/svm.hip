@@ -1536,7 +1536,9 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
     const bool gen_f32 = (policy == RML_PATH_F32);
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
-    const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, ctx->num_cu);
+    // CUs the GEMM can use: all of them, or the aux stream's share of a CU partition (RML_GEMM_CUS)
+    const int gemm_cus = (ctx->gemm_cus_per_xcd > 0 && st == ctx->aux_stream) ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
+    const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, gemm_cus);
     // general tiles whose rows fit the model's fixed-point range go to the multi-digit int8 kernel (digit planes in w.dig)
     const bool run_dig = dig_ready && w.dig && run_gen && !gen_f32 && !kmat && m->dig_ok;
     if (!tiles_done) {
@@ -1869,16 +1871,22 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // Byte volumes (k_project_u8_max, two workgroups per CU) take the 128x128 GEMM and the small chunks as well: its
     // workgroups fit beside the projection's, the 256x256 kernel's time-slice the CUs with them and three chunks per 65 536
     // frames leave the pipeline mostly filling and draining (64x64x128 uint8, same box: 6.0 -> 6.7-7.1 M frames/s).
-    // RML_PIPE_GEMM (experiment knob): 1 = the 256x256 ring kernel in whole-round chunks for the byte volumes as well
+    // RML_PIPE_GEMM (experiment knob): 1 = the 256x256 ring kernel in whole-round chunks for the byte volumes as well.
+    // CU partition (RML_GEMM_CUS=g at context creation): the GEMM owns g CUs of every XCD (aux stream), the projection the other
+    // 32 - g (masked projection stream) -- nothing shares a CU, so the projection runs in its stand-alone configuration and the
+    // GEMM is the ring kernel, its chunks sized for whole rounds of ITS CUs
+    const bool part = ctx->gemm_cus_per_xcd > 0 && ctx->proj_stream != nullptr;
+    const int gemm_cus = part ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
     const char* pge = getenv("RML_PIPE_GEMM");
-    const bool small_gemm = wave_proj || (vdtype == RML_VOL_U8 && !(pge && atoi(pge) == 1));
+    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && !(pge && atoi(pge) == 1)));
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
     // rows off the code grid: the multi-digit int8 kernel (256 x 256 tiles: chunks sized for whole rounds) where the model has a
     // digit frame and the batch is large enough, the float64 MFMA kernel otherwise
     const bool use_dig = vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
-    const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, ctx->num_cu)
+    const int64_t CH = part ? std::min<int64_t>(round_up(B, kTile), pick_chunk_env(small_chunk))       // short chunks: the last chunk's GEMM is exposed
+                       : (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
                        : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig);
@@ -1912,7 +1920,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
-        o.share_cu = 1;
+        o.share_cu = part ? 0 : 1;
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // uint8 volumes are on the code grid by construction: one projection pass (codes + statistics), the exact GEMM on
@@ -1944,7 +1952,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
-            const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, ctx->num_cu))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
@@ -1958,7 +1966,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             }
         of.sel = mask & RML_MASK_ALL;
         of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
-        of.share_cu = 1;
+        of.share_cu = part ? 0 : 1;
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
         if (!grid_ok) rml_prof_mark(ctx, st);

@@ -54,6 +54,8 @@ def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
     with RML_WAVE_SHARE: quarter-plane buffers, one workgroup per CU)."""
     import torch
     monkeypatch.setenv("RML_WAVEFRAME", knob)
+    monkeypatch.setenv("RML_LINPLANE", "0")           # rows of 44 quads: this test keeps them on k_project_wave (the linear-plane kernel
+    #                                                   has its own test below)
     if knob == "3" and shape[0] % 2 == 0:
         monkeypatch.setenv("RML_WAVE_SHARE", "1")
     X, Y, Z = shape
@@ -81,6 +83,55 @@ def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
     vf = (rng.standard_normal((64, X, Y, Z)) * 50).astype(np.float32)      # non-integer, negative values
     for g, w in zip(rml.project(vf, mode="max"), O.project_max(vf)):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("shape", [(22, 31, 176), (4, 20, 176), (3, 32, 176), (5, 17, 176), (1, 31, 176)])
+@pytest.mark.parametrize("share", ["0", "1"])
+def test_linear_plane_kernel_many_frames(rml, shape, share, monkeypatch):
+    """k_project_lin (csrc/project_lin.hip): rows of 44 quads loaded as the contiguous array of quads a plane is (the Walabot
+    arena grid 22 x 31 x 176 and its neighbours with 17..32 rows): more frames than resident waves, so every wave walks
+    several frames with the cross-frame prefetch; stand-alone (two workgroups per CU) and in the configuration the fused
+    pipeline uses beside the GEMM (RML_WAVE_SHARE: one workgroup per CU); max and sum, float rows + codes + statistics,
+    integer and non-integer / negative data -- bit-exact against the oracle, and against k_project_wave on the same frames."""
+    monkeypatch.setenv("RML_LINPLANE", "1")
+    if share == "1":
+        monkeypatch.setenv("RML_WAVE_SHARE", "1")
+    else:
+        monkeypatch.delenv("RML_WAVE_SHARE", raising=False)
+    X, Y, Z = shape
+    B = 2600
+    rng = np.random.default_rng(X * 1000 + Y)
+    v = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
+    v[rng.random((B, X, Y, Z)) < 0.7] = 0
+    got = rml.project(v, mode="max")
+    for g, w in zip(got, O.project_max(v)):
+        np.testing.assert_array_equal(g, w)
+    got = rml.project(v, mode="sum")
+    for g, w in zip(got, O.project_sum(v)):
+        np.testing.assert_array_equal(g, w)
+    feat, q, isum, isq, flags = rml.process_volumes(v, mode="max", scale=True, codes=True)
+    xz, yz, xy = O.project_max(v)
+    np.testing.assert_array_equal(feat.cpu().numpy(), O.features_from_projections(xz, yz, xy, (True, True, True), True))
+    raw = O.features_from_projections(xz, yz, xy, (True, True, True), False)
+    D = raw.shape[1]
+    qh = q.cpu().numpy()
+    np.testing.assert_array_equal(qh[:, :D] ^ 0x80, raw.astype(np.uint8))
+    assert not qh[:, D:].any()
+    np.testing.assert_array_equal(isum.cpu().numpy(), raw.astype(np.int64).sum(1))
+    np.testing.assert_array_equal(isq.cpu().numpy(), (raw.astype(np.int64) ** 2).sum(1))
+    assert flags.cpu().numpy().all()
+    vf = (rng.standard_normal((700, X, Y, Z)) * 50).astype(np.float32)     # non-integer, negative values; > 2 * 256 frames
+    lin = rml.project(vf, mode="max")
+    for g, w in zip(lin, O.project_max(vf)):
+        np.testing.assert_array_equal(g, w)
+    monkeypatch.setenv("RML_LINPLANE", "0")
+    for g, w in zip(rml.project(vf, mode="max"), lin):                     # the wave kernel gives the same bits
+        np.testing.assert_array_equal(g, w)
+    # masks: only some planes wanted
+    monkeypatch.setenv("RML_LINPLANE", "1")
+    for mask in ((True, False, True), (False, True, False)):
+        f2 = rml.process_volumes(v[:600], mode="max", proj_mask=rml.ProjMask(*mask), scale=True)
+        np.testing.assert_array_equal(f2.cpu().numpy(), O.features_from_projections(xz[:600], yz[:600], xy[:600], mask, True))
 
 
 @pytest.mark.parametrize("shape", [(22, 31, 176), (64, 64, 128), (5, 7, 9)])
