@@ -81,7 +81,7 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ev_proj[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     }
@@ -101,7 +101,7 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (ctx->ev_proj[i]) (void)hipEventDestroy(ctx->ev_proj[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }

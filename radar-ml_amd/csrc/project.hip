@@ -395,7 +395,7 @@ void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
     // beside a GEMM: the request is padded past half of the CU's LDS, so that the dispatcher cannot put two of these
     // persistent workgroups on one CU (and none on another) while GEMM workgroups (69.6 KB) still fit next to one
     size_t pad = 0;
-    if (pp.o.share_cu && per_cu == 1) {
+    if (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad) {
         const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
         pad = mine < 82 * 1024 ? 82 * 1024 - mine : 0;
     }

@@ -17,9 +17,17 @@ namespace {
 
 using namespace rmlproj;
 
-template <int MODE, int NI, int RG, int NGRP, bool PRED>
-__global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
+// BALLAST: 64 extra live registers (260 in all): two of these waves can then not share a SIMD's 512 registers while a
+// 128-register GEMM wave still fits beside one -- the pipeline's way of getting exactly one projection workgroup per CU when the
+// GEMM workgroup beside it needs half of the LDS itself (k_svm_gemm_ring128: 80 KiB), so that an LDS pad cannot do it.
+template <int MODE, int NI, int RG, int NGRP, bool PRED, bool BALLAST>
+__global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams a) {
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
+    float ballast[BALLAST ? 64 : 1];
+    if constexpr (BALLAST) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) ballast[i] = __int_as_float((int)threadIdx.x + i);
+    }
     static_assert(NGRP == 2 && RG % 8 == 0, "two groups per plane (the row buffers alternate statically); xz folds 8 rows per wait");
     constexpr int NT = NI * NGRP;                       // load instructions per plane
     const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
@@ -70,6 +78,10 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
     Emitter em(a, cf);
     fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
     for (; cf < a.B; cf += stride) {
+        if constexpr (BALLAST) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(ballast[i]));
+        }
         em.reset(cf);
         float4 yz[NT];
         static_for<NT>([&](auto tc) { yz[decltype(tc)::value] = id4; });
@@ -144,26 +156,33 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
         });
         em.finish_wave(lane_f);
     }
+    if constexpr (BALLAST) {                            // a use the compiler cannot remove (never true: the values are small integers' bits)
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { asm volatile("" : "+v"(ballast[i])); acc += ballast[i]; }
+        if (acc == 123456.789f && a.o.row_flags) a.o.row_flags[0] = 0;
+    }
 }
 
-template <int MODE>
+template <int MODE, bool BALLAST>
 void launch_lin(const ProjParams& pp, int num_cu, hipStream_t st) {
     constexpr int NI = 11, RG = 16, NGRP = 2;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
     const int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
     const int64_t want = (pp.B + 3) / 4;
-    const int64_t cap = (int64_t)num_cu * per_cu;
+    const int64_t cap = (int64_t)num_cu * (BALLAST ? 1 : per_cu);
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
-    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) = 66 KB; beside a GEMM the request is padded past half of the
-    // CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see launch_wave)
+    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) = 66 KB.  Beside a GEMM (share_cu = 1) the request is padded past
+    // half of the CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see launch_wave);
+    // share_cu = 2: the BALLAST variant does that with registers and asks for its own 66 KB only
     const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
-    const size_t lds = (pp.o.share_cu && per_cu == 1 && mine < 82 * 1024) ? 82 * 1024 : mine;
+    const size_t lds = (!BALLAST && pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 82 * 1024) ? 82 * 1024 : mine;
     if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, true>);
-        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, true>), grid, block, lds, st, pp);
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>);
+        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>), grid, block, lds, st, pp);
     } else {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, false>);
-        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, false>), grid, block, lds, st, pp);
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, false, BALLAST>);
+        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, false, BALLAST>), grid, block, lds, st, pp);
     }
 }
 
@@ -178,8 +197,9 @@ bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st) 
     if (pp.B < 2 * (int64_t)num_cu) return false;       // small batches stay on the workgroup-per-frame kernels (latency)
     const char* env = getenv("RML_LINPLANE");
     if (env && atoi(env) == 0) return false;
-    if (mode == RML_MODE_MAX) launch_lin<RML_MODE_MAX>(pp, num_cu, st);
-    else if (mode == RML_MODE_SUM) launch_lin<RML_MODE_SUM>(pp, num_cu, st);
+    const bool ballast = pp.o.share_cu == 2;
+    if (mode == RML_MODE_MAX) { if (ballast) launch_lin<RML_MODE_MAX, true>(pp, num_cu, st); else launch_lin<RML_MODE_MAX, false>(pp, num_cu, st); }
+    else if (mode == RML_MODE_SUM) { if (ballast) launch_lin<RML_MODE_SUM, true>(pp, num_cu, st); else launch_lin<RML_MODE_SUM, false>(pp, num_cu, st); }
     else return false;
     return true;
 }

@@ -22,7 +22,7 @@ struct rml_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm
+    hipEvent_t ev_proj[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};   // chunk pipeline of rml_project_svm (up to 3 workspaces)
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
     // optional CU partition (RML_GEMM_CUS=g): aux_stream is restricted to g CUs of every XCD and proj_stream to
     // the remaining 32-g, so the MFMA-bound GEMM and the HBM-bound projection stop fighting for wave slots/LDS
@@ -127,6 +127,9 @@ struct ProjOut {
     // should leave every CU the registers / LDS for one of its workgroups (k_project_wave: quarter-plane buffers, one
     // workgroup per CU) -- measured +5 % end to end on the Walabot grid against filling the CUs with projection waves
     int share_cu;
+    // the predicated (usually skipped) second pass of the fused pipeline: launch without the LDS pad of share_cu, so that its
+    // workgroups can start -- and exit at once -- on CUs whose LDS a resident projection workgroup of the next chunk holds
+    int no_pad;
 };
 
 // true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then

@@ -662,12 +662,13 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
 // I = a0 2^24 + a1 2^16 + a2 2^8 + a3 with a_i in [-128, 127].  Then  u_x . u_s = 2^-14 sum_{i,j} 2^-8(i+j) (a_i^x . a_j^s)
 // and every digit-plane product is an exact int32 GEMM (|.| <= 2^14 K < 2^29).  The ten pairs with i + j <= 3 are kept (the
 // dropped ones weigh 2^-46 per digit product: typical 1e-8 on u.u), grouped by g = i + j and accumulated from
-// the least significant group up IN THE SAME int32 accumulator: after g = 3 and g = 2 the accumulator is divided by 256 with
-// rounding, (acc + 128) >> 8, and the next group accumulates on top (4 x 2^28.3 < 2^31), which leaves R1 = G1 + G2/2^8 + G3/2^16.
+// the least significant group up IN THE SAME int32 accumulator: after g = 3 it is divided by 256 with rounding, (acc + 128) >> 8
+// (2^-31 on u.u), after g = 2 it is split R2 = 256 q + r -- q stays, R2 is parked -- and the next group accumulates on top
+// (4 x 2^28.3 < 2^31), which leaves R1 = G1 + floor(R2 / 2^8) and the remainder r for the epilogue.
 // The top group G0 needs its own 32 bits (u.u = 2^-14 (G0 + R1/256) is a 38-bit quantity): it is computed FIRST and parked in a
 // per-workgroup HBM scratch tile (256 KiB, written once, read once in the epilogue by the lane that wrote it: L2 traffic that
 // is nothing next to ten K loops) -- a second accumulator set or packed remainders in registers pushed the kernel over 256
-// VGPRs and the spills landed in the K loop.  u.u carries 2^-23 absolute precision on a quantity of magnitude <= D/4 -- the
+// VGPRs and the spills landed in the K loop.  u.u carries 2^-31 absolute precision on a quantity of magnitude <= D/4 -- the
 // arithmetic class of the float64 path at ~3x its rate.  d^2 = s^2 (||u_x||^2 + ||u_s||^2 - 2 u_x.u_s) with the norms of the QUANTISED
 // values in float64.  The K loop runs over (pair, K-step); the DMA cursors run one and two steps ahead across pair boundaries.
 // ------------------------------------------------------------------------------------------
@@ -691,7 +692,7 @@ struct RingArgs {
     const double* W;
     double gs; int kernel;
     double* partial; int64_t Npart;
-    int32_t* stash;                            // DIG: gridDim.x * 256 KiB of scratch for the top digit group
+    int32_t* stash;                            // DIG: gridDim.x * 2 * 256 KiB of scratch: the top digit group and the g = 2 level
 };
 
 // ring tile of block b: false = nothing to do
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     // DIG: the top group's accumulators are parked in this workgroup's scratch tile, 16 bytes per lane and store, coalesced
     v4i* stash = nullptr;
     if constexpr (DIG) {
-        stash = reinterpret_cast<v4i*>(a.stash) + (int64_t)blockIdx.x * (kDigStashBytes / 16) + tid;
+        stash = reinterpret_cast<v4i*>(a.stash) + (int64_t)blockIdx.x * (2 * kDigStashBytes / 16) + tid;
         segment(a.KT);                                 // pair 0: g = 0
         {
             v4i* sp = stash;                           // a running pointer: 32 hoisted 64-bit addresses would be spilled
@@ -882,17 +883,35 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
         // stores and DMA loads share the VM counter and may complete out of order with respect to each other: drain once, so
         // that the counted waits of the next segment see DMA instructions only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // groups g = 3 (pairs 1-4), g = 2 (5-7), g = 1 (8-9); after g = 3 and g = 2 the accumulator is divided by 256 with rounding
+        // groups g = 3 (pairs 1-4), g = 2 (5-7), g = 1 (8-9).  After g = 3 the accumulator is divided by 256 with rounding (2^-31
+        // on u.u); after g = 2 it is split R2 = 256 q + r: q stays and g = 1 accumulates on top, R2 itself is parked in the second
+        // scratch tile so that the epilogue puts the remainder r back -- no rounding at the 2^-23 level
 #pragma nounroll                                       // one copy of the step bodies for the three groups (instruction cache)
         for (int g = 0; g < 3; ++g) {
             segment((4 - g) * a.KT);
-            if (g < 2) {
+            if (g == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + 128) >> 8;
+            } else if (g == 1) {
+                v4i* sp = stash + kDigStashBytes / 16;   // second tile of this workgroup
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            v4i v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+                            *sp = v;
+                            sp += 512;
+                            asm volatile("" : "+v"(sp));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][4 * r4 + r] >>= 8;      // floor: the remainder comes back in the epilogue
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores and DMA loads share the VM counter (see above)
             }
         }
     } else {
@@ -926,6 +945,7 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const v4i g0 = *sp;
+                            const v4i r2 = *(sp + kDigStashBytes / 16);
                             sp += 512;
                             asm volatile("" : "+v"(sp));
 #pragma unroll
@@ -933,7 +953,8 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
                                 const int r = 4 * r4 + rr;
                                 const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
                                 const int nn = j * 32 + (lane & 31);
-                                gd[ml * 64 + nn] = ((double)g0[rr] * 256.0 + (double)acc[i][j][r]) * 0x1p-22;
+                                // 2^22 u.u = 256 G0 + (G1 + floor(R2 / 256)) + (R2 mod 256) / 256
+                                gd[ml * 64 + nn] = ((double)g0[rr] * 256.0 + (double)acc[i][j][r] + (double)(r2[rr] & 255) * 0x1p-8) * 0x1p-22;
                             }
                         }
             }
@@ -1027,6 +1048,188 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_svm_gemm_ring128<PT>: the ring schedule on the 128 x 128 tile, for the fused pipeline, where ONE GEMM workgroup per CU runs
+// beside a persistent projection workgroup.  There the two-stage 128 x 128 kernel is bound by the latency of a stage under the
+// projection's HBM stream (one workgroup per CU: nothing else covers it); the ring gives every stage 1 to 1.5 steps to land.
+// 4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 MFMA tiles; operand stage = 128 rows x 128 B = 16 KiB, 5 slots = 80 KiB (the
+// projection workgroup beside it keeps its own 34-66 KiB; it is kept from doubling up on a CU by registers, not by an LDS pad:
+// see ProjOut::share_cu).  Per step a wave issues 16 MFMAs and 8 DMA instructions (one after every two MFMAs), same rotation by
+// one MFMA group as k_svm_gemm_ring.  Epilogue and partial sums exactly as k_svm_gemm<I8> (bit-identical outputs).
+// ------------------------------------------------------------------------------------------
+constexpr int kOp128Bytes = kTile * kStepBytes;           // 16 KiB
+
+template <int PT>
+__global__ __launch_bounds__(256, 2) void k_svm_gemm_ring128(RingArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int ftile, stile;
+    if (!ring_tile(blockIdx.x, a.FT, a.ST, ftile, stile)) return;
+    if (a.tile_exact && a.tile_exact[ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kTile;
+    const int64_t m0 = (int64_t)stile * kTile;
+
+    const uint8_t* gsv[4];
+    const uint8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;          // 16-byte slot in the 16 KiB image
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    int aoff[2], asw[2], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int ra = wr * 64 + t * 32 + (lane & 31);
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+        boff[t] = rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int TT = a.KT;
+    int64_t ox = 0, os = 0;                            // K offsets of the next sample stage / SV stage to send
+    auto burst = [&](const uint8_t* const (&g)[4], int64_t off, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(g[q] + off, smem + slot * kOp128Bytes + wave * 4096 + q * 1024);
+    };
+    burst(gsv, 0, 0); burst(gx, 0, 1);                 // SV_0, X_0
+    os = kStepBytes; ox = kStepBytes;
+    if (TT > 1) { burst(gsv, os, 2); os += kStepBytes; }
+    int sa = 0, sx = 3, ss = 4, t = 0;
+    v4i af[2][2], bf[2][2];
+    auto mfma_half = [&](int set, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[half][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set][half], bf[set][j], acc[half][j], 0, 0, 0);
+    };
+    auto step = [&](auto first_) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_)::value;
+        const bool hx = t + 1 < TT, hs = t + 2 < TT;
+        if (hx) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
+        const unsigned char* pa = smem + sa * kOp128Bytes;
+        const unsigned char* pb = smem + sbx * kOp128Bytes;
+        sa = sa + 2 >= kRingSlots ? sa + 2 - kRingSlots : sa + 2;
+        unsigned char* dx = smem + sx * kOp128Bytes + wave * 4096;
+        unsigned char* dsv = smem + ss * kOp128Bytes + wave * 4096;
+        sx = sx + 2 >= kRingSlots ? sx + 2 - kRingSlots : sx + 2;
+        ss = ss + 2 >= kRingSlots ? ss + 2 - kRingSlots : ss + 2;
+        const int64_t offx = ox, offs = os;
+        auto reads = [&](int set, int kk) __attribute__((always_inline)) {
+            const int ch = 2 * kk + chalf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                af[set][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((ch ^ asw[u]) << 4));
+                bf[set][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((ch ^ bsw[u]) << 4));
+            }
+        };
+        auto dma = [&](int g) __attribute__((always_inline)) {
+            if (g < 4) { if (hx) glds16(gx[g] + offx, dx + g * 1024); }
+            else       { if (hs) glds16(gsv[g - 4] + offs, dsv + (g - 4) * 1024); }
+        };
+        reads(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int set = (r + 1) & 1;                // r = 0: the deferred kk = 3 of the previous step (set 1)
+            if (r >= 1) {
+                reads(r & 1, r);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (!(FIRST && r == 0)) mfma_half(set, half);
+                __builtin_amdgcn_sched_barrier(0);
+                dma(2 * r + half);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (hx) ox += kStepBytes;
+        if (hs) os += kStepBytes;
+        ++t;
+    };
+    step(std::true_type{});
+    for (int n = TT - 1; n > 0; --n) step(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(1, 0); mfma_half(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue of k_svm_gemm<I8>: G[128][128] int32 through slots 0-3, the per-SV table in slot 4 ----
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    double* svw = reinterpret_cast<double*>(smem + 4 * kOp128Bytes);
+    const double* etab = svw + kTile * (1 + PT);
+    __syncthreads();
+    exp_tab_init(svw + kTile * (1 + PT), tid);
+    for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
+    }
+    {
+        int* gl = reinterpret_cast<int*>(smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                    const int nn = wc * 64 + j * 32 + (lane & 31);
+                    gl[ml * kTile + nn] = acc[i][j][r];
+                }
+    }
+    __syncthreads();
+    const int nl = tid & 127, h = tid >> 7;
+    const int64_t n = f0 + nl;
+    const int64_t nc = n < a.N ? n : a.N - 1;
+    const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+    double S[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) S[p] = 0.0;
+    const int* gcol = reinterpret_cast<const int*>(smem) + nl;
+#pragma unroll 2
+    for (int mm = 0; mm < 64; ++mm) {
+        const int ml = h * 64 + mm;
+        const double* e = svw + ml * (1 + PT);
+        const double g = (double)gcol[ml * kTile];
+        double kv;
+        if (rbf) {
+            double d2 = xt + e[0] - 2.0 * g;
+            d2 = d2 > 0.0 ? d2 : 0.0;
+            kv = rml_exp_neg(-a.gs * d2, etab);
+        } else {
+            kv = (g + xt + e[0]) * a.gs;
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
+    }
+    __syncthreads();
+    double* xch = reinterpret_cast<double*>(smem);
+    if (h == 1) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) xch[nl * PT + p] = S[p];
+    }
+    __syncthreads();
+    if (h == 0 && n < a.N) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[p] + xch[nl * PT + p];
     }
 }
 
@@ -1415,6 +1618,31 @@ int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
     return RML_OK;
 }
 
+// the 128 x 128 tile with the ring schedule (k_svm_gemm_ring128): what the fused pipeline runs beside the projection
+int launch_gemm_ring128(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+    RingArgs ra{};
+    ra.sv = ga.sv; ra.x = ga.x; ra.ld_sv = ga.ld_sv; ra.ld_x = ga.ld_x; ra.KT = ga.KT;
+    ra.N = ga.N; ra.Mpad = ga.Mpad; ra.sv_rows = ga.sv_rows; ra.ST = ga.ST; ra.FT = ga.FT;
+    ra.tile_exact = ga.tile_exact; ra.want = ga.want; ra.x_isum = ga.x_isum; ra.x_isq = ga.x_isq;
+    ra.sv_term = ga.sv_term; ra.W = ga.W; ra.gs = ga.gs; ra.kernel = ga.kernel; ra.partial = ga.partial; ra.Npart = ga.Npart;
+    dim3 grid(ring_grid(ga.FT, ga.ST)), block(256);
+    const size_t lds = (size_t)kRingSlots * kOp128Bytes;
+#define RML_R128_CASE(PTV)                                                                                         \
+    case PTV: {                                                                                                    \
+        RML_MAX_DYN_LDS(160 * 1024, &k_svm_gemm_ring128<PTV>);                                                     \
+        hipLaunchKernelGGL((k_svm_gemm_ring128<PTV>), grid, block, lds, st, ra);                                   \
+    } break;
+    switch (m->PT) {
+        RML_R128_CASE(1)
+        RML_R128_CASE(3)
+        RML_R128_CASE(6)
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 128x128 ring kernel");
+    }
+#undef RML_R128_CASE
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     // RML_GEMM_RING (read per call: tests and A/B runs flip it): unset / 1 = k_svm_gemm_ring (5-slot operand-stage ring,
     // interleaved DMA issue), 0 = the two-stage kernel of round 2
@@ -1504,7 +1732,7 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     w.dig = (int8_t*)take(need_dig ? (size_t)4 * CH * m->Dq : 0);
     w.dnsq = (double*)take(need_dig ? (size_t)CH * 8 : 0);
     w.dflags = (int32_t*)take(need_dig ? (size_t)CH * 4 : 0);
-    w.stash = (int32_t*)take(need_dig ? (size_t)ring_grid((int)((CH + kBig - 1) / kBig), (int)((m->Mpad + kBig - 1) / kBig)) * kDigStashBytes : 0);
+    w.stash = (int32_t*)take(need_dig ? (size_t)ring_grid((int)((CH + kBig - 1) / kBig), (int)((m->Mpad + kBig - 1) / kBig)) * 2 * kDigStashBytes : 0);
     if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; w.stash = nullptr; }
     w.bytes = off;
     return w;
@@ -1558,7 +1786,11 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
-        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st));
+        // RML_GEMM_RING128 (read per call): 1 = the small tile with the ring schedule
+        const char* r128 = getenv("RML_GEMM_RING128");
+        const bool ring128 = !kmat && !big && m->PT <= 6 && r128 && atoi(r128) == 1;
+        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st)
+                      : (big ? launch_gemm_big(m, ga, st) : (ring128 ? launch_gemm_ring128(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st)));
         if (rc) return rc;
     }
     if (run_dig) {
@@ -1890,11 +2122,15 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
                        : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig);
+    // workspaces in rotation: 2 (projection of chunk c+1 beside the GEMM of chunk c); RML_NBUF=3 lets the projection run two
+    // chunks ahead (experiment knob: loosens the lock-step of the two streams when their per-chunk times are equal)
+    const char* nbe = getenv("RML_NBUF");
+    const int NBUF = (nbe && atoi(nbe) == 3) ? 3 : 2;
     void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, 2 * probe.bytes, &ws);
+    int rc = rml_ws_reserve(ctx, (size_t)NBUF * probe.bytes, &ws);
     if (rc) return rc;
-    ChunkWs w2[2] = {carve(m, CH, static_cast<unsigned char*>(ws), grid_ok, true, use_dig),
-                     carve(m, CH, static_cast<unsigned char*>(ws) + probe.bytes, grid_ok, true, use_dig)};
+    ChunkWs w2[3];
+    for (int i = 0; i < NBUF; ++i) w2[i] = carve(m, CH, static_cast<unsigned char*>(ws) + (size_t)i * probe.bytes, grid_ok, true, use_dig);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
     const int64_t frame_elems = (int64_t)X * Y * Z;
     hipStream_t aux = ctx->aux_stream;
@@ -1907,8 +2143,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     int64_t c = 0;
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
         const int64_t n = std::min(CH, B - r0);
-        const ChunkWs& w = w2[c & 1];
-        if (c >= 2) RML_HIP(hipStreamWaitEvent(st, ev_done[c & 1], 0));    // workspace reuse
+        const ChunkWs& w = w2[c % NBUF];
+        if (c >= NBUF) RML_HIP(hipStreamWaitEvent(st, ev_done[c % NBUF], 0));    // workspace reuse
         const int FT = (int)((n + kTile - 1) / kTile);
         ProjOut o{};
         int64_t off = 0;
@@ -1920,7 +2156,11 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
-        o.share_cu = part ? 0 : 1;
+        // share mode 2: one projection workgroup per CU by registers (its BALLAST variant) instead of an LDS pad -- what the
+        // 128 x 128 ring GEMM (80 KiB of LDS) needs to fit beside it.  Only the linear-plane kernel has that variant so far.
+        const char* r128 = getenv("RML_GEMM_RING128");
+        const bool share_regs = !part && r128 && atoi(r128) == 1 && vdtype == RML_VOL_F32 && Z == 176 && Y > 16 && Y <= 32;
+        o.share_cu = part ? 0 : (share_regs ? 2 : 1);
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // uint8 volumes are on the code grid by construction: one projection pass (codes + statistics), the exact GEMM on
@@ -1933,17 +2173,22 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             rml_prof_mark(ctx, st);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
-            RML_HIP(hipEventRecord(ev_proj[c & 1], st));
-            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
+            RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
+            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
             rml_prof_mark_gemm(ctx, aux);
             rc = run_chunk(ctx, m, RML_PATH_I8, n, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out.at(r0, m->C, m->P), aux,
                            /*tiles_done=*/true, nullptr, 0, /*all_exact_known=*/true, /*allow_big=*/!small_gemm);
             rml_prof_mark_gemm(ctx, aux);
             if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
             if (rc) return rc;
-            RML_HIP(hipEventRecord(ev_done[c & 1], aux));
+            RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
             continue;
         }
+        // With a model on the code grid the caller's stream carries NOTHING but the first projection pass of every chunk (codes
+        // + statistics): the tile decision, the predicated second pass (float rows for tiles that left the grid: a no-op
+        // otherwise) and the digit planes follow on the second stream, in front of the chunk's GEMMs.  (Round 2 had them between
+        // the projection launches: three launches and their gaps per chunk on the stream the step waits for.)
+        hipStream_t s2 = grid_ok ? aux : st;            // the stream of pass 2 and its followers
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
             rml_prof_mark(ctx, st);
@@ -1951,9 +2196,11 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             rml_prof_mark(ctx, st);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.all_exact, 1);
+            RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
+            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, aux, w.all_exact, 1);
             const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
-            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, st, w.flags, n, FT, 0, 1, w.tile_exact,
+            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, aux, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
         // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
@@ -1966,31 +2213,34 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             }
         of.sel = mask & RML_MASK_ALL;
         of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
-        of.share_cu = part ? 0 : 1;
+        of.share_cu = o.share_cu;
+        of.no_pad = grid_ok ? 1 : 0;
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
         if (!grid_ok) rml_prof_mark(ctx, st);
-        rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, of, st);
+        rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, of, s2);
         if (!grid_ok) { rml_prof_mark(ctx, st); if (ctx->profiling) ctx->prof_frames += n; }
         if (rc) return rc;
         if (use_dig) {
             // digit planes of the float rows (skipped with the float rows when every tile is exact); with an exact model the
             // general tiles are re-decided here, otherwise run_chunk decides
-            hipLaunchKernelGGL(k_digit_rows, dim3((unsigned)n), dim3(256), 0, st, w.f32, m->Df, m->D, m->Dq, w.dig_plane, w.dig, w.dnsq,
+            hipLaunchKernelGGL(k_digit_rows, dim3((unsigned)n), dim3(256), 0, s2, w.f32, m->Df, m->D, m->Dq, w.dig_plane, w.dig, w.dnsq,
                                w.dflags, m->dig_c0, 2147483648.0 / m->dig_s, of.skip_if_set);
             if (grid_ok)
-                hipLaunchKernelGGL(k_tile_dig, dim3((FT + 1) / 2), dim3(256), 0, st, w.dflags, n, FT, w.tile_exact, of.skip_if_set);
+                hipLaunchKernelGGL(k_tile_dig, dim3((FT + 1) / 2), dim3(256), 0, s2, w.dflags, n, FT, w.tile_exact, of.skip_if_set);
             RML_HIP(hipGetLastError());
         }
-        RML_HIP(hipEventRecord(ev_proj[c & 1], st));
-        RML_HIP(hipStreamWaitEvent(aux, ev_proj[c & 1], 0));
+        if (!grid_ok) {
+            RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
+            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
+        }
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
-        RML_HIP(hipEventRecord(ev_done[c & 1], aux));
+        RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
     }
     // join: the caller's stream continues after the last GEMMs
     RML_HIP(hipEventRecord(ctx->ev_join, aux));

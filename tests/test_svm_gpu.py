@@ -539,6 +539,14 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
         assert np.abs(got - ref).max() <= _tol(m, ref), big
         outs[big] = (got, svc.predict(X), rml.GpuCalibratedClassifier(svc).predict_proba(X))
     monkeypatch.delenv("RML_GEMM_RING")
+    # the 128 x 128 tile with the ring schedule (what the pipeline can run beside the projection): the same bits again
+    monkeypatch.setenv("RML_GEMM_BIG", "0")
+    monkeypatch.setenv("RML_GEMM_RING128", "1")
+    svc.decision_function_shape = "ovo"
+    got128 = svc.decision_function(X).reshape(len(X), -1)
+    np.testing.assert_array_equal(got128, outs["0"][0])
+    np.testing.assert_array_equal(rml.GpuCalibratedClassifier(svc).predict_proba(X), outs["0"][2])
+    monkeypatch.delenv("RML_GEMM_RING128")
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
     # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
     np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
