@@ -2144,7 +2144,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
         const int64_t n = std::min(CH, B - r0);
         const ChunkWs& w = w2[c % NBUF];
-        if (c >= NBUF) RML_HIP(hipStreamWaitEvent(st, ev_done[c % NBUF], 0));    // workspace reuse
+        hipStream_t sp = st;                            // the stream of this chunk's first projection pass
+        if (c >= NBUF) RML_HIP(hipStreamWaitEvent(sp, ev_done[c % NBUF], 0));    // workspace reuse
         const int FT = (int)((n + kTile - 1) / kTile);
         ProjOut o{};
         int64_t off = 0;
@@ -2191,12 +2192,12 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         hipStream_t s2 = grid_ok ? aux : st;            // the stream of pass 2 and its followers
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
-            rml_prof_mark(ctx, st);
-            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, st);
-            rml_prof_mark(ctx, st);
+            rml_prof_mark(ctx, sp);
+            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, sp);
+            rml_prof_mark(ctx, sp);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
-            RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
+            RML_HIP(hipEventRecord(ev_proj[c % NBUF], sp));
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, aux, w.all_exact, 1);
             const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
