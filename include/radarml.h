@@ -57,9 +57,15 @@ typedef struct rml_linear rml_linear;
                               NaN policy (a pinned deviation from SURVEY 8 a-1', which defines it "as NumPy"): np.max propagates a
                               NaN, this mode IGNORES it (IEEE maxNum: v_max_f32 / ds_max_f32), i.e. it equals np.fmax.reduce, and a
                               line of nothing but NaN gives -inf.  Radar magnitudes are integers 0..255 (common.py:30-31): the
-                              reference path never meets one; tests/test_projection_gpu.py pins the behaviour of every kernel */
+                              reference path never meets one; tests/test_projection_gpu.py pins the behaviour of every kernel.
+                              RML_MODE_MAX_NAN below is the NumPy-faithful variant */
 #define RML_MODE_SLICE 1   /* reference-faithful plane slices through (i,j,k): predict.py:102-107       */
 #define RML_MODE_SUM   2   /* sum-projection (the reductions of common.py:51-53), float32 accumulation  */
+#define RML_MODE_MAX_NAN 3 /* the max-projection with NumPy's NaN policy (SURVEY 8 a-1'): a line that holds a NaN gives NaN, like
+                              np.max.  Opt-in and not tuned: every shape runs on the general kernel (three passes over a frame, the
+                              second and third from L2); uint8 volumes cannot hold a NaN and take the RML_MODE_MAX kernels.  A row with
+                              a NaN is off the code grid, so the SVM front doors score it on the float64 path and its scores are NaN
+                              (scikit-learn raises ValueError on such a row instead) */
 
 /* element type of the volumes */
 #define RML_VOL_F32    0

@@ -85,10 +85,10 @@ SIGNATURES = {
                                   c_void_p]),
 }
 
-MODE_MAX, MODE_SLICE, MODE_SUM = 0, 1, 2
+MODE_MAX, MODE_SLICE, MODE_SUM, MODE_MAX_NAN = 0, 1, 2, 3
 AUG_ROTATE, AUG_ZOOM, AUG_NOISE = 0, 1, 2
 VOL_F32, VOL_U8 = 0, 1
-MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM}
+MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM, "max_nan": MODE_MAX_NAN}
 KERNEL_RBF, KERNEL_LINEAR = 0, 1
 PATH_AUTO, PATH_F32, PATH_I8, PATH_F64, PATH_DIGITS = 0, 1, 2, 3, 4
 PATHS = {"auto": PATH_AUTO, "f32": PATH_F32, "i8": PATH_I8, "f64": PATH_F64, "digits": PATH_DIGITS}

@@ -144,7 +144,8 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
 
     mode='slice': ``yz=V[i,:,:]``, ``xz=V[:,j,:]``, ``xy=V[:,:,k]`` per frame at ``ijk[b]``
     (predict.py:102-107, ground_truth_samples.py:413-419; negative indices wrap like
-    Python's).  mode='max': the max-projection named by BASELINE.json.  mode='sum': the
+    Python's).  mode='max': the max-projection named by BASELINE.json (a NaN is ignored, np.fmax);
+    mode='max_nan': the same with NumPy's NaN policy (np.max propagates; opt-in, general kernel).  mode='sum': the
     reductions of common.py:51-53.  ``volumes`` is (B,X,Y,Z) or (X,Y,Z); numpy in -> numpy
     out, torch CUDA in -> torch CUDA out.
     """

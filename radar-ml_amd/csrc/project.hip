@@ -246,6 +246,9 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
 // ------------------------------------------------------------------------------------------
 template <typename VT, int MODE, int NY, int G, bool PRED>
 __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_project_wave(ProjParams a) {
+#ifdef RML_PRIO_PROJ
+    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
+#endif
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     constexpr int NG = (NY + G - 1) / G;                // row groups per plane
     static_assert(NG == 1 || NG % 2 == 0, "the two row buffers must alternate statically");
@@ -483,6 +486,9 @@ __device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
 
 template <int NM, bool PRED>
 __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int CPR, int S) {
+#ifdef RML_PRIO_PROJ
+    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
+#endif
     extern __shared__ __align__(16) unsigned char lds8[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     const int X = a.X, Y = a.Y, Z = a.Z;
@@ -868,6 +874,11 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
     bool fast = false;
     if (mode == RML_MODE_MAX) launch_mode<VT, RML_MODE_MAX>(pp, num_cu, st, &fast);
     else if (mode == RML_MODE_SUM) launch_mode<VT, RML_MODE_SUM>(pp, num_cu, st, &fast);
+    else if (mode == RML_MODE_MAX_NAN) {
+        // NumPy's NaN policy, opt-in: bytes hold no NaN (same kernels as MAX); float volumes take the general kernel
+        if constexpr (sizeof(VT) == 1) launch_mode<VT, RML_MODE_MAX>(pp, num_cu, st, &fast);
+        else hipLaunchKernelGGL((k_project_generic<VT, RML_MODE_MAX_NAN>), dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
+    }
     else if (mode == RML_MODE_SLICE) {
         RML_REQUIRE(pp.ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
         hipLaunchKernelGGL(k_project_slice<VT>, dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
@@ -889,6 +900,7 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame) {
     if (B == 0) return RML_OK;
     RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project: unknown volume dtype %d", vdtype);
+    if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
     RML_REQUIRE(targets_per_frame == 1 || mode == RML_MODE_SLICE, RML_ERR_INVALID, "rml_project: several targets per frame only in mode SLICE");
     ProjParams pp;
     fill_params(pp, V, B, X, Y, Z, ijk, o);       // B counts output rows

@@ -22,6 +22,9 @@ using namespace rmlproj;
 // GEMM workgroup beside it needs half of the LDS itself (k_svm_gemm_ring128: 80 KiB), so that an LDS pad cannot do it.
 template <int MODE, int NI, int RG, int NGRP, bool PRED, bool BALLAST>
 __global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams a) {
+#ifdef RML_PRIO_PROJ
+    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
+#endif
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     float ballast[BALLAST ? 64 : 1];
     if constexpr (BALLAST) {

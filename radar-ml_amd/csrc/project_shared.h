@@ -37,6 +37,12 @@ template <> struct Op<RML_MODE_SUM> {
     }
 };
 
+// np.max: a NaN anywhere in the line is the result (the first one met; every NaN compares unequal to itself)
+template <> struct Op<RML_MODE_MAX_NAN> {
+    static __device__ __forceinline__ float ident() { return -INFINITY; }
+    static __device__ __forceinline__ float f(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+};
+
 template <int MODE> __device__ __forceinline__ float4 op4(float4 a, float4 b) {
     return make_float4(Op<MODE>::f(a.x, b.x), Op<MODE>::f(a.y, b.y), Op<MODE>::f(a.z, b.z), Op<MODE>::f(a.w, b.w));
 }

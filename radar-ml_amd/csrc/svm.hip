@@ -139,6 +139,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 template <int PATH, int PT, bool KM = false>
 __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
+#ifdef RML_PRIO_GEMM
+    __builtin_amdgcn_s_setprio(RML_PRIO_GEMM);      // experiment: issue priority of the GEMM waves beside the projection's
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -2085,6 +2088,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
                 (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
     RML_REQUIRE(mode != RML_MODE_SLICE || ijk, RML_ERR_INVALID, "rml_project_svm: mode SLICE needs ijk");
+    if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
     // the code grid of the features must be the model's: codes are the unscaled values
     const bool scaled = scale_div > 1.0f;
     const bool grid_ok = m->exact && ((scaled && (double)scale_div == m->code_scale) || (!scaled && m->code_scale == 1.0));
@@ -2116,7 +2120,12 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
     // rows off the code grid: the multi-digit int8 kernel (256 x 256 tiles: chunks sized for whole rounds) where the model has a
     // digit frame and the batch is large enough, the float64 MFMA kernel otherwise
-    const bool use_dig = vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
+    // Only for models off the code grid: with a grid model the rows off the grid are the exception, and the digit kernel's
+    // predicated launch -- a whole CU's LDS per workgroup even when it exits at once -- cannot start beside the resident projection
+    // and GEMM workgroups: on the GEMM stream it waited for the end of the running projection launch, chunk after chunk
+    // (profiles/r03_stats_walabot_f32.txt of session r3o: 224 launches of k_svm_gemm_ring<3,1>, up to 325 us each)
+    static const bool pipe_dig_always = [] { const char* e = getenv("RML_PIPE_DIGITS"); return e && atoi(e) == 1; }();      // A/B knob: round-3 state before r3o
+    const bool use_dig = (!grid_ok || pipe_dig_always) && vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
     const int64_t CH = part ? std::min<int64_t>(round_up(B, kTile), pick_chunk_env(small_chunk))       // short chunks: the last chunk's GEMM is exposed
                        : (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
                        : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)

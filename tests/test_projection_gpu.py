@@ -483,6 +483,35 @@ def test_nan_policy_of_the_max_projection_is_pinned(rml, shape):
     assert got[1][1, 0, 0] == -np.inf
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 9), (7, 37, 160)])
+def test_max_nan_mode_has_numpys_nan_policy(rml, shape):
+    """RML_MODE_MAX_NAN (include/radarml.h; SURVEY 8 a-1' defines the policy "as NumPy"): np.max bit for bit, NaN positions
+    included -- through ``project``, through ``process_volumes`` (scaled rows) and, for uint8 volumes (no NaN possible),
+    identical to mode 'max'."""
+    X, Y, Z = shape
+    rng = np.random.default_rng(19)
+    B = 3
+    v = (rng.standard_normal((B, X, Y, Z)) * 20).astype(np.float32)
+    v[rng.random(v.shape) < 0.01] = np.nan
+    v[1, :, 0, 0] = np.nan
+    v[2] = np.abs(np.nan_to_num(v[2]))                 # one frame without any NaN
+    got = rml.project(v, mode="max_nan")
+    with np.errstate(invalid="ignore"):
+        want = O.project_max(v)                        # np.max: propagates
+    for g, w in zip(got, want):
+        assert np.isnan(w).any() and not np.isnan(w[2]).any()
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(w))
+        np.testing.assert_array_equal(np.nan_to_num(g, nan=-1e30), np.nan_to_num(w, nan=-1e30))
+    rows = rml.process_volumes(v, mode="max_nan", scale=True)
+    with np.errstate(invalid="ignore"):
+        ref = np.stack([np.concatenate([(w[b] / np.float32(255.0)).ravel() for w in want]) for b in range(B)])
+    np.testing.assert_array_equal(np.isnan(rows), np.isnan(ref))
+    np.testing.assert_array_equal(np.nan_to_num(rows, nan=-1e30), np.nan_to_num(ref.astype(np.float32), nan=-1e30))
+    v8 = rng.integers(0, 256, size=(B, X, Y, Z), dtype=np.uint8)
+    for a, b in zip(rml.project(v8, mode="max_nan"), rml.project(v8, mode="max")):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_augmentation_kernels_match_the_reference_data_generator(rml):
     """csrc/augment.hip (rotate / clipped zoom / sparse noise, train.py:84-185) against train.DataGenerator itself: first the
     kernels on the draws the reference made (recorded by make_golden.py), then the Python mirror ``rml.DataGenerator`` seeded
