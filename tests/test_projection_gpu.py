@@ -502,7 +502,7 @@ def test_max_nan_mode_has_numpys_nan_policy(rml, shape):
         assert np.isnan(w).any() and not np.isnan(w[2]).any()
         np.testing.assert_array_equal(np.isnan(g), np.isnan(w))
         np.testing.assert_array_equal(np.nan_to_num(g, nan=-1e30), np.nan_to_num(w, nan=-1e30))
-    rows = rml.process_volumes(v, mode="max_nan", scale=True)
+    rows = rml.process_volumes(v, mode="max_nan", scale=True).cpu().numpy()
     with np.errstate(invalid="ignore"):
         ref = np.stack([np.concatenate([(w[b] / np.float32(255.0)).ravel() for w in want]) for b in range(B)])
     np.testing.assert_array_equal(np.isnan(rows), np.isnan(ref))
