@@ -461,193 +461,6 @@ bool try_launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// uint8 volumes, mode MAX: the byte-native path.  Widening every voxel to float (the path above) is VALU-bound at a
-// third of the HBM rate once the volume is 1 byte per voxel, so here the data stays packed: a lane loads 16
-// voxels of a row (uint4), splits every dword once into its even and odd bytes as 16-bit pairs (v_perm_b32) and all
-// maxima are v_pk_max_u16 on those pairs -- 2 voxels per instruction.
-//   * wave w owns the planes i = w, w+4, ...; lane = (row slot s, 16-byte chunk c), rows j = s + S*m.
-//   * yz (max over i) accumulates in registers per wave and the 4 wave partials meet in LDS once per frame;
-//   * xz (max over j) is combined in-lane over m, then across the row slots with ds_bpermute -- a plane belongs to
-//     one wave, so there are no LDS atomics at all;
-//   * xy (max over z) is reduced in-lane to one 16-bit value per row, two rows share a dword through the
-//     cross-lane steps over the chunks of a row.
-// Projections are staged in LDS as bytes and leave through the same Emitter as every other path (scaled float rows,
-// biased codes, statistics).  Invalid rows / idle lanes re-read a valid neighbour: a duplicate is harmless for max.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pkmax_u16(uint32_t a, uint32_t b) {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    u16x2 x = *reinterpret_cast<u16x2*>(&a), y = *reinterpret_cast<u16x2*>(&b);
-    u16x2 r = __builtin_elementwise_max(x, y);
-    return *reinterpret_cast<uint32_t*>(&r);
-}
-__device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
-    return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
-}
-
-template <int NM, bool PRED>
-__global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int CPR, int S) {
-#ifdef RML_PRIO_PROJ
-    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
-#endif
-    extern __shared__ __align__(16) unsigned char lds8[];
-    if constexpr (PRED) { if (*a.o.skip_if_set) return; }
-    const int X = a.X, Y = a.Y, Z = a.Z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = lane / CPR, c = lane - s * CPR;
-    const int64_t b = blockIdx.x;
-    // LDS: yz [4 waves][Y][Z], xz [X][Z], xy [X*Y] (dense).  The reduction scratch of Emitter::finish lies over yz
-    // (finish synchronises before it writes): two of these workgroups and one k_svm_gemm workgroup (69.6 KB) then
-    // fit a CU together at 64x64x128, which is what lets the fused pipeline overlap them.
-    unsigned char* yz_s = lds8;
-    unsigned char* xz_s = yz_s + (size_t)4 * Y * Z;
-    unsigned char* xy_s = xz_s + (size_t)X * Z;
-    int64_t* red = reinterpret_cast<int64_t*>(lds8);
-    const uint4* __restrict__ Vb = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(a.V) + b * (int64_t)X * Y * Z);
-    const int plane = Y * CPR;          // uint4 per x-plane
-
-    int roff[NM];
-    bool rv[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int j = s + S * m;
-        rv[m] = (s < S) && (j < Y);
-        roff[m] = min(j, Y - 1) * CPR + c;
-    }
-    // cross-lane sources (byte addresses for ds_bpermute); an invalid source is the lane itself (max(x,x) = x)
-    int xsrc[6], ysrc[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        const int ox = CPR << t, oy = 1 << t;
-        xsrc[t] = ((lane + ox < 64) ? lane + ox : lane) << 2;
-        ysrc[t] = ((c + oy < CPR) ? lane + oy : lane) << 2;
-    }
-    int nslots = (64 + CPR - 1) / CPR, xsteps = 0, ysteps = 0;
-    while ((1 << xsteps) < nslots) ++xsteps;
-    while ((1 << ysteps) < CPR) ++ysteps;
-
-    uint32_t yz[NM][8];
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) yz[m][k] = 0u;
-
-    for (int i = wave; i < X; i += 4) {
-        const uint4* __restrict__ Vi = Vb + (int64_t)i * plane;
-        uint4 cur[NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-            const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(Vi + roff[m]));
-            cur[m] = make_uint4(v.x, v.y, v.z, v.w);
-        }
-        uint32_t xz[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xz[k] = 0u;
-        uint32_t rowmax[NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const uint32_t w[4] = {cur[m].x, cur[m].y, cur[m].z, cur[m].w};
-            uint32_t h[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                h[2 * q] = __builtin_amdgcn_perm(w[q], w[q], 0x0c020c00u);          // bytes 0 and 2 as 16-bit values
-                h[2 * q + 1] = __builtin_amdgcn_perm(w[q], w[q], 0x0c030c01u);      // bytes 1 and 3
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                yz[m][k] = pkmax_u16(yz[m][k], h[k]);
-                xz[k] = pkmax_u16(xz[k], h[k]);
-            }
-            const uint32_t t0 = pkmax_u16(pkmax_u16(h[0], h[1]), pkmax_u16(h[2], h[3]));
-            const uint32_t t1 = pkmax_u16(pkmax_u16(h[4], h[5]), pkmax_u16(h[6], h[7]));
-            const uint32_t u = pkmax_u16(t0, t1);
-            rowmax[m] = max(u & 0xFFFFu, u >> 16);
-        }
-        // xy: rows m and m+1 share a dword through the reduction over the chunks of a row
-#pragma unroll
-        for (int m = 0; m < NM; m += 2) {
-            uint32_t rp = rowmax[m] | ((m + 1 < NM ? rowmax[m + 1] : 0u) << 16);
-            for (int t = 0; t < ysteps; ++t) rp = pkmax_u16(rp, (uint32_t)__builtin_amdgcn_ds_bpermute(ysrc[t], (int)rp));
-            if (c == 0) {
-                if (rv[m]) xy_s[i * Y + s + S * m] = (unsigned char)(rp & 0xFFu);
-                if (m + 1 < NM && rv[m + 1]) xy_s[i * Y + s + S * (m + 1)] = (unsigned char)(rp >> 16);
-            }
-        }
-        // xz: across the row slots of the wave
-        for (int t = 0; t < xsteps; ++t) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xz[k] = pkmax_u16(xz[k], (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc[t], (int)xz[k]));
-        }
-        if (s == 0)
-            *reinterpret_cast<uint4*>(xz_s + (size_t)i * Z + 16 * c) =
-                make_uint4(xz[0] | (xz[1] << 8), xz[2] | (xz[3] << 8), xz[4] | (xz[5] << 8), xz[6] | (xz[7] << 8));
-    }
-    // the wave's yz partial
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-        if (rv[m])
-            *reinterpret_cast<uint4*>(yz_s + ((size_t)wave * Y + s + S * m) * Z + 16 * c) =
-                make_uint4(yz[m][0] | (yz[m][1] << 8), yz[m][2] | (yz[m][3] << 8), yz[m][4] | (yz[m][5] << 8), yz[m][6] | (yz[m][7] << 8));
-    __syncthreads();
-
-    Emitter em(a, b);
-    const int nxz4 = (X * Z) >> 2;
-    for (int idx = tid; idx < nxz4; idx += kThreads)
-        em.put4(0, (int64_t)idx * 4, bytes_to_float4(*reinterpret_cast<const uint32_t*>(xz_s + idx * 4)));
-    const int nyz4 = (Y * Z) >> 2;
-    const int nw = X < 4 ? X : 4;       // waves that saw a plane
-    for (int idx = tid; idx < nyz4; idx += kThreads) {
-        uint32_t lo = 0u, hi = 0u;
-        for (int w = 0; w < nw; ++w) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(yz_s + (size_t)w * Y * Z + idx * 4);
-            lo = pkmax_u16(lo, v & 0x00FF00FFu);
-            hi = pkmax_u16(hi, (v >> 8) & 0x00FF00FFu);
-        }
-        em.put4(1, (int64_t)idx * 4, bytes_to_float4(lo | (hi << 8)));
-    }
-    const int nxy = X * Y, nxy4 = nxy >> 2;
-    for (int idx = tid; idx < nxy4; idx += kThreads)
-        em.put4(2, (int64_t)idx * 4, bytes_to_float4(*reinterpret_cast<const uint32_t*>(xy_s + idx * 4)));
-    for (int idx = nxy4 * 4 + tid; idx < nxy; idx += kThreads) em.put1(2, idx, (float)xy_s[idx]);
-    em.finish(red);
-}
-
-template <int NM>
-void launch_u8_max(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hipStream_t st) {
-    dim3 grid((unsigned)pp.B), block(kThreads);
-    if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(160 * 1024, &k_project_u8_max<NM, true>);
-        hipLaunchKernelGGL((k_project_u8_max<NM, true>), grid, block, lds_bytes, st, pp, CPR, S);
-    } else {
-        RML_MAX_DYN_LDS(160 * 1024, &k_project_u8_max<NM, false>);
-        hipLaunchKernelGGL((k_project_u8_max<NM, false>), grid, block, lds_bytes, st, pp, CPR, S);
-    }
-}
-
-// returns true when the byte-native kernel took the launch
-bool try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
-    static const bool allow = [] { const char* e = getenv("RML_U8_NATIVE"); return !e || atoi(e) != 0; }();
-    const int X = pp.X, Y = pp.Y, Z = pp.Z;
-    if (!allow || Z % 16 != 0 || Z / 16 > 64 || (reinterpret_cast<uintptr_t>(pp.V) & 15) != 0) return false;
-    const int CPR = Z / 16, S = 64 / CPR;
-    const int nm = (Y + S - 1) / S;
-    size_t lds_bytes = (size_t)X * Z + (((size_t)X * Y + 15) & ~(size_t)15) + (size_t)4 * Y * Z;
-    if (lds_bytes < 64 * 8 + 64) lds_bytes = 64 * 8 + 64;      // Emitter::finish scratch
-    if (nm > 8 || lds_bytes > 150 * 1024) return false;
-    switch (nm) {       // rows per lane and plane: exact, so that no lane re-reads rows it does not need
-        case 1: launch_u8_max<1>(pp, CPR, S, lds_bytes, st); break;
-        case 2: launch_u8_max<2>(pp, CPR, S, lds_bytes, st); break;
-        case 3: launch_u8_max<3>(pp, CPR, S, lds_bytes, st); break;
-        case 4: launch_u8_max<4>(pp, CPR, S, lds_bytes, st); break;
-        case 5: launch_u8_max<5>(pp, CPR, S, lds_bytes, st); break;
-        case 6: launch_u8_max<6>(pp, CPR, S, lds_bytes, st); break;
-        case 7: launch_u8_max<7>(pp, CPR, S, lds_bytes, st); break;
-        default: launch_u8_max<8>(pp, CPR, S, lds_bytes, st); break;
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------
 // Generic fallback: any (X,Y,Z).  Three coalesced passes over the frame (L2 resident after
 // the first), no shape restrictions.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------

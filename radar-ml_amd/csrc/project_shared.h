@@ -47,6 +47,10 @@ template <int MODE> __device__ __forceinline__ float4 op4(float4 a, float4 b) {
     return make_float4(Op<MODE>::f(a.x, b.x), Op<MODE>::f(a.y, b.y), Op<MODE>::f(a.z, b.z), Op<MODE>::f(a.w, b.w));
 }
 
+__device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
+    return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
+}
+
 // Per-thread sink for finished projection values: scaled float store, uint8 code store and
 // the row statistics of the exact-integer SVM path.
 struct Emitter {
@@ -89,6 +93,17 @@ struct Emitter {
         if (want_stats) {
             uint32_t c = code(v);
             if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)c;
+        }
+    }
+    // four projection values that ARE bytes (uint8 volumes; idx a multiple of 4): when only codes and their statistics are
+    // wanted the bytes are the codes -- biased with one xor, summed and squared with v_dot4_u32_u8 -- and nothing is widened
+    __device__ __forceinline__ void put_bytes4(int pl, int64_t idx, uint32_t w) {
+        if (!((a.o.sel >> pl) & 1u)) return;
+        if (a.o.p[pl] || a.o.row_nsq) { put4(pl, idx, bytes_to_float4(w)); return; }
+        if (want_stats) {
+            isum += (int32_t)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+            isq = __builtin_amdgcn_udot4(w, w, isq, false);
+            if (a.o.q[pl]) *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = w ^ 0x80808080u;
         }
     }
     // idx is a multiple of 4
@@ -267,5 +282,8 @@ template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b
 // project_lin.hip: the linear-plane wave-per-frame kernel for rows that do not fill a load instruction (32 < Z/4 < 64); returns
 // true when it took the launch
 bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st);
+
+// project_u8.hip: the byte-native max-projection of uint8 volumes (rows of whole 16-byte chunks); true when it took the launch
+bool try_launch_u8_max(const ProjParams& pp, hipStream_t st);
 
 }  // namespace rmlproj

@@ -2104,17 +2104,18 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
     const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
-    // Byte volumes (k_project_u8_max, two workgroups per CU) take the 128x128 GEMM and the small chunks as well: its
-    // workgroups fit beside the projection's, the 256x256 kernel's time-slice the CUs with them and three chunks per 65 536
-    // frames leave the pipeline mostly filling and draining (64x64x128 uint8, same box: 6.0 -> 6.7-7.1 M frames/s).
-    // RML_PIPE_GEMM (experiment knob): 1 = the 256x256 ring kernel in whole-round chunks for the byte volumes as well.
+    // Byte volumes (k_project_u8_max): the GEMM is a third of the step there, and since the projection's cross-lane steps left the
+    // LDS pipe (round 3: 0.59 -> 0.71 of 8 TB/s alone) each kernel is worth more alone than beside the other: the 256x256 ring
+    // kernel in whole-round chunks, the projection between its rounds (64x64x128 uint8, same box: 6.5-6.9 -> 7.4-7.5 M frames/s;
+    // Walabot grid 17.9-18.0 -> 18.4).  RML_PIPE_GEMM=0: the round-2 pairing (128x128 GEMM workgroups beside two projection
+    // workgroups per CU, 8 192-frame chunks).
     // CU partition (RML_GEMM_CUS=g at context creation): the GEMM owns g CUs of every XCD (aux stream), the projection the other
     // 32 - g (masked projection stream) -- nothing shares a CU, so the projection runs in its stand-alone configuration and the
     // GEMM is the ring kernel, its chunks sized for whole rounds of ITS CUs
     const bool part = ctx->gemm_cus_per_xcd > 0 && ctx->proj_stream != nullptr;
     const int gemm_cus = part ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
     const char* pge = getenv("RML_PIPE_GEMM");
-    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && !(pge && atoi(pge) == 1)));
+    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && pge && atoi(pge) == 0));
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;

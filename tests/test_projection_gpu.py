@@ -371,6 +371,43 @@ def test_reference_generated_data_rows(rml):
         np.testing.assert_array_equal(got, O.features_from_projections(g["xz"], g["yz"], g["xy"], (True, True, True), bool(sc)))
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 128), (10, 20, 128), (3, 5, 128), (5, 31, 256), (3, 7, 256), (22, 31, 176), (4, 9, 64)])
+def test_uint8_byte_kernel_lane_layouts_and_codes_only_output(rml, shape):
+    """k_project_u8_max per lane layout: rows of 128 / 256 voxels take the cross-lane steps on the VALU (v_permlane32_swap /
+    v_permlane16_swap reduce-scatter, DPP moves), every other row length the ds_bpermute steps; and per output form: float rows
+    (values widened through the Emitter) and the fused pipeline's codes-only first pass (bytes biased with one xor, statistics
+    from v_dot4_u32_u8) -- both against NumPy on the same values, bit for bit."""
+    import torch
+    from radar_ml_amd import _lib
+    X, Y, Z = shape
+    rng = np.random.default_rng(X * 1000 + Z)
+    B = 5
+    v8 = rng.integers(0, 256, (B, X, Y, Z)).astype(np.uint8)
+    v8[1][rng.random((X, Y, Z)) < 0.9] = 0                       # a sparse frame: ties and all-zero lines
+    v8[2] = 255
+    vf = v8.astype(np.float32)
+    want = O.project_max(vf)
+    for g, w in zip(rml.project(v8, mode="max"), want):
+        np.testing.assert_array_equal(g, w)
+    rows = O.features_from_projections(*want, (True, True, True), False)
+    D = rows.shape[1]
+    dev = torch.device("cuda", 0)
+    lib = _lib.load(); ctx = _lib.context(dev)
+    V = torch.from_numpy(v8).to(dev)
+    ldq = (D + 127) // 128 * 128
+    q = torch.full((B, ldq), 7, dtype=torch.uint8, device=dev)
+    isum = torch.empty(B, dtype=torch.int32, device=dev); isq = torch.empty(B, dtype=torch.int64, device=dev)
+    flags = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.rml_project(ctx, V.data_ptr(), 1, B, X, Y, Z, 0, None, 255.0, 7, None, 0, q.data_ptr(), ldq,
+                               isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "rml_project")
+    torch.cuda.synchronize()
+    codes = (q[:, :D].cpu().numpy() ^ 0x80).astype(np.int64)
+    np.testing.assert_array_equal(codes, rows.astype(np.int64))
+    assert int(q[:, D:].to(torch.int32).sum()) == 0 and bool((flags == 1).all())
+    np.testing.assert_array_equal(isum.cpu().numpy(), codes.sum(axis=1))
+    np.testing.assert_array_equal(isq.cpu().numpy(), (codes * codes).sum(axis=1))
+
+
 def test_uint8_random_shapes_property(rml):
     """Property test for the uint8 ingest over random grids (byte-native kernel when Z % 16 == 0, widening kernels
     otherwise; 1..8 rows per lane): max / sum / slice projections and the code rows equal NumPy's on the same values."""
