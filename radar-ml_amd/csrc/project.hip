@@ -604,11 +604,14 @@ void launch_fast_pred(const ProjParams& pp, size_t lds_bytes, hipStream_t st) {
 template <typename VT, int MODE, int LPR>
 int launch_fast_nm(const ProjParams& pp, int nm, size_t lds_bytes, hipStream_t st) {
     constexpr int NSLOT = 4 * (64 / LPR);
-    if (nm > 8) return 1;
-    const int NMr = nm <= 4 ? 4 : 8;
+    // up to 8 rows per lane and plane; 16 for the long rows (LPR = 64: planes of 33..64 rows of 129..256 voxels, e.g. 64x64x256,
+    // which otherwise fell to the general kernel at 0.04 of 8 TB/s)
+    if (nm > (LPR == 64 ? 16 : 8)) return 1;
+    const int NMr = nm <= 4 ? 4 : (nm <= 8 ? 8 : 16);
     const bool full = (pp.ZQ == LPR) && (pp.Y == NMr * NSLOT);
     if (NMr == 4) { if (full) launch_fast_pred<VT, MODE, LPR, 4, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 4, false>(pp, lds_bytes, st); }
-    else          { if (full) launch_fast_pred<VT, MODE, LPR, 8, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 8, false>(pp, lds_bytes, st); }
+    else if (NMr == 8) { if (full) launch_fast_pred<VT, MODE, LPR, 8, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 8, false>(pp, lds_bytes, st); }
+    else if constexpr (LPR == 64) { if (full) launch_fast_pred<VT, MODE, LPR, 16, true>(pp, lds_bytes, st); else launch_fast_pred<VT, MODE, LPR, 16, false>(pp, lds_bytes, st); }
     return 0;
 }
 

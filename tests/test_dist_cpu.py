@@ -108,3 +108,34 @@ def test_bench_sgan_leg_runs_data_parallel_on_two_gloo_ranks():
     row = res[0]
     assert row["n_gpus"] == 2 and row["global_batch"] == 12 and row["replicas_identical"] is True
     assert row["value"] > 0 and "all-reduce" in row["parallelism"]
+
+
+def test_bench_helpers_resolve_every_name_they_call():
+    """tools/bench_support.py is only exercised on the GPU box (cpu_baseline / roofline.traffic legs of bench.py); a missing helper
+    there turns into an ``error`` field of the JSON line instead of a failure.  Check statically that every module-level function
+    a helper calls exists (round 3 lost two of them to an editing accident and the bench line lost its CPU baseline)."""
+    import ast
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("tools/bench_support.py", "bench.py"):
+        src = open(os.path.join(root, rel)).read()
+        tree = ast.parse(src)
+        defined = {n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+        imported = set()
+        for n in ast.walk(tree):
+            if isinstance(n, ast.Import):
+                imported |= {(a.asname or a.name).split(".")[0] for a in n.names}
+            elif isinstance(n, ast.ImportFrom):
+                imported |= {a.asname or a.name for a in n.names}
+        import builtins
+        known = defined | imported | set(dir(builtins))
+        for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+            local = {a.arg for a in fn.args.args + fn.args.kwonlyargs} | {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
+            local |= {n.name for n in ast.walk(fn) if isinstance(n, (ast.FunctionDef, ast.Lambda)) and hasattr(n, "name")}
+            local |= {a.arg for n in ast.walk(fn) if isinstance(n, (ast.FunctionDef, ast.Lambda)) for a in n.args.args}
+            for call in [n for n in ast.walk(fn) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)]:
+                assert call.func.id in known | local, "%s: %s() calls undefined %s()" % (rel, fn.name, call.func.id)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_support
+    for name in ("reference_libs_baseline", "reference_libs_process_pool", "measure_traffic"):
+        assert callable(getattr(bench_support, name))

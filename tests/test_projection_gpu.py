@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 9), (3, 70, 24), (2, 3, 260), (16, 16, 64), (9, 130, 32),
           (7, 37, 160), (5, 33, 48), (4, 9, 48), (3, 100, 176),      # row-group kernel shapes (Z/4 not a power of two)
-          (4, 8, 132), (6, 16, 256), (3, 20, 180), (2, 32, 176), (5, 31, 176), (1, 24, 200)]   # wave-per-frame kernel
+          (4, 8, 132), (6, 16, 256), (3, 20, 180), (2, 32, 176), (5, 31, 176), (1, 24, 200),   # wave-per-frame kernel
+          (6, 64, 256), (3, 41, 200), (2, 50, 132)]                       # 9..16 rows per lane of the long-row fast kernel
 
 
 def _vol(seed, B, X, Y, Z, integer=True):

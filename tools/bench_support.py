@@ -160,3 +160,136 @@ def reference_libs_baseline(vh, model, gpu_label_idx, threads, budget_s=25.0, wa
     return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "reference-libs",
             "sample": "%d of the same synthetic frames on %d threads in %.1f s (the process pool could not be run): %s" % (done, threads, dt2, what),
             "label_mismatch_vs_gpu": mism2, "note": note, "single_process": single, "thread_pool": thread_pool}
+
+
+def reference_libs_process_pool(vh, model, gpu_label_idx, workers, budget_s=12.0, ready_timeout_s=90.0):
+    """All host cores the honest way: one PROCESS per core (NumPy ``max`` and ``ndimage.zoom`` hold the GIL, so a thread pool
+    measures the interpreter lock, not the machine), each running the reference path on its own slice of the frames.
+    Frames and the float64 SV matrix sit once in /dev/shm (memory-mapped by the workers: one copy for all of them); the workers
+    import their libraries and build the scikit-learn object first, report ready, and start together when the parent says
+    go; the rate is (frames done by all) / (latest end - earliest start).  Returns the object or None when the pool could
+    not be run."""
+    import tempfile
+    classes = np.asarray(model["classes"])
+    n = int(len(vh))
+    workers = int(max(1, min(workers, n // 4 if n >= 4 else 1)))
+    d = tempfile.mkdtemp(prefix="rml_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    procs = []
+    try:
+        np.save(os.path.join(d, "frames.npy"), np.ascontiguousarray(vh))
+        np.save(os.path.join(d, "sv_f64.npy"), (np.asarray(model["sv_u8"]).astype(np.float32) / np.float32(255.0)).astype(np.float64))
+        for k in ("dual_coef", "intercept", "n_support", "calib_a", "calib_b", "classes"):
+            np.save(os.path.join(d, k + ".npy"), np.ascontiguousarray(model[k]))
+        np.save(os.path.join(d, "gamma.npy"), np.float64(model["gamma"]))
+        per = (n + workers - 1) // workers
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        for w in range(workers):
+            lo, hi = w * per, min(n, (w + 1) * per)
+            if lo >= hi:
+                break
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_worker.py"), d, str(w), str(lo), str(hi), str(budget_s)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd="/tmp"))
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(d, "ready_%d" % w)) for w in range(len(procs))) < len(procs):
+            if time.time() - t_wait > ready_timeout_s or any(p.poll() not in (None, 0) for p in procs):
+                return None
+            time.sleep(0.05)
+        with open(os.path.join(d, "go.tmp"), "w") as f:
+            f.write(repr(time.time() + 0.5))
+        os.replace(os.path.join(d, "go.tmp"), os.path.join(d, "go"))
+        outs = []
+        deadline = time.time() + budget_s + 60.0
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                return None
+            if p.returncode != 0:
+                return None
+            outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+    except Exception:
+        return None
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+    done = sum(o["done"] for o in outs)
+    span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
+    mism = 0
+    for o in outs:
+        lab = np.asarray(o["labels"], dtype=np.int64)
+        mism += int((lab != classes[gpu_label_idx[o["lo"]:o["lo"] + len(lab)]]).sum())
+    return {"value": round(done / span, 2) if span > 0 else 0.0, "unit": "frames/s", "cores": len(outs), "frames": int(done),
+            "seconds": round(span, 2), "start_skew_s": round(max(o["t0"] for o in outs) - min(o["t0"] for o in outs), 3),
+            "label_mismatch_vs_gpu": mism}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the projection launches from this run's own counters
+# ------------------------------------------------------------------------------------------------------------------
+def _find_db(d):
+    hits = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True) + glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return hits[0] if hits else None
+
+
+def _read_counter(db, counter):
+    """[(kernel_name, value, duration_ns)] in dispatch order"""
+    c = sqlite3.connect(db)
+    cur = c.execute("select * from counters_collection limit 1")
+    cols = [d[0] for d in cur.description]
+    order = next((k for k in ("dispatch_id", "start", "start_timestamp", "timestamp", "id") if k in cols), None)
+    q = "select kernel_name, value, duration from counters_collection where counter_name=?" + (" order by %s" % order if order else "")
+    return c.execute(q, (counter,)).fetchall()
+
+
+def measure_traffic(configs, timeout_s=240):
+    """configs: [{"tag", "grid": [X,Y,Z], "frames", "u8": bool}].  Returns {tag: {"hbm_bytes", "fetch_bytes",
+    "write_bytes", "kernel", "dispatches"}} or None.  One child process per counter runs every configuration."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = os.path.join(ROOT, "tools", "pmc_child.py")
+    spec = json.dumps(configs)
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="rml_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RML_WAVE_SHARE="1")      # the child launches the kernel configuration of the fused pipeline
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "k", "--", sys.executable, child, spec]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except Exception:
+                return None
+            if r.returncode != 0:
+                return None
+            order = None
+            for line in r.stdout.decode(errors="replace").splitlines():
+                if line.startswith("PMC_CHILD_ORDER "):
+                    order = json.loads(line[len("PMC_CHILD_ORDER "):])
+            db = _find_db(out)
+            if db is None or order is None:
+                return None
+            rows = [x for x in _read_counter(db, counter) if "k_project" in x[0]]
+            # the child launches every configuration `reps` times in order and nothing else that is called k_project*
+            reps = order["reps"]
+            if len(rows) != reps * len(order["tags"]):
+                return None
+            for i, tag in enumerate(order["tags"]):
+                mine = rows[i * reps:(i + 1) * reps][1:]          # first launch of a configuration = warm-up
+                got.setdefault(tag, {})[counter] = statistics.mean(v for _, v, _ in mine)
+                got[tag]["kernel"] = mine[0][0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
+                got[tag]["dispatches"] = len(mine)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for tag, g in got.items():
+        if "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
+            return None
+        fetch = 2.0 * g["FETCH_SIZE"] * 1024.0      # KB as reported; gfx950 tallies 128-B requests at 64 B (guide, HBM section)
+        write = g["WRITE_SIZE"] * 1024.0
+        res[tag] = {"hbm_bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "kernel": g["kernel"],
+                    "dispatches": g["dispatches"],
+                    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, this run), 2x FETCH correction"}
+    return res
