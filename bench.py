@@ -637,7 +637,7 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
     sgan = importlib.import_module("radar_ml_amd.sgan")
     torch.manual_seed(a.seed)                                                   # the same initial weights on every rank
     d = sgan.define_discriminator((hw, hw, 1), (hw, hw, 1), (hw, hw, 1), device=dev)
-    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16" if on_gpu else None, use_graph=on_gpu)    # ddp: on when world > 1
+    tr = sgan.DiscriminatorTrainer(d, amp_dtype="float16" if on_gpu else None, use_graph=on_gpu, tune_convolutions=on_gpu)    # ddp: on when world > 1
     g = torch.Generator(device=dev).manual_seed(a.seed + 17 * rank)             # every rank its own shard of the global batch
     x = [torch.rand((n, hw, hw), device=dev, generator=g) * 2 - 1 for _ in range(3)]
     y = torch.randint(0, 3, (n,), device=dev, generator=g)

@@ -196,7 +196,7 @@ class DiscriminatorTrainer:
     """c_model / d_model ``train_on_batch`` (sgan.py:525-532) with the reference's optimizers, fp16 autocast and,
     when torch.distributed is initialised, DistributedDataParallel gradient all-reduce."""
 
-    def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None, use_graph=False):
+    def __init__(self, model, lr=2e-4, beta1=0.5, amp_dtype="float16", ddp=None, use_graph=False, tune_convolutions=False):
         """``use_graph``: capture forward + backward of each head in a HIP graph (torch.cuda.graphs) after three eager
         warm-up steps and replay it afterwards; the optimizer, the loss scaler and the gradient all-reduce stay outside
         the graph.  Inputs must keep their shapes.  With the fused layers the step is launch-bound on the host side,
@@ -208,9 +208,15 @@ class DiscriminatorTrainer:
         backward pass and before the loss-scaled optimizer step -- a single collective of a few tens of microseconds
         instead of per-bucket hooks inside the backward, so forward + backward can still be replayed from a HIP graph.
         ``ddp="torch"`` wraps the model in torch's DistributedDataParallel instead (no graph replay then).
-        BatchNorm statistics stay per replica (what Keras does per replica)."""
+        BatchNorm statistics stay per replica (what Keras does per replica).
+
+        ``tune_convolutions``: sets ``torch.backends.cudnn.benchmark = True`` (process-wide): MIOpen then times its solvers for
+        every convolution shape on first use instead of taking its heuristic pick -- a few seconds once, 3 % off the step on an
+        MI355X (a CK xdl forward kernel and a smaller-tile weight-gradient kernel win)."""
         import torch
         import torch.distributed as dist
+        if tune_convolutions:
+            torch.backends.cudnn.benchmark = True
         self.model = model
         self.device = next(model.parameters()).device
         self.net = model

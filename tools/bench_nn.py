@@ -138,6 +138,8 @@ def main():
                           "label_hist": torch.bincount(lab, minlength=3).tolist()}))
     else:
         sgan = importlib.import_module("radar_ml_amd.sgan")
+        if os.environ.get("RML_CUDNN_BENCHMARK"):          # experiment: let MIOpen time its solvers instead of taking the heuristic pick
+            torch.backends.cudnn.benchmark = bool(int(os.environ["RML_CUDNN_BENCHMARK"]))
         n = a.batch or 256
         d = sgan.define_discriminator(device=dev)
         tr = sgan.DiscriminatorTrainer(d, amp_dtype=a.dtype or "float16", ddp=False, use_graph=bool(int(os.environ.get("RML_SGAN_GRAPH", "1"))))
