@@ -84,7 +84,10 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ev_proj[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_flags[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gemm[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
         return rml_hip_fail(e, "stream/event creation", __FILE__, __LINE__);
@@ -104,7 +107,10 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     for (int i = 0; i < 3; ++i) {
         if (ctx->ev_proj[i]) (void)hipEventDestroy(ctx->ev_proj[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+        if (ctx->ev_flags[i]) (void)hipEventDestroy(ctx->ev_flags[i]);
+        if (ctx->ev_gemm[i]) (void)hipEventDestroy(ctx->ev_gemm[i]);
     }
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_ev_g) (void)hipEventDestroy(e);
     for (const rml_resize_tab& t : ctx->resize_tabs) (void)hipFree(const_cast<double*>(t.kk));

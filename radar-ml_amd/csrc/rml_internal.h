@@ -24,6 +24,10 @@ struct rml_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_proj[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};   // chunk pipeline of rml_project_svm (up to 3 workspaces)
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
+    // third stream of rml_project_svm: the small kernels either side of a chunk's GEMM (tile decision and predicated second
+    // projection pass before it, k_svm_finish after it), so that the GEMM stream carries nothing but GEMMs back to back
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_flags[3] = {nullptr, nullptr, nullptr}, ev_gemm[3] = {nullptr, nullptr, nullptr};
     // optional CU partition (RML_GEMM_CUS=g): aux_stream is restricted to g CUs of every XCD and proj_stream to
     // the remaining 32-g, so the MFMA-bound GEMM and the HBM-bound projection stop fighting for wave slots/LDS
     hipStream_t proj_stream = nullptr;

@@ -1755,10 +1755,25 @@ struct DecisionOut {
 };
 
 // GEMM(s) + finish for one chunk whose operands are already in place.
+// the epilogue of a chunk: partial sums of every SV tile -> decision values, votes, calibrated probabilities, labels
+int run_finish(const rml_svm* m, int64_t n, const int32_t* flags, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
+               bool all_exact_known, bool forced_i8) {
+    FinishArgs fa{};
+    fa.partial = w.partial; fa.Npart = n; fa.ST = (int)(m->Mpad / kTile); fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
+    fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
+    fa.row_flags = all_exact_known ? nullptr : flags; fa.tile_exact = all_exact_known ? nullptr : w.tile_exact;
+    fa.forced_i8 = forced_i8;
+    fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
+    fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
+    hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
               bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true,
-              bool dig_ready = false) {
+              bool dig_ready = false, bool defer_finish = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -1814,17 +1829,8 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
                          : (kmat ? launch_gemm<PATH_F64, true>(m, ga, st) : launch_gemm<PATH_F64>(m, ga, st));
         if (rc) return rc;
     }
-    if (kmat) { RML_HIP(hipGetLastError()); return RML_OK; }      // kernel values only: no decision outputs
-    FinishArgs fa{};
-    fa.partial = w.partial; fa.Npart = n; fa.ST = ST; fa.PT = m->PT; fa.N = n; fa.C = m->C; fa.P = m->P;
-    fa.intercept = m->intercept; fa.calib = m->calib; fa.has_calib = m->has_calib;
-    fa.row_flags = all_exact_known ? nullptr : flags; fa.tile_exact = all_exact_known ? nullptr : w.tile_exact;
-    fa.forced_i8 = (run_i8 && !run_gen);
-    fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
-    fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
-    hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
-    RML_HIP(hipGetLastError());
-    return RML_OK;
+    if (kmat || defer_finish) { RML_HIP(hipGetLastError()); return RML_OK; }      // kernel values only, or the caller launches run_finish itself
+    return run_finish(m, n, flags, w, out, st, all_exact_known, run_i8 && !run_gen);
 }
 
 }  // namespace
@@ -2146,9 +2152,34 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     hipStream_t aux = ctx->aux_stream;
     hipEvent_t* ev_proj = ctx->ev_proj;
     hipEvent_t* ev_done = ctx->ev_done;
+    // RML_PIPE_SPLIT=1 (experiment knob, off): three streams for a grid model on float volumes.  At the Walabot grid the second
+    // stream's chain -- tile decision, skipped second pass, GEMM, skipped float64 GEMM, finish and the launch gaps between them --
+    // is the period of the pipeline (profiles/r03_timeline_walabot.txt), so the small kernels move to a third stream: tile decision
+    // and second pass of chunk c as soon as its projection is done (under the GEMM of chunk c-1), k_svm_finish of chunk c under the
+    // GEMM of chunk c+1, the GEMM stream carries GEMMs back to back (use with RML_NBUF=3: with two workspaces the next projection
+    // waits for a finish that is queued behind this chunk's tile decision).  Measured over four boxes: Walabot +6.4 / +7.1 % on
+    // one, -1.6 / +4.8 % on another, +0.7 % over five interleaved rounds on a third (bimodal: 10.8 or 10.2 M frames/s, depending
+    // on which kernel's workgroups reach the CUs first); 64x64x128 -5 % (2.79 vs 2.93 M).  Not a default.
+    static const bool split_env = [] { const char* e = getenv("RML_PIPE_SPLIT"); return e && atoi(e) == 1; }();
+    const bool split = split_env && grid_ok && vdtype != RML_VOL_U8 && !part && ctx->side_stream != nullptr;
+    hipStream_t side = split ? ctx->side_stream : aux;
+    hipEvent_t* ev_flags = ctx->ev_flags;
+    hipEvent_t* ev_gemm = ctx->ev_gemm;
+    int64_t pend_c = -1, pend_r0 = 0, pend_n = 0;            // chunk whose k_svm_finish is still to be queued (split mode)
+    auto queue_finish = [&]() -> int {
+        if (pend_c < 0) return RML_OK;
+        const ChunkWs& pw = w2[pend_c % NBUF];
+        RML_HIP(hipStreamWaitEvent(side, ev_gemm[pend_c % NBUF], 0));
+        int frc = run_finish(m, pend_n, pw.flags, pw, out.at(pend_r0, m->C, m->P), side, false, false);
+        if (frc) return frc;
+        RML_HIP(hipEventRecord(ev_done[pend_c % NBUF], side));
+        pend_c = -1;
+        return RML_OK;
+    };
     // aux (and the masked projection stream) must start after everything already queued by the caller
     RML_HIP(hipEventRecord(ctx->ev_fork, caller));
     RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    if (split) RML_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
     if (st != caller) RML_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
     int64_t c = 0;
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
@@ -2199,7 +2230,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         // + statistics): the tile decision, the predicated second pass (float rows for tiles that left the grid: a no-op
         // otherwise) and the digit planes follow on the second stream, in front of the chunk's GEMMs.  (Round 2 had them between
         // the projection launches: three launches and their gaps per chunk on the stream the step waits for.)
-        hipStream_t s2 = grid_ok ? aux : st;            // the stream of pass 2 and its followers
+        hipStream_t s2 = grid_ok ? side : st;           // the stream of pass 2 and its followers
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
             rml_prof_mark(ctx, sp);
@@ -2208,10 +2239,10 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
             RML_HIP(hipEventRecord(ev_proj[c % NBUF], sp));
-            RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, aux, w.all_exact, 1);
+            RML_HIP(hipStreamWaitEvent(side, ev_proj[c % NBUF], 0));
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, side, w.all_exact, 1);
             const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
-            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, aux, w.flags, n, FT, 0, 1, w.tile_exact,
+            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, side, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
         // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
@@ -2245,16 +2276,36 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
             RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
         }
+        if (split) {
+            // the side stream: this chunk's tile decision and second pass are queued; the previous chunk's finish follows them (it
+            // waits for that chunk's GEMMs, which end later than this chunk's projection), then the GEMM stream takes this chunk
+            RML_HIP(hipEventRecord(ev_flags[c % NBUF], side));
+            rc = queue_finish();
+            if (rc) return rc;
+            RML_HIP(hipStreamWaitEvent(aux, ev_flags[c % NBUF], 0));
+        }
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
-                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig);
+                       out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig,
+                       /*defer_finish=*/split);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
-        RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
+        if (split) {
+            RML_HIP(hipEventRecord(ev_gemm[c % NBUF], aux));
+            pend_c = c; pend_r0 = r0; pend_n = n;
+        } else {
+            RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
+        }
     }
-    // join: the caller's stream continues after the last GEMMs
-    RML_HIP(hipEventRecord(ctx->ev_join, aux));
+    if (split) {
+        rc = queue_finish();
+        if (rc) return rc;
+        RML_HIP(hipEventRecord(ctx->ev_join, side));          // the last finish waited for the last GEMMs: side is the join
+    } else {
+        RML_HIP(hipEventRecord(ctx->ev_join, aux));
+    }
+    // join: the caller's stream continues after the last GEMMs and their finish
     RML_HIP(hipStreamWaitEvent(caller, ctx->ev_join, 0));
     if (st != caller) {
         RML_HIP(hipEventRecord(ctx->ev_fork, st));
