@@ -495,6 +495,26 @@ def run_general(a, env, grid, frames):
                 "dec_ovo_max_abs_err": float(np.abs(g["dec_ovo"] - r["dec_ovo"]).max()),
                 "proba_max_abs_err": float(np.abs(g["proba"] - r["proba"]).max())}
 
+    # throughput of the augmentation kernels themselves (train.py:84-185 on the GPU): device-resident xz planes of the batch,
+    # one rml_augment launch per kind; bytes = one float32 read + one write per pixel
+    aug = None
+    if rank == 0:
+        planes = rows[:, :X * Z].reshape(B, X, Z).contiguous()
+        rng = np.random.default_rng(a.seed + 5)
+        pars = {"rotate": np.stack([rml.rotation_params(v, (X, Z)) for v in rng.uniform(-15.0, 15.0, B)]),
+                "zoom": rng.uniform(0.7, 1.3, B), "noise": rng.normal(0.0, 0.2, B)}
+        aug = {"workload": "%d device-resident %dx%d float32 planes per launch (csrc/augment.hip: order-3 spline rotate / clipped zoom with "
+                           "float64 arithmetic like SciPy, sparse noise), parameters uploaded per call" % (B, X, Z)}
+        for kind in ("rotate", "zoom", "noise"):
+            rml.augment_planes(planes, kind, pars[kind])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rml.augment_planes(planes, kind, pars[kind])
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t0) / 3
+            aug[kind] = {"planes_per_s": round(B / dta), "ms": round(dta * 1e3, 3), "GBs": round(B * X * Z * 8 / dta / 1e9, 1)}
+        del planes
     ops = 2.0 * D * M
     value = world * B * a.steps / dt
     v64 = world * B * max(1, a.steps // 4) / dt64
@@ -519,6 +539,7 @@ def run_general(a, env, grid, frames):
                          "workload": "the fused front door on the %d volumes scaled by 1 - 2^-10 with N(0, 0.05) noise on the returns "
                                      "(projection -> float rows -> digit planes -> GEMM)" % B,
                          "parity": par(outv, refv, np.arange(256))},
+        "augmentation": aug,
     }
 
 
