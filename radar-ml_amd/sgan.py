@@ -210,13 +210,14 @@ class DiscriminatorTrainer:
         ``ddp="torch"`` wraps the model in torch's DistributedDataParallel instead (no graph replay then).
         BatchNorm statistics stay per replica (what Keras does per replica).
 
-        ``tune_convolutions``: sets ``torch.backends.cudnn.benchmark = True`` (process-wide): MIOpen then times its solvers for
-        every convolution shape on first use instead of taking its heuristic pick -- a few seconds once, 3 % off the step on an
-        MI355X (a CK xdl forward kernel and a smaller-tile weight-gradient kernel win)."""
+        ``tune_convolutions``: runs this trainer's steps with ``torch.backends.cudnn.benchmark = True`` (set around each step and
+        restored afterwards: the flag is process-wide and changes which MIOpen kernels -- and so which round-off -- every other
+        convolution in the process gets): MIOpen then times its solvers for every convolution shape on first use instead of taking
+        its heuristic pick -- a few seconds once, 3 % off the step on an MI355X (a CK xdl forward kernel and a smaller-tile
+        weight-gradient kernel win)."""
         import torch
         import torch.distributed as dist
-        if tune_convolutions:
-            torch.backends.cudnn.benchmark = True
+        self._tune = bool(tune_convolutions)
         self.model = model
         self.device = next(model.parameters()).device
         self.net = model
@@ -277,7 +278,7 @@ class DiscriminatorTrainer:
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         self._flat.mul_(1.0 / self.world)
 
-    def _graph_step(self, head, opt, make_loss, x, targets):
+    def _graph_step_impl(self, head, opt, make_loss, x, targets):
         """One update of ``head`` ('c' or 'd') through a captured graph.  ``targets``: tuple of tensors the loss needs
         (copied into static buffers); ``make_loss(logits, *static_targets)`` builds the loss."""
         import torch
@@ -337,10 +338,29 @@ class DiscriminatorTrainer:
         self.scaler.update()
         return st["loss"].detach(), st["logits"].detach()
 
+    def _tuned(self, fn, *args):
+        """``fn(*args)`` with MIOpen's timed solver search on while this trainer runs its convolutions (``tune_convolutions``),
+        the process-wide flag put back afterwards."""
+        if not self._tune:
+            return fn(*args)
+        import torch
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            return fn(*args)
+        finally:
+            torch.backends.cudnn.benchmark = prev
+
+    def _graph_step(self, head, opt, make_loss, x, targets):
+        return self._tuned(self._graph_step_impl, head, opt, make_loss, x, targets)
+
+    def _step(self, opt, loss_fn, x):
+        return self._tuned(self._step_impl, opt, loss_fn, x)
+
     def _inputs(self, x):
         return [to_nchw(a, self.device) for a in x]
 
-    def _step(self, opt, loss_fn, x):
+    def _step_impl(self, opt, loss_fn, x):
         import torch
         self.net.train()
         if self._flat is not None:
