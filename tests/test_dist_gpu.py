@@ -37,6 +37,10 @@ def test_two_rank_bench_on_one_device_matches_the_single_process_run():
               "--general-frames", "512", "--dnn-frames", "512", "--dnn-parity", "64"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RML_BENCH_ONE_DEVICE", None)
+    # bench.py lets MIOpen time its convolution solvers (tune_convolutions); the picks land in MIOpen's user find-db, which later
+    # processes on the box read: keep this test's picks to itself, so that the numerics tests of the suite see MIOpen's defaults
+    import tempfile
+    env["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="rml_miopen_db_")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", str(2 * per_rank),
                           "--walabot-frames", str(2 * per_rank)] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=1500)

@@ -382,7 +382,10 @@ def _sgan_param_class(name):
 # measured on MI355X (worst over the c and d heads, round 3); the tolerance is twice that, with a floor for the classes whose
 # error is round-off only
 SGAN_GRAD_REL_MEASURED = {
-    "float16": {"bn1.beta": 0.0526, "bn1.gamma": 0.0524, "bn2.beta": 0.0576, "bn2.gamma": 0.0477, "bn3.beta": 0.0639, "bn3.gamma": 0.0461, "conv1.kernel": 0.0514, "conv2.kernel": 0.0460, "conv3.kernel": 0.0450, "dense_bn1.beta": 0.0510, "dense_bn1.gamma": 0.0343, "dense_bn2.beta": 0.0166, "dense_bn2.gamma": 0.0009, "fc1.kernel": 0.0409, "fc2.kernel": 0.0415, "fc3.bias": 0.0007, "fc3.kernel": 0.0013},
+    # float16: the worst of three runs -- MIOpen's heuristic solver pick (0.0166 ... 0.0639) and two runs after a timed find had left
+    # its picks in the box's user find-db (bench.py's tune_convolutions through test_dist_gpu: a CK xdl forward kernel and another
+    # weight-gradient kernel, whose choice is timing-dependent): the convolution kernels in use decide a third of these numbers
+    "float16": {"bn1.beta": 0.0639, "bn1.gamma": 0.0633, "bn2.beta": 0.0650, "bn2.gamma": 0.0627, "bn3.beta": 0.0738, "bn3.gamma": 0.0705, "conv1.kernel": 0.0619, "conv2.kernel": 0.0549, "conv3.kernel": 0.0543, "dense_bn1.beta": 0.0518, "dense_bn1.gamma": 0.0402, "dense_bn2.beta": 0.0377, "dense_bn2.gamma": 0.0009, "fc1.kernel": 0.0520, "fc2.kernel": 0.0490, "fc3.bias": 0.0007, "fc3.kernel": 0.0013},
     "bfloat16": {"bn1.beta": 0.2087, "bn1.gamma": 0.2144, "bn2.beta": 0.2126, "bn2.gamma": 0.1983, "bn3.beta": 0.2234, "bn3.gamma": 0.1943, "conv1.kernel": 0.1936, "conv2.kernel": 0.1844, "conv3.kernel": 0.1759, "dense_bn1.beta": 0.1387, "dense_bn1.gamma": 0.1201, "dense_bn2.beta": 0.0727, "dense_bn2.gamma": 0.0089, "fc1.kernel": 0.1688, "fc2.kernel": 0.1426, "fc3.bias": 0.0061, "fc3.kernel": 0.0092},
 }
 SGAN_GRAD_REL_TOL = {amp: {k: max(2.0 * v, {"float16": 0.004, "bfloat16": 0.03}[amp]) for k, v in d.items()} for amp, d in SGAN_GRAD_REL_MEASURED.items()}
@@ -427,6 +430,7 @@ def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
 
     dt = getattr(torch, amp)
     tols = SGAN_GRAD_REL_TOL[amp]                            # per parameter class: ~2x the measured worst (printed below)
+    bad = []                                                # every parameter is checked before the test fails: the print below shows them all
     for head in ("c", "d"):
         l32, g32 = grads(ref, None, head)
         l16, g16 = grads(fus, dt, head)
@@ -450,11 +454,13 @@ def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
             worst.append((rel, cos, k))
             pc = _sgan_param_class(k)
             by_class[pc] = max(by_class.get(pc, 0.0), rel)
-            assert rel < tols[pc] and cos > 1.0 - 0.6 * tols[pc] ** 2 - 1e-4, (head, k, pc, rel, cos)
+            if not (rel < tols[pc] and cos > 1.0 - 0.6 * tols[pc] ** 2 - 1e-4):
+                bad.append((head, k, pc, round(rel, 4), tols[pc], round(cos, 5)))
         assert len(worst) >= 30
         print("sgan %s head %s: worst relative gradient error %.4f (%s), worst cosine %.5f; per class: %s"
               % (amp, head, max(worst)[0], max(worst)[2], min(w[1] for w in worst),
                  ", ".join("%s %.4f" % kv for kv in sorted(by_class.items()))))
+    assert not bad, bad
     # running statistics after the same number of forward passes agree as well (incl. the bias the fused path adds back)
     for (k, a), (_, b) in zip(ref.named_buffers(), fus.named_buffers()):
         if k.endswith("running_mean") or k.endswith("running_var"):
