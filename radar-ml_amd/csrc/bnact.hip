@@ -341,53 +341,86 @@ __global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__
     }
 }
 
-template <bool BF>
+// CPT = channels per thread.  8 (round 2): 250 registers -- 88 accumulators, 72 weights, 32 batch-norm constants -- two waves per
+// SIMD, and every output row starts with a dependent global load (the image rows) in front of a barrier: the kernel ran at a third
+// of what its arithmetic needs.  4 (round 3): half the accumulators, weights and constants per thread, twice the threads' worth of
+// waves per SIMD to hide the loads behind; a pixel's 8-byte gradient loads of 32 lanes are the same contiguous 256 B.  By itself that
+// changed nothing (154 vs 153 us per branch); with the row's eight gradient loads issued before the image rows are staged 136 us.
+template <bool BF, int CPT>
 __global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
                                                 int64_t N, int H, int W, int C, int ph, int pw, const float* mean, const float* rstd,
                                                 const float* gamma, const float* beta, float slope, float* part /* [G][11][C] */) {
     __shared__ float lds[kT * 8];
-    const int CG = C >> 3, PL = kT / CG, Wp = W + pw, Hp = H + ph;
+    const int CG = C / CPT, PL = kT / CG, Wp = W + pw, Hp = H + ph;
     const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
-    const int64_t M = N * H * W;
-    Conv1<BF> cv;
-    cv.init(wgt, C, cg, image, H, W);
-    float acc[11][8];                   // 0..8: A[k], 9: sum g, 10: sum g*x_hat
+    float wk[9][CPT];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) wk[k][i] = wgt[k * C + cg * CPT + i];
+    float acc[11][CPT];                 // 0..8: A[k], 9: sum g, 10: sum g*x_hat
 #pragma unroll
     for (int k = 0; k < 11; ++k)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[k][i] = 0.0f;
-    float mu[8], rs[8], ga[8], be[8];
+        for (int i = 0; i < CPT; ++i) acc[k][i] = 0.0f;
+    float mu[CPT], rs[CPT], ga[CPT], be[CPT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = cg * 8 + i;
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg * CPT + i;
         mu[i] = mean[c]; rs[i] = rstd[c]; ga[i] = gamma[c]; be[i] = beta[c];
     }
     // one output row per iteration: its three image rows go through LDS (as float), so the nine taps of a pixel are LDS
     // broadcasts instead of nine dependent global loads
     float* rows_s = lds;                             // [3][IW], reused for the reductions afterwards
     const int IW = 2 * W + 1, IH = 2 * H + 1;
-    (void)M;
     for (int64_t row = blockIdx.x; row < N * H; row += gridDim.x) {
         const int64_t n = row / H;
         const int h = (int)(row - n * H);
+        const uint16_t* dyr = dy + ((n * Hp + h) * (int64_t)Wp) * C + cg * CPT;
+        // the row's gradient loads go out first (up to NB per thread in flight), then the image rows are staged: the barrier and the
+        // staging's own global loads hide under them.  (Issued at their use, each of them was a full memory latency per pixel.)
+        constexpr int NB = CPT == 8 ? 1 : 8;        // CPT = 8 has no registers to spare (292 with four loads ahead: one wave per SIMD)
+        typedef uint32_t dq_t __attribute__((ext_vector_type(CPT / 2)));
+        dq_t dq[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int w = pl + u * PL;
+            dq[u] = *reinterpret_cast<const dq_t*>(dyr + (int64_t)(w < W ? w : W - 1) * C);
+        }
         __syncthreads();
         for (int i = tid; i < 3 * IW; i += kT) {
             const int ky = i / IW, xx = i - ky * IW;
             rows_s[i] = h2f<BF>(image[(n * IH + 2 * h + ky) * (int64_t)IW + xx]);
         }
         __syncthreads();
-        const uint16_t* dyr = dy + ((n * Hp + h) * (int64_t)Wp) * C + cg * 8;
-        for (int w = pl; w < W; w += PL) {
-            float t[9], v[8], d[8];
+        for (int w0 = pl, u0 = 0; w0 < W; w0 += NB * PL, ++u0) {
+            if (u0 > 0) {               // rows longer than NB * PL pixels: the next batch of loads (not prefetched)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int w = w0 + u * PL;
+                    dq[u] = *reinterpret_cast<const dq_t*>(dyr + (int64_t)(w < W ? w : W - 1) * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+            const int w = w0 + u * PL;
+            if (w >= W) break;
+            float t[9], d[CPT];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) t[ky * 3 + kx] = rows_s[ky * IW + 2 * w + kx];
-            cv.z(t, v);
-            unpack8<BF>(*reinterpret_cast<const uint4*>(dyr + (int64_t)w * C), d);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float xh = (v[i] - mu[i]) * rs[i];
+            for (int i = 0; i < CPT / 2; ++i) {
+                const uint32_t q = dq[u][i];
+                d[2 * i] = h2f<BF>((uint16_t)(q & 0xFFFFu)); d[2 * i + 1] = h2f<BF>((uint16_t)(q >> 16));
+            }
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                float v = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v = fmaf(wk[k][i], t[k], v);
+                const float xh = (v - mu[i]) * rs[i];
                 const float zz = xh * ga[i] + be[i];
                 const float g = zz > 0.0f ? d[i] : d[i] * slope;
                 acc[9][i] += g;
@@ -395,16 +428,17 @@ __global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ ima
 #pragma unroll
                 for (int k = 0; k < 9; ++k) acc[k][i] = fmaf(g, t[k], acc[k][i]);
             }
+            }
         }
     }
     for (int k = 0; k < 11; ++k) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = acc[k][i];
+        for (int i = 0; i < CPT; ++i) lds[tid * CPT + i] = acc[k][i];
         __syncthreads();
         for (int c = tid; c < C; c += kT) {
             float s = 0.0f;
-            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c >> 3)) * 8 + (c & 7)];
+            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c / CPT)) * CPT + (c % CPT)];
             part[((size_t)blockIdx.x * 11 + k) * C + c] = s;
         }
     }
@@ -602,8 +636,16 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     float* part = workspace;
     float* sums = part + (size_t)G * 11 * C;
     const float* img = img_stats;
-    if (dtype) hipLaunchKernelGGL(k_c1_bwd1<true>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
-    else hipLaunchKernelGGL(k_c1_bwd1<false>, dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+    // four channels per thread where the channel groups divide the workgroup (C = 128: 32 groups x 8 pixels); RML_C1_CPT=8: round 2's
+    static const bool cpt8 = [] { const char* e = getenv("RML_C1_CPT"); return e && atoi(e) == 8; }();
+    const bool four = !cpt8 && C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
+    if (four) {
+        if (dtype) hipLaunchKernelGGL((k_c1_bwd1<true, 4>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+        else hipLaunchKernelGGL((k_c1_bwd1<false, 4>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+    } else {
+        if (dtype) hipLaunchKernelGGL((k_c1_bwd1<true, 8>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+        else hipLaunchKernelGGL((k_c1_bwd1<false, 8>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3(11 * C), dim3(kT), 0, st, part, G, 11 * C, sums);
     hipLaunchKernelGGL(k_c1_wgrad_combine, dim3((C + 63) / 64), dim3(64), 0, st, sums, img, weight, save_mean, save_rstd, gamma, C, (double)M,
                        dweight, dgamma, dbeta);
