@@ -400,7 +400,7 @@ void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
     size_t pad = 0;
     if (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad) {
         const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
-        pad = mine < 82 * 1024 ? 82 * 1024 - mine : 0;
+        pad = mine < 81 * 1024 ? 81 * 1024 - mine : 0;
     }
     if (pp.o.skip_if_set) {
         RML_MAX_DYN_LDS(96 * 1024, &k_project_wave<VT, MODE, NY, G, true>);

@@ -179,7 +179,7 @@ void launch_lin(const ProjParams& pp, int num_cu, hipStream_t st) {
     // half of the CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see launch_wave);
     // share_cu = 2: the BALLAST variant does that with registers and asks for its own 66 KB only
     const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
-    const size_t lds = (!BALLAST && pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 82 * 1024) ? 82 * 1024 : mine;
+    const size_t lds = (!BALLAST && pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 81 * 1024) ? 81 * 1024 : mine;
     if (pp.o.skip_if_set) {
         RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>);
         hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>), grid, block, lds, st, pp);

@@ -448,6 +448,162 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_svm_gemm_lite<PT>: the exact 128 x 128 tile in 40 KB of LDS -- the GEMM of the fused pipeline's second stream.  Beside a
+// persistent projection workgroup (66-82 KB of LDS per CU) only ONE k_svm_gemm workgroup (70 KB) fits a CU: one wave per SIMD, a
+// barrier per K-step, nothing to overlap a stall with -- and when the GEMM's workgroups happen to reach a CU before the
+// projection's, two of them take the LDS and the projection's workgroup waits (the bimodal results of RML_PIPE_SPLIT).  Here a
+// K-step is 64 B per row (two stages of 2 x 8 KiB) and the accumulators go through LDS in two halves of 32 KiB, so that two of
+// these workgroups and the projection's always fit together.  The image is [128 rows][64 B] with the 16-byte chunk index XORed
+// by (row >> 2) & 3 (rows r, r+4, r+8, r+12 of a 16-lane group share the 64 B bank window: four chunk positions, four rows).
+// Same arithmetic and the same summation order as k_svm_gemm<PATH_I8> (a thread sums its 64 SV rows in order, half 0 + half 1):
+// bit-identical partial sums.
+// ------------------------------------------------------------------------------------------
+constexpr int kLiteStep = 64;                          // K bytes per row and step
+constexpr int kLiteOp = kTile * kLiteStep;             // 8 KiB per operand and stage
+
+template <int PT>
+__global__ __launch_bounds__(256, 2) void k_svm_gemm_lite(GemmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int XPX = (a.FT + 7) >> 3;
+    const int ftile = (slot % XPX) * 8 + xcd;
+    const int stile = slot / XPX;
+    if (ftile >= a.FT) return;
+    if (a.tile_exact && a.tile_exact[ftile] != a.want) return;
+    const int64_t f0 = (int64_t)ftile * kTile;
+    const int64_t m0 = (int64_t)stile * kTile;
+
+    // LDS: [2 stages][SV 8 KiB | samples 8 KiB] = 32 KiB (later: 64 x 128 accumulators), then the per-SV table and the exp table
+    double* svw = reinterpret_cast<double*>(smem + 4 * kLiteOp);
+    const double* etab = svw + kTile * (1 + PT);
+    exp_tab_init(svw + kTile * (1 + PT), tid);
+    for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
+        int m = idx / (1 + PT), c = idx - m * (1 + PT);
+        svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
+    }
+
+    // staging: 8 wave-instructions of 1 KiB per operand tile and stage, 2 per wave
+    const uint8_t* gsv[2];
+    const uint8_t* gx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = (wave * 2 + q) * 64 + lane;    // 16-byte slot in the LDS image
+        const int r = s >> 2;
+        const int c = (s & 3) ^ ((r >> 2) & 3);      // inverse swizzle on the source
+        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * 2 * kLiteOp;
+        const int64_t ko = (int64_t)kt * kLiteStep;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(gsv[q] + ko, base + (wave * 2 + q) * 1024);
+            glds16(gx[q] + ko, base + kLiteOp + (wave * 2 + q) * 1024);
+        }
+    };
+    int aoff[2], asw[2], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wr * 64 + t * 32 + (lane & 31);
+        const int rb = wc * 64 + t * 32 + (lane & 31);
+        aoff[t] = ra * kLiteStep; asw[t] = (ra >> 2) & 3;
+        boff[t] = rb * kLiteStep; bsw[t] = (rb >> 2) & 3;
+    }
+    const int chalf = lane >> 5;
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int KT = a.KT * (kStepBytes / kLiteStep);  // a.KT counts 128-byte steps
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* sA = smem + (kt & 1) * 2 * kLiteOp;
+        const unsigned char* sB = sA + kLiteOp;
+        v4i af[2][2], bf[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = 2 * kk + chalf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[kk][t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
+                bf[kk][t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- fused float64 epilogue, one SV half (64 rows x 128 samples x 4 B = 32 KiB) at a time; threads 0..127 own a sample
+    // column each and sum its 64 rows in order -- the order, and therefore the bits, of k_svm_gemm's thread (n, h)
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    const int nl = tid & 127;
+    const int64_t n = f0 + nl;
+    const int64_t nc = n < a.N ? n : a.N - 1;
+    const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
+    double S[2][PT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[h][p] = 0.0;
+    int* gl = reinterpret_cast<int*>(smem);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                       // the tile images (h = 0) / the first half (h = 1) are consumed
+        if (wr == h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;      // row within the half
+                        const int nn = wc * 64 + j * 32 + (lane & 31);
+                        gl[ml * kTile + nn] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int* gcol = gl + nl;
+#pragma unroll 2
+            for (int mm = 0; mm < 64; ++mm) {
+                const double* e = svw + (h * 64 + mm) * (1 + PT);
+                const double g = (double)gcol[mm * kTile];
+                double kv;
+                if (rbf) {
+                    double d2 = xt + e[0] - 2.0 * g;
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    kv = rml_exp_neg(-a.gs * d2, etab);
+                } else {
+                    kv = (g + xt + e[0]) * a.gs;
+                }
+#pragma unroll
+                for (int p = 0; p < PT; ++p) S[h][p] = fma(e[1 + p], kv, S[h][p]);
+            }
+        }
+    }
+    if (tid < 128 && n < a.N) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[0][p] + S[1][p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // I8 hot path, large batches: 256 SVs x 256 samples per workgroup (512 threads, 8 waves as 2 x 4, wave tile 128 x 64 =
 // 4 x 2 MFMA tiles of 32x32, 128 accumulator registers), K-step 128 B per row, two 64 KiB stages.
 //
@@ -1600,6 +1756,21 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
+// the 40 KB version of the exact 128 x 128 kernel (k_svm_gemm_lite): beside a persistent projection in the fused pipeline
+int launch_gemm_lite(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+    const size_t lds = 4 * kLiteOp + (size_t)kTile * (1 + m->PT) * sizeof(double) + kExpTabBytes;
+    const int FT8 = (int)round_up(ga.FT, 8);
+    dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
+    switch (m->PT) {
+        case 1: hipLaunchKernelGGL((k_svm_gemm_lite<1>), grid, block, lds, st, ga); break;
+        case 3: hipLaunchKernelGGL((k_svm_gemm_lite<3>), grid, block, lds, st, ga); break;
+        case 6: hipLaunchKernelGGL((k_svm_gemm_lite<6>), grid, block, lds, st, ga); break;
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the lite kernel");
+    }
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 template <int DIG>
 int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
     const int FT2 = (ra.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
@@ -1773,7 +1944,7 @@ int run_finish(const rml_svm* m, int64_t n, const int32_t* flags, const ChunkWs&
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
               bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true,
-              bool dig_ready = false, bool defer_finish = false) {
+              bool dig_ready = false, bool defer_finish = false, bool lite_gemm = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -1807,8 +1978,11 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         // RML_GEMM_RING128 (read per call): 1 = the small tile with the ring schedule
         const char* r128 = getenv("RML_GEMM_RING128");
         const bool ring128 = !kmat && !big && m->PT <= 6 && r128 && atoi(r128) == 1;
+        const char* lt2 = getenv("RML_GEMM_LITE");                     // 2: every small exact GEMM (tests, tools/gemm_ab.py)
+        const bool lite = !kmat && !big && !ring128 && (lite_gemm || (lt2 && atoi(lt2) == 2)) && m->PT <= 6;
         int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st)
-                      : (big ? launch_gemm_big(m, ga, st) : (ring128 ? launch_gemm_ring128(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st)));
+                      : (big ? launch_gemm_big(m, ga, st)
+                             : (ring128 ? launch_gemm_ring128(m, ga, st) : (lite ? launch_gemm_lite(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st))));
         if (rc) return rc;
     }
     if (run_dig) {
@@ -2161,6 +2335,10 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     // one, -1.6 / +4.8 % on another, +0.7 % over five interleaved rounds on a third (bimodal: 10.8 or 10.2 M frames/s, depending
     // on which kernel's workgroups reach the CUs first); 64x64x128 -5 % (2.79 vs 2.93 M).  Not a default.
     static const bool split_env = [] { const char* e = getenv("RML_PIPE_SPLIT"); return e && atoi(e) == 1; }();
+    // RML_GEMM_LITE=1 (read per call): the 40 KB version of the exact 128 x 128 kernel beside the projection (two of its workgroups
+    // and the projection's fit a CU together)
+    const char* lte = getenv("RML_GEMM_LITE");
+    const bool lite = small_gemm && grid_ok && lte && atoi(lte) == 1;
     const bool split = split_env && grid_ok && vdtype != RML_VOL_U8 && !part && ctx->side_stream != nullptr;
     hipStream_t side = split ? ctx->side_stream : aux;
     hipEvent_t* ev_flags = ctx->ev_flags;
@@ -2287,7 +2465,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig,
-                       /*defer_finish=*/split);
+                       /*defer_finish=*/split, /*lite_gemm=*/lite);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;

@@ -547,6 +547,13 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     np.testing.assert_array_equal(got128, outs["0"][0])
     np.testing.assert_array_equal(rml.GpuCalibratedClassifier(svc).predict_proba(X), outs["0"][2])
     monkeypatch.delenv("RML_GEMM_RING128")
+    # k_svm_gemm_lite (64-byte K-steps, the accumulators through LDS in two halves: 40 KB instead of 70): the same bits once more
+    monkeypatch.setenv("RML_GEMM_LITE", "2")
+    svc.decision_function_shape = "ovo"
+    got_lite = svc.decision_function(X).reshape(len(X), -1)
+    np.testing.assert_array_equal(got_lite, outs["0"][0])
+    np.testing.assert_array_equal(rml.GpuCalibratedClassifier(svc).predict_proba(X), outs["0"][2])
+    monkeypatch.delenv("RML_GEMM_LITE")
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
     # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
     np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
