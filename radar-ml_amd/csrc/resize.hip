@@ -94,12 +94,27 @@ __device__ __forceinline__ void horizontal_fixed(const float* in_s, int H, int W
                                                  int g, int G, int xx, float* tmp_s) {
 #pragma clang fp contract(off)
     if (g >= G) return;
-    for (int y = g; y < H; y += G) {
+    // two rows at a time: two independent float64 chains per thread (a single chain of KS dependent adds left the VALU idle most
+    // of the time: three waves per SIMD cannot cover an 8-cycle add latency per tap); each sum keeps its own tap order
+    int y = g;
+    for (; y + G < H; y += 2 * G) {
+        const float* s = in_s + y * W + first;
+        const float* s2 = s + G * W;
+        double ss = 0.0, ss2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            ss = ss + (double)s[t] * k[t];
+            ss2 = ss2 + (double)s2[t] * k[t];
+        }
+        tmp_s[y * OW + xx] = (float)ss;                 // Pillow's float32 intermediate image
+        tmp_s[(y + G) * OW + xx] = (float)ss2;
+    }
+    if (y < H) {
         const float* s = in_s + y * W + first;
         double ss = 0.0;
 #pragma unroll
         for (int t = 0; t < KS; ++t) ss = ss + (double)s[t] * k[t];
-        tmp_s[y * OW + xx] = (float)ss;                 // Pillow's float32 intermediate image
+        tmp_s[y * OW + xx] = (float)ss;
     }
 }
 
@@ -214,6 +229,32 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
         if (!vert) {
             if (!horiz)             // no pass at all: Image.resize returns a copy
                 for (int i = tid; i < OH * OW; i += 256) emit(i, cur[i]);
+        } else if ((OW & 3) == 0) {
+            // vertical pass: a thread produces the four outputs (yy, xx + q * OW/4) from one read of the row's weights -- four
+            // independent float64 chains (two left the VALU waiting on the add latency), each in its own tap order
+            const int HW4 = OW >> 2;
+            const int dq = 256 / HW4, dr = 256 - dq * HW4;
+            int yy = tid / HW4, xx = tid - yy * HW4;
+            for (int i = tid; i < OH * HW4; i += 256) {
+                const int first = bv_s[2 * yy], n = bv_s[2 * yy + 1];
+                const float* s = cur + first * OW + xx;
+                const double* k = kv_s + yy * a.ksv;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                for (int t = 0; t < n; ++t) {
+                    const double kt = k[t];
+                    const float* r = s + t * OW;
+                    s0 = s0 + (double)r[0] * kt;
+                    s1 = s1 + (double)r[HW4] * kt;
+                    s2 = s2 + (double)r[2 * HW4] * kt;
+                    s3 = s3 + (double)r[3 * HW4] * kt;
+                }
+                emit(yy * OW + xx, (float)s0);
+                emit(yy * OW + xx + HW4, (float)s1);
+                emit(yy * OW + xx + 2 * HW4, (float)s2);
+                emit(yy * OW + xx + 3 * HW4, (float)s3);
+                yy += dq; xx += dr;
+                while (xx >= HW4) { xx -= HW4; ++yy; }
+            }
         } else if ((OW & 1) == 0) {
             // vertical pass: a thread produces (yy, xx) and (yy, xx + OW/2) from one read of the row's weights
             const int HW2 = OW >> 1;
