@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // k_svm_gemm_lite<PT>: the exact 128 x 128 tile in 40 KB of LDS -- the GEMM of the fused pipeline's second stream.  Beside a
-// persistent projection workgroup (66-82 KB of LDS per CU) only ONE k_svm_gemm workgroup (70 KB) fits a CU: one wave per SIMD, a
+// persistent projection workgroup (66-81 KB of LDS per CU) only ONE k_svm_gemm workgroup (70 KB) fits a CU: one wave per SIMD, a
 // barrier per K-step, nothing to overlap a stall with -- and when the GEMM's workgroups happen to reach a CU before the
 // projection's, two of them take the LDS and the projection's workgroup waits (the bimodal results of RML_PIPE_SPLIT).  Here a
 // K-step is 64 B per row (two stages of 2 x 8 KiB) and the accumulators go through LDS in two halves of 32 KiB, so that two of
