@@ -574,3 +574,58 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
         for k in ("label_vote", "label_calib"):
             np.testing.assert_array_equal(res["0"][k], res["1"][k])
         np.testing.assert_array_equal(res["0"]["dec_ovo"], res["1"]["dec_ovo"])
+
+
+@pytest.mark.parametrize("grid,frames", [((64, 64, 128), 65536), ((22, 31, 176), 262144)])
+def test_full_size_batches_size_independent_properties(rml, grid, frames):
+    """BASELINE.json's full sizes (configs[2]: 65 536 frames of 64x64x128; the Walabot grid at the bench's 262 144) through
+    properties that do not need an oracle of that size:
+      * chunking independence -- the whole batch in one call against the same frames in three ragged calls (the library chunks
+        each call for itself: different chunk boundaries, different last-chunk sizes, 8 192-frame and whole-round paths): decision
+        values, probabilities and labels BIT-identical;
+      * ingest independence -- the same frames as uint8 volumes (byte kernel, ring GEMM in whole rounds): bit-identical again;
+      * monotonicity of the max-projection -- features of max(V1, V2) = max of the features, on a slab;
+      * the float64 C oracle on 96 frames drawn from the whole range (labels bit-exact, decision values within 1e-5).
+    The model: support vectors on the code grid drawn from the same generator as the frames (an exact model, ~1.5 k SVs)."""
+    X, Y, Z = grid
+    free = torch.cuda.mem_get_info()[0]
+    need = frames * X * Y * Z * 5 + (8 << 30)               # float32 volumes + their uint8 copy + workspaces
+    if free < need:
+        pytest.skip("needs %.0f GB of free HBM" % (need / 2 ** 30))
+    rng = np.random.default_rng(17)
+    M = 1536
+    svv, _ = rml.synth_volumes(M, X, Y, Z, seed=101)
+    sv = rml.process_volumes(svv, mode="max", scale=True).cpu().numpy().astype(np.float64)
+    del svv
+    nsv = np.array([M // 3, M // 3, M - 2 * (M // 3)], dtype=np.int32)
+    dual = rng.uniform(-1.0, 1.0, size=(2, M))
+    icpt = rng.uniform(-0.1, 0.1, 3)
+    svc = rml.GpuSVC(sv, dual, icpt, nsv, 0.01, np.array([0, 1, 2]),
+                     calib_a=-np.abs(rng.uniform(1.0, 3.0, 3)), calib_b=rng.uniform(-0.2, 0.2, 3))
+    assert svc.exact
+    V, _ = rml.synth_volumes(frames, X, Y, Z, seed=7)
+    whole = svc.decide_volumes(V, mode="max", scale=True)
+    torch.cuda.synchronize()
+    cuts = [0, frames // 3 + 1000, frames // 3 + 1000 + 12345, frames]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = svc.decide_volumes(V[lo:hi], mode="max", scale=True)
+        for k in ("dec_ovo", "dec_ovr", "proba", "label_vote", "label_calib"):
+            assert torch.equal(part[k], whole[k][lo:hi]), (k, lo, hi)
+    # the same frames as bytes
+    V8 = V.to(torch.uint8)
+    bytes_out = svc.decide_volumes(V8, mode="max", scale=True)
+    for k in ("dec_ovo", "proba", "label_calib"):
+        assert torch.equal(bytes_out[k], whole[k]), k
+    del V8, bytes_out
+    # monotone: the projections of an element-wise maximum are the element-wise maximum of the projections
+    a, b = V[:2048], V[frames - 2048:]
+    fa, fb = rml.process_volumes(a, mode="max", scale=True), rml.process_volumes(b, mode="max", scale=True)
+    fm = rml.process_volumes(torch.maximum(a, b), mode="max", scale=True)
+    assert torch.equal(fm, torch.maximum(fa, fb))
+    # the oracle on frames from the whole range
+    pick = np.unique(np.concatenate([np.arange(32), rng.integers(0, frames, 32), np.arange(frames - 32, frames)]))
+    idx = torch.as_tensor(pick, device=V.device)
+    rows = O.features_from_projections(*O.project_max(V[idx].cpu().numpy()), (True, True, True), True).astype(np.float32)
+    want = O.svm_decision_ovo(rows, sv, dual, icpt, nsv, 0.01, "rbf")
+    assert np.abs(whole["dec_ovo"][idx].cpu().numpy() - want).max() <= 1e-5
+    np.testing.assert_array_equal(whole["label_vote"][idx].cpu().numpy(), O.svm_vote_labels(want, 3))
