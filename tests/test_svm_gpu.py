@@ -588,6 +588,8 @@ def test_full_size_batches_size_independent_properties(rml, grid, frames):
       * the float64 C oracle on 96 frames drawn from the whole range (labels bit-exact, decision values within 1e-5).
     The model: support vectors on the code grid drawn from the same generator as the frames (an exact model, ~1.5 k SVs)."""
     X, Y, Z = grid
+    import gc
+    gc.collect(); torch.cuda.empty_cache()                 # earlier tests' blocks sit in PyTorch's caching allocator
     free = torch.cuda.mem_get_info()[0]
     need = frames * X * Y * Z * 5 + (8 << 30)               # float32 volumes + their uint8 copy + workspaces
     if free < need:
@@ -629,3 +631,5 @@ def test_full_size_batches_size_independent_properties(rml, grid, frames):
     want = O.svm_decision_ovo(rows, sv, dual, icpt, nsv, 0.01, "rbf")
     assert np.abs(whole["dec_ovo"][idx].cpu().numpy() - want).max() <= 1e-5
     np.testing.assert_array_equal(whole["label_vote"][idx].cpu().numpy(), O.svm_vote_labels(want, 3))
+    del V, whole, a, b, fa, fb, fm
+    gc.collect(); torch.cuda.empty_cache()
