@@ -341,7 +341,7 @@ def run_workload(a, env, grid, frames, primary):
             cpu = BS.reference_libs_baseline(vh, model, gl, threads, budget_s=25.0 if primary else 12.0,
                                              want_all=2048 if primary else 1024)
         except Exception as e:                                  # sklearn internals moved: say so, keep the port
-            cpu = {"value": None, "unit": "frames/s", "cores": threads, "kind": "reference-libs", "error": repr(e)[:200]}
+            cpu = {"value": None, "unit": "frames/s", "cores": threads, "kind": "port", "port_of": "the reference's own library calls (NumPy max, scipy.ndimage.zoom, scikit-learn CalibratedClassifierCV(SVC).predict), restated call for call", "error": repr(e)[:200]}
         ncpu = a.cpu_frames
         if ncpu <= 0:
             est = 3.0 * D * M / (1.2e9 * threads)
@@ -353,7 +353,7 @@ def run_workload(a, env, grid, frames, primary):
         OC.svm(cf, sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"], model["gamma"], "rbf",
                model["calib_a"], model["calib_b"], threads=threads)
         cdt = time.perf_counter() - t1
-        cpu["port"] = {"value": round(ncpu / cdt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+        cpu["c_port"] = {"value": round(ncpu / cdt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
                        "sample": "%d of the same frames, oracle/oracle.c (max-projection + float64 libsvm loops, OpenMP over frames), "
                                  "%.1f s" % (ncpu, cdt)}
 

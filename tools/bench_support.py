@@ -149,15 +149,15 @@ def reference_libs_baseline(vh, model, gpu_label_idx, threads, budget_s=25.0, wa
                     "label_mismatch_vs_gpu": pool["label_mismatch_vs_gpu"], "start_skew_s": pool["start_skew_s"],
                     "note": "one worker process per core, the model's arrays shared through page-cache-backed memory maps"}
         if pool["value"] >= thread_pool["value"]:
-            return {"value": pool["value"], "unit": "frames/s", "cores": pool["cores"], "kind": "reference-libs",
+            return {"value": pool["value"], "unit": "frames/s", "cores": pool["cores"], "kind": "port", "port_of": "the reference's own library calls (NumPy max, scipy.ndimage.zoom, scikit-learn CalibratedClassifierCV(SVC).predict), restated call for call",
                     "sample": "%d of the same synthetic frames on %d worker processes (one per core) in %.1f s: %s" % (pool["frames"], pool["cores"], pool["seconds"], what),
                     "label_mismatch_vs_gpu": pool["label_mismatch_vs_gpu"], "note": note,
                     "single_process": single, "thread_pool": thread_pool, "process_pool": pool_row}
-        return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "reference-libs",
+        return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "port", "port_of": "the reference's own library calls (NumPy max, scipy.ndimage.zoom, scikit-learn CalibratedClassifierCV(SVC).predict), restated call for call",
                 "sample": "%d of the same synthetic frames on %d threads of one process in %.1f s: %s" % (done, threads, dt2, what),
                 "label_mismatch_vs_gpu": mism2, "note": note,
                 "single_process": single, "thread_pool": thread_pool, "process_pool": pool_row}
-    return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "reference-libs",
+    return {"value": thread_pool["value"], "unit": "frames/s", "cores": int(threads), "kind": "port", "port_of": "the reference's own library calls (NumPy max, scipy.ndimage.zoom, scikit-learn CalibratedClassifierCV(SVC).predict), restated call for call",
             "sample": "%d of the same synthetic frames on %d threads in %.1f s (the process pool could not be run): %s" % (done, threads, dt2, what),
             "label_mismatch_vs_gpu": mism2, "note": note, "single_process": single, "thread_pool": thread_pool}
 
