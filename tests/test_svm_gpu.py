@@ -633,3 +633,22 @@ def test_full_size_batches_size_independent_properties(rml, grid, frames):
     np.testing.assert_array_equal(whole["label_vote"][idx].cpu().numpy(), O.svm_vote_labels(want, 3))
     del V, whole, a, b, fa, fb, fm
     gc.collect(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_fused_front_door_edge_batch_sizes(rml, u8):
+    """decide_volumes on batches of 0, 1, 127, 129 and 8 193 frames (empty; below, across and just past a 128-row tile; one frame
+    past a pipeline chunk), float32 and uint8 volumes: every frame's outputs equal the ones it gets in the 8 193-frame batch."""
+    g = load_golden("svm_walabot.npz")
+    svc, m = _model(rml, g)
+    X, Y, Z = 22, 31, 176
+    V, _ = rml.synth_volumes(8193, X, Y, Z, seed=23)
+    if u8:
+        V = V.to(torch.uint8)
+    whole = svc.decide_volumes(V, mode="max", scale=True)
+    assert whole["dec_ovo"].shape == (8193, 3)
+    for n in (0, 1, 127, 129):
+        part = svc.decide_volumes(V[8193 - n:], mode="max", scale=True)
+        for k in ("dec_ovo", "dec_ovr", "label_vote"):
+            assert part[k].shape[0] == n
+            assert torch.equal(part[k], whole[k][8193 - n:]), (k, n)
