@@ -2,9 +2,9 @@
 # Round profile on the GPU box (run through gpurun from the repo root):   tools/profile_round.sh rNN
 # ONE rocprofv3 --kernel-trace --stats run PER WORKLOAD, so that every roofline.frac of the bench line can be recomputed from
 # one row of one summary (a summary over the whole bench mixes launches of one kernel on different shapes):
-#   stats_headline_f32   64x64x128 f32 volumes -> SVM          (k_project_wave + k_svm_gemm<I8>)
-#   stats_walabot_f32    22x31x176 f32 volumes -> SVM
-#   stats_headline_u8 / stats_walabot_u8    the same frames as uint8 volumes (k_project_u8_max)
+#   stats_headline_f32   64x64x128 f32 volumes -> SVM          (k_project_wave + k_svm_gemm<I8> sharing the CUs)
+#   stats_walabot_f32    22x31x176 f32 volumes -> SVM          (k_project_lin + k_svm_gemm<I8> sharing the CUs)
+#   stats_headline_u8 / stats_walabot_u8    the same frames as uint8 volumes (k_project_u8_max, then k_svm_gemm_ring<PT,0> in whole rounds)
 #   stats_general_rows   rows off the code grid -> multi-digit int8 kernel (k_svm_gemm_ring<PT,1>) and float64 MFMA
 #   stats_gemm_alone     code rows -> k_svm_gemm_ring<PT,0>, whole-round chunks (tools/gemm_ab.py)
 #   stats_dnn / stats_sgan
