@@ -44,10 +44,16 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     extern __shared__ __align__(16) unsigned char lds8[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     const int X = a.X, Y = a.Y, Z = a.Z;
+    // CPR = chunks per row in the LANE geometry, CPRm = chunks per row in memory.  They differ when a row that is not a power of
+    // two of chunks (the Walabot grid: 11) runs in the next power-of-two geometry (16 lanes per row, 5 of them idle: they re-read
+    // the row's last chunk, a duplicate is harmless for a maximum, and store nothing) to get the VALU cross-lane steps
     const int CPR = FCPR ? FCPR : CPR_rt;
+    const int CPRm = CPR_rt;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // plane indices and their addresses stay scalar
     const int s = lane / CPR, c = lane - s * CPR;
+    const bool cval = c < CPRm;
+    const int cm = cval ? c : CPRm - 1;
     const int64_t b = blockIdx.x;
     // LDS: yz [4 waves][Y][Z], xz [X][Z], xy [X*Y] (dense).  The reduction scratch of Emitter::finish lies over yz
     // (finish synchronises before it writes): two of these workgroups and one k_svm_gemm workgroup (69.6 KB) then
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     unsigned char* xy_s = xz_s + (size_t)X * Z;
     int64_t* red = reinterpret_cast<int64_t*>(lds8);
     const uint4* __restrict__ Vb = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(a.V) + b * (int64_t)X * Y * Z);
-    const int plane = Y * CPR;          // uint4 per x-plane
+    const int plane = Y * CPRm;         // uint4 per x-plane
 
     int roff[NM];
     bool rv[NM];
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     for (int m = 0; m < NM; ++m) {
         const int j = s + S * m;
         rv[m] = (s < S) && (j < Y);
-        roff[m] = min(j, Y - 1) * CPR + c;
+        roff[m] = min(j, Y - 1) * CPRm + cm;
     }
     // cross-lane sources (byte addresses for ds_bpermute); an invalid source is the lane itself (max(x,x) = x)
     int xsrc[6], ysrc[6];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
                 for (int j = 0; j < 2; ++j) u2[j] = pkmax_u16(u2[j], dpp_u32<0x128>(u2[j]));       // row_ror:8 -- the other row slot of the 16 lanes
             }
             const int q = ((lane >> 4) & 1) + 2 * (lane >> 5);
-            if (FCPR == 16 || (lane & 8) == 0)
+            if ((FCPR == 16 || (lane & 8) == 0) && cval)
                 *reinterpret_cast<uint32_t*>(xz_s + (size_t)i * Z + 16 * c + 4 * q) = u2[0] | (u2[1] << 8);
         } else {
             for (int t = 0; t < xsteps; ++t) {
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     // the wave's yz partial
 #pragma unroll
     for (int m = 0; m < NM; ++m)
-        if (rv[m])
+        if (rv[m] && cval)
             *reinterpret_cast<uint4*>(yz_s + ((size_t)wave * Y + s + S * m) * Z + 16 * c) =
                 make_uint4(yz[m][0] | (yz[m][1] << 8), yz[m][2] | (yz[m][3] << 8), yz[m][4] | (yz[m][5] << 8), yz[m][6] | (yz[m][7] << 8));
     __syncthreads();
@@ -211,8 +217,9 @@ template <int NM>
 void launch_u8_max(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hipStream_t st) {
     // rows of 128 / 256 voxels: the cross-lane steps on the VALU (RML_U8_XLANE=0: the ds_bpermute path, for A/B)
     static const bool xlane = [] { const char* e = getenv("RML_U8_XLANE"); return !e || atoi(e) != 0; }();
-    if (xlane && CPR == 8) launch_u8_max_f<NM, 8>(pp, CPR, S, lds_bytes, st);
-    else if (xlane && CPR == 16) launch_u8_max_f<NM, 16>(pp, CPR, S, lds_bytes, st);
+    const int G = S == 4 ? 16 : (S == 8 ? 8 : 0);     // lane geometry chosen by try_launch_u8_max (S = 64 / lanes per row)
+    if (xlane && G == 8) launch_u8_max_f<NM, 8>(pp, CPR, S, lds_bytes, st);
+    else if (xlane && G == 16) launch_u8_max_f<NM, 16>(pp, CPR, S, lds_bytes, st);
     else launch_u8_max_f<NM, 0>(pp, CPR, S, lds_bytes, st);
 }
 
@@ -222,20 +229,30 @@ bool rmlproj::try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
     static const bool allow = [] { const char* e = getenv("RML_U8_NATIVE"); return !e || atoi(e) != 0; }();
     const int X = pp.X, Y = pp.Y, Z = pp.Z;
     if (!allow || Z % 16 != 0 || Z / 16 > 64 || (reinterpret_cast<uintptr_t>(pp.V) & 15) != 0) return false;
-    const int CPR = Z / 16, S = 64 / CPR;
+    const int CPR = Z / 16;
+    // lane geometry: the row's own chunk count, or -- rows of 5..7 / 9..15 chunks whose planes then still fit 8 rows per lane -- the
+    // next power of two (RML_U8_PADGEOM=0: never), which moves the cross-lane steps from ds_bpermute to the VALU
+    static const bool padgeom = [] { const char* e = getenv("RML_U8_PADGEOM"); return !e || atoi(e) != 0; }();
+    int G = (CPR == 8 || CPR == 16) ? CPR : 0;
+    if (padgeom && G == 0) {
+        const int g2 = CPR > 8 && CPR < 16 ? 16 : (CPR > 4 && CPR < 8 ? 8 : 0);
+        if (g2 && (Y + 64 / g2 - 1) / (64 / g2) <= 8) G = g2;
+    }
+    const int S = 64 / (G ? G : CPR);
     const int nm = (Y + S - 1) / S;
+    const ProjParams& pg = pp;
     size_t lds_bytes = (size_t)X * Z + (((size_t)X * Y + 15) & ~(size_t)15) + (size_t)4 * Y * Z;
     if (lds_bytes < 64 * 8 + 64) lds_bytes = 64 * 8 + 64;      // Emitter::finish scratch
     if (nm > 8 || lds_bytes > 150 * 1024) return false;
     switch (nm) {       // rows per lane and plane: exact, so that no lane re-reads rows it does not need
-        case 1: launch_u8_max<1>(pp, CPR, S, lds_bytes, st); break;
-        case 2: launch_u8_max<2>(pp, CPR, S, lds_bytes, st); break;
-        case 3: launch_u8_max<3>(pp, CPR, S, lds_bytes, st); break;
-        case 4: launch_u8_max<4>(pp, CPR, S, lds_bytes, st); break;
-        case 5: launch_u8_max<5>(pp, CPR, S, lds_bytes, st); break;
-        case 6: launch_u8_max<6>(pp, CPR, S, lds_bytes, st); break;
-        case 7: launch_u8_max<7>(pp, CPR, S, lds_bytes, st); break;
-        default: launch_u8_max<8>(pp, CPR, S, lds_bytes, st); break;
+        case 1: launch_u8_max<1>(pg, CPR, S, lds_bytes, st); break;
+        case 2: launch_u8_max<2>(pg, CPR, S, lds_bytes, st); break;
+        case 3: launch_u8_max<3>(pg, CPR, S, lds_bytes, st); break;
+        case 4: launch_u8_max<4>(pg, CPR, S, lds_bytes, st); break;
+        case 5: launch_u8_max<5>(pg, CPR, S, lds_bytes, st); break;
+        case 6: launch_u8_max<6>(pg, CPR, S, lds_bytes, st); break;
+        case 7: launch_u8_max<7>(pg, CPR, S, lds_bytes, st); break;
+        default: launch_u8_max<8>(pg, CPR, S, lds_bytes, st); break;
     }
     return true;
 }
