@@ -2295,7 +2295,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     const bool part = ctx->gemm_cus_per_xcd > 0 && ctx->proj_stream != nullptr;
     const int gemm_cus = part ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
     const char* pge = getenv("RML_PIPE_GEMM");
-    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && pge && atoi(pge) == 0));
+    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && pge && pge[0] == '0'));
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
