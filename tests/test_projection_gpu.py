@@ -372,10 +372,13 @@ def test_reference_generated_data_rows(rml):
         np.testing.assert_array_equal(got, O.features_from_projections(g["xz"], g["yz"], g["xy"], (True, True, True), bool(sc)))
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 128), (10, 20, 128), (3, 5, 128), (5, 31, 256), (3, 7, 256), (22, 31, 176), (4, 9, 64)])
+@pytest.mark.parametrize("shape", [(64, 64, 128), (10, 20, 128), (3, 5, 128), (5, 31, 256), (3, 7, 256), (22, 31, 176), (4, 9, 64),
+                                   (6, 20, 96), (3, 9, 80), (5, 12, 208), (4, 32, 240), (3, 40, 176), (2, 70, 96)])
 def test_uint8_byte_kernel_lane_layouts_and_codes_only_output(rml, shape):
     """k_project_u8_max per lane layout: rows of 128 / 256 voxels take the cross-lane steps on the VALU (v_permlane32_swap /
-    v_permlane16_swap reduce-scatter, DPP moves), every other row length the ds_bpermute steps; and per output form: float rows
+    v_permlane16_swap reduce-scatter, DPP moves); rows of 5..7 / 9..15 chunks run in the next power-of-two lane geometry with idle
+    lanes (80, 96, 176, 208, 240 voxels) unless their planes then need more than 8 rows per lane (40 x 176, 70 x 96: the row's own
+    geometry); every other row length the ds_bpermute steps; and per output form: float rows
     (values widened through the Emitter) and the fused pipeline's codes-only first pass (bytes biased with one xor, statistics
     from v_dot4_u32_u8) -- both against NumPy on the same values, bit for bit."""
     import torch
