@@ -64,8 +64,12 @@ typedef struct rml_linear rml_linear;
 #define RML_MODE_MAX_NAN 3 /* the max-projection with NumPy's NaN policy (SURVEY 8 a-1'): a line that holds a NaN gives NaN, like
                               np.max.  Opt-in and not tuned: every shape runs on the general kernel (three passes over a frame, the
                               second and third from L2); uint8 volumes cannot hold a NaN and take the RML_MODE_MAX kernels.  A row with
-                              a NaN is off the code grid, so the SVM front doors score it on the float64 path and its scores are NaN
-                              (scikit-learn raises ValueError on such a row instead) */
+                              a NaN is off the code grid, so the SVM front doors score it on the float64 path -- where the NaN does
+                              NOT survive: the RBF epilogue clamps the squared distance with "d2 > 0 ? d2 : 0", which maps NaN to 0,
+                              so every kernel value of the row is 1 and its decision values are the finite, meaningless
+                              sum of the pair weights + intercept (scikit-learn raises ValueError on such a row instead).  Callers
+                              that may meet NaNs must test the projections themselves; pinned by
+                              tests/test_svm_gpu.py::test_nan_row_through_the_svm_is_finite_and_documented */
 
 /* element type of the volumes */
 #define RML_VOL_F32    0
@@ -161,6 +165,25 @@ int rml_project_planes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
  */
 int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                        int num_targets, int32_t* ijk, float* profiles, void* stream);
+
+/* The reference-faithful path in ONE pass over the volumes: derive the num_targets strongest targets of every frame
+ * (common.py:49-80, as rml_derive_targets) and slice the three planes through each of them (predict.py:98-107) into feature
+ * rows -- what predict.py does per frame when the SDK reports no target and get_derived_targets stands in
+ * (ground_truth_samples.py:357).  Row r = b*num_targets + t of every row output belongs to target t of frame b (ascending by
+ * energy, like rml_derive_targets).  The frame is streamed once for the three energy profiles (no sum planes through HBM);
+ * the planes of its targets are gathered right behind (4*D more bytes per target).
+ *   ijk      B*num_targets*3 int32 or NULL (the derived indices, as rml_derive_targets writes them)
+ *   profiles B*(X+Y+Z) float32 or NULL
+ *   feat, feat_q, row_*   B*num_targets rows, as rml_project
+ * Shapes without the fused kernel (rows that are not whole 16-byte quads, Z > 256, odd part of Z/4 above 15, a misaligned V)
+ * run rml_derive_targets + rml_project_slices internally.  rml_derive_slice_supported: 1 when the one-pass kernel takes the
+ * shape (V may be NULL: alignment not checked). */
+int rml_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,
+                     int32_t* ijk, float* profiles, float scale_div, uint32_t mask,
+                     float* feat, int64_t ld_feat,
+                     uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
+                     void* stream);
+int rml_derive_slice_supported(const void* V, int vdtype, int X, int Y, int Z, int num_targets);
 
 /* Assemble feature rows from already separate projection planes (the list-of-tuples
  * input of common.process_samples, common.py:123-149, stacked per plane), zoom 1.
@@ -261,6 +284,15 @@ int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, i
                     int mode, const int32_t* ijk, float scale_div, uint32_t mask,
                     double* dec_ovo, double* dec_ovr, double* proba,
                     int32_t* label_vote, int32_t* label_calib, void* stream);
+
+/* The same front door for the reference-faithful projection with DERIVED targets: per frame the strongest derived target
+ * (common.py:49-80, num_targets = 1), the three slices through it (predict.py:98-107) and the SVM outputs, the frame read once
+ * (+ 4*D bytes for the slices).  ijk_out: B*3 int32 or NULL (the derived indices).  RML_ERR_UNSUPPORTED when
+ * rml_derive_slice_supported(V, ...) is 0: call rml_derive_targets and rml_project_svm(RML_MODE_SLICE, ijk) then. */
+int rml_derive_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
+                           float scale_div, uint32_t mask, int32_t* ijk_out,
+                           double* dec_ovo, double* dec_ovr, double* proba,
+                           int32_t* label_vote, int32_t* label_calib, void* stream);
 
 /* ---- linear classifier (SGDClassifier(loss='log'), train.py:350-381; predict 421,433) --- */
 int rml_linear_load(rml_ctx* ctx, const double* coef /* host (C,D) */, const double* intercept /* host C */,

@@ -42,6 +42,9 @@ SIGNATURES = {
     "rml_project_planes": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rml_derive_slice": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_uint32,
+                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_derive_slice_supported": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "rml_assemble_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                       c_uint32, c_void_p, c_int64, c_void_p]),
     "rml_zoom_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_float,
@@ -61,6 +64,8 @@ SIGNATURES = {
     "rml_svm_kernel_matrix": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "rml_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                 c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rml_derive_project_svm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_uint32, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rml_linear_load": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, C.POINTER(c_void_p)]),
     "rml_linear_free": (c_int, [c_void_p, c_void_p]),
     "rml_linear_decision": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

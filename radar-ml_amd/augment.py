@@ -129,17 +129,25 @@ class DataGenerator(object):
         top = counts[0][1]
         return {cls: (top / n if self.balance else 1) for cls, n in counts}
 
-    def flow(self, x, y, batch_size=32):
-        """Generator protocol of train.py:52-83: walks ``x`` / ``y`` in slices of ``batch_size`` (the last one shorter), yields
-        ``(augmented tuples, augmented labels)`` per slice and starts over when the data set is exhausted -- it never stops, the
-        caller counts the batches (train.py:508-515).  (The reference can also dump every input batch to a pickle on the way;
-        that debugging aid is not part of the path.)"""
+    def flow(self, x, y, batch_size=32, save_to_dir=None, save_prefix='./datasets/augment'):
+        """Generator protocol of train.py:52-83 (same keyword arguments): walks ``x`` / ``y`` in slices of ``batch_size`` (the
+        last one shorter), yields ``(augmented tuples, augmented labels)`` per slice and starts over when the data set is
+        exhausted -- it never stops, the caller counts the batches (train.py:508-515).  With ``save_to_dir`` set, every INPUT
+        slice is pickled after its batch was consumed, as the reference's debugging aid does (train.py:207-211: the file goes
+        under ``save_prefix``, named by epoch and slice start; ``save_to_dir`` itself is only the switch there too)."""
         weights = self._class_weights(y)
         n = len(x)
+        epoch = 0
         while True:
             for lo in range(0, n, batch_size):
                 hi = min(lo + batch_size, n)
                 yield self._augment(x[lo:hi], y[lo:hi], weights)
+                if save_to_dir is not None:
+                    import os
+                    import pickle
+                    with open(os.path.join(save_prefix, 'batch_%d_%d.pickle' % (epoch, lo)), 'wb') as fp:
+                        pickle.dump({'x_batch': x[lo:hi], 'y_batch': y[lo:hi]}, fp)
+            epoch += 1
 
     def augment_dataset(self, x, y):
         """One pass of ``flow`` over the whole data set (what an epoch of train.py:506-515 appends to the training set) as ONE

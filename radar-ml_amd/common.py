@@ -112,7 +112,8 @@ def _slice_indices(ijk, B, X, Y, Z, dev, validate=True):
     """ijk as (B,3) or (B,T,3) (numpy / torch, any integer dtype) -> (contiguous int32 CUDA tensor (B*T,3), T).
     Raises like the reference's NumPy indexing would: one (i,j,k) (or T of them) per frame, every index within
     [-size, size) (Python negative-index wrap) -- the kernel never sees an index it would have to clamp.  The range check
-    runs on the caller's integers BEFORE the int32 cast (an int64 index must not wrap into range); host arrays are checked
+    runs on the caller's integers widened to int64, BEFORE the int32 cast (an int64 index must not wrap into range, a narrow
+    dtype must not wrap the bound); host arrays are checked
     on the host, device tensors cost one synchronising read-back.  ``validate=False``: indices this package derived itself
     (derive_targets) -- in range by construction, no host synchronisation on the asynchronous path."""
     torch = _torch()
@@ -128,10 +129,19 @@ def _slice_indices(ijk, B, X, Y, Z, dev, validate=True):
         raise ValueError("ijk holds no target")
     if t.dtype.is_floating_point or t.dtype == torch.bool:
         raise IndexError("ijk must hold integers")
+    if t.dtype in (getattr(torch, "uint16", None), getattr(torch, "uint32", None), getattr(torch, "uint64", None)):
+        # torch has no comparison kernels for the wide unsigned types: through NumPy (a uint64 above int64's range is out of
+        # bounds for any volume and must not wrap)
+        h = t.cpu().numpy()
+        if h.size and int(h.max()) > np.iinfo(np.int64).max:
+            raise IndexError("index out of bounds: %d" % int(h.max()))
+        t = torch.from_numpy(h.astype(np.int64))
     if validate:
-        flat = t.reshape(-1, 3)
-        size = torch.tensor([X, Y, Z], dtype=flat.dtype, device=flat.device)
-        bad = ((flat >= size) | (flat < -size)).any(dim=0).cpu().numpy()       # in the caller's dtype, where the tensor lives
+        # widened to int64 BEFORE comparing: in a narrow caller dtype -size wraps (uint8) or does not fit (int8 with Z = 128), and
+        # an int64 index must be checked before the int32 cast below could wrap it into range
+        flat = t.reshape(-1, 3).to(torch.int64)
+        size = torch.tensor([X, Y, Z], dtype=torch.int64, device=flat.device)
+        bad = ((flat >= size) | (flat < -size)).any(dim=0).cpu().numpy()       # where the tensor lives
         for ax in range(3):
             if bad[ax]:
                 raise IndexError("index out of bounds for axis %d with size %d" % (ax, (X, Y, Z)[ax]))
@@ -186,14 +196,15 @@ def project(volumes, mode="max", ijk=None, return_numpy=None):
 
 
 def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, yz=True, xy=True), scale=False,
-                    out=None, codes=False, num_targets=1, device=None):
+                    out=None, codes=False, num_targets=1, device=None, return_ijk=False):
     """Fused batched front door: (B,X,Y,Z) volumes -> (B,D) float32 feature rows in one pass over
     the volumes (projection + ``process_samples`` at zoom 1).  Returns a CUDA tensor; with
     ``codes=True`` returns ``(feat, codes_u8, row_isum, row_isq, row_flags)`` for the exact SVM path.
 
     mode='slice' takes ``ijk`` as (B,3) or -- several targets per frame, the reference's ``for target in targets`` over one
     image (predict.py:93-119) -- (B,T,3): the result then has B*T rows, frame-major (row b*T+t), and no volume is
-    duplicated.  Without ``ijk`` the ``num_targets`` strongest derived targets of every frame are used (common.py:49-80).
+    duplicated.  Without ``ijk`` the ``num_targets`` strongest derived targets of every frame are used (common.py:49-80);
+    ``return_ijk=True`` appends the (B,T,3) int32 indices the rows were sliced at to the result.
     """
     torch = _torch()
     lib = _lib.load()
@@ -208,13 +219,19 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
     m = _lib.MODES[mode]
     ijk_t = None
     T = 1
+    fused_derive = False
     if m == _lib.MODE_SLICE:
         derived = False
         if ijk is None:
-            # no SDK targets: derive the strongest return(s) per frame on the GPU (common.py:49-80), then slice there
-            ijk = derive_targets(v, num_targets)
+            # no SDK targets: derive the strongest return(s) per frame on the GPU (common.py:49-80) and slice there -- one pass
+            # over the volumes where the shape has the fused kernel (rml_derive_slice), two launches otherwise
             derived = True
-        ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
+            T = int(num_targets)
+            fused_derive = bool(lib.rml_derive_slice_supported(_lib.ptr(v), vdt, X, Y, Z, T))
+            if not fused_derive:
+                ijk = derive_targets(v, num_targets)
+        if not fused_derive:
+            ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
     R = B * T                           # output rows
     feat = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=dev)
     if feat.shape[0] != R or feat.shape[1] < D or feat.device != dev:
@@ -228,7 +245,12 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
         isq = torch.empty((R,), dtype=torch.int64, device=dev)
         flags = torch.empty((R,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        if T > 1:
+        if fused_derive:
+            ijk_t = torch.empty((B, T, 3), dtype=torch.int32, device=dev) if return_ijk else None
+            _lib.check(lib.rml_derive_slice(ctx, _lib.ptr(v), vdt, B, X, Y, Z, T, _lib.ptr(ijk_t), None, float(RADAR_MAX) if scale else 0.0,
+                                            bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                            _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_derive_slice")
+        elif T > 1:
             _lib.check(lib.rml_project_slices(ctx, _lib.ptr(v), vdt, B, X, Y, Z, T, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
                                               bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                               _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project_slices")
@@ -236,9 +258,11 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
             _lib.check(lib.rml_project(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
                                        bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                        _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
-    if codes:
-        return feat, q, isum, isq, flags
-    return feat
+    res = (feat, q, isum, isq, flags) if codes else feat
+    if return_ijk:
+        ijk_r = ijk_t.reshape(B, T, 3) if ijk_t is not None else None
+        return (res + (ijk_r,)) if codes else (res, ijk_r)
+    return res
 
 
 def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),

@@ -678,6 +678,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
 
 void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
     pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.rpl = 1; pp.o = o;
+    pp.ntgt = 1; pp.ijk_out = nullptr; pp.profiles = nullptr; pp.wave_lds = 0;
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
 }
@@ -697,7 +698,8 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
     }
     else if (mode == RML_MODE_SLICE) {
         RML_REQUIRE(pp.ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
-        hipLaunchKernelGGL(k_project_slice<VT>, dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
+        if (!try_launch_slice(pp, (int)sizeof(VT), st))        // rows that are not whole quads: the general kernel
+            hipLaunchKernelGGL(k_project_slice<VT>, dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
     } else {
         RML_REQUIRE(false, RML_ERR_INVALID, "rml_project: unknown mode %d", mode);
     }
@@ -726,6 +728,20 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     const int num_cu = !ctx ? 256 : ((ctx->gemm_cus_per_xcd > 0 && st == ctx->proj_stream) ? 8 * (32 - ctx->gemm_cus_per_xcd) : ctx->num_cu);
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// derive (-> slice) in one pass where the shape has a fused kernel: RML_OK when launched, RML_ERR_UNSUPPORTED (no message: the
+// callers fall back to the two-kernel path) otherwise.  o.sel == 0: derive only.
+int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,
+                            int32_t* ijk_out, float* profiles, const ProjOut& o, hipStream_t st) {
+    if (B == 0) return RML_OK;
+    ProjParams pp;
+    fill_params(pp, V, B, X, Y, Z, nullptr, o);
+    pp.ntgt = num_targets; pp.ijk_out = ijk_out; pp.profiles = profiles;
+    const int num_cu = !ctx ? 256 : ((ctx->gemm_cus_per_xcd > 0 && st == ctx->proj_stream) ? 8 * (32 - ctx->gemm_cus_per_xcd) : ctx->num_cu);
+    if (!try_launch_derive_slice(pp, vdtype == RML_VOL_U8 ? 1 : 4, num_cu, st)) return RML_ERR_UNSUPPORTED;
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
@@ -760,6 +776,74 @@ extern "C" int rml_project_slices(rml_ctx* ctx, const void* V, int vdtype, int64
     RML_REQUIRE(B == 0 || ijk != nullptr, RML_ERR_INVALID, "rml_project_slices: ijk is NULL");
     return project_rows(ctx, V, vdtype, B * T, X, Y, Z, RML_MODE_SLICE, T, ijk, scale_div, mask, feat, ld_feat, feat_q, ld_q, row_isum,
                         row_isq, row_flags, stream);
+}
+
+// the row outputs of rml_project / rml_project_slices / rml_derive_slice as a ProjOut
+static void rows_out(ProjOut& o, int X, int Y, int Z, uint32_t mask, float scale_div, float* feat, int64_t ld_feat, uint8_t* feat_q,
+                     int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags) {
+    int64_t off = 0;
+    for (int pl = 0; pl < 3; ++pl) {
+        if (mask & (1u << pl)) {
+            o.p[pl] = feat ? feat + off : nullptr;
+            o.stride[pl] = ld_feat;
+            o.q[pl] = feat_q ? feat_q + off : nullptr;
+            off += plane_len(pl, X, Y, Z);
+        }
+    }
+    o.sel = mask & RML_MASK_ALL;
+    o.qstride = ld_q;
+    o.qrow = feat_q; o.qD = rml_feature_len(X, Y, Z, mask);
+    o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
+    o.scale_div = scale_div;
+}
+
+static int derive_two_kernels(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets, int32_t* ijk,
+                              float* profiles, hipStream_t st);
+
+extern "C" int rml_derive_slice_supported(const void* V, int vdtype, int X, int Y, int Z, int num_targets) {
+    if (X <= 0 || Y <= 0 || Z <= 0 || (vdtype != RML_VOL_F32 && vdtype != RML_VOL_U8)) return 0;
+    const size_t quad = vdtype == RML_VOL_U8 ? 4 : 16;
+    if (V && (reinterpret_cast<uintptr_t>(V) & (quad - 1))) return 0;
+    return derive_slice_shape_ok(X, Y, Z, num_targets) ? 1 : 0;
+}
+
+extern "C" int rml_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,
+                                int32_t* ijk, float* profiles, float scale_div, uint32_t mask,
+                                float* feat, int64_t ld_feat, uint8_t* feat_q, int64_t ld_q,
+                                int32_t* row_isum, int64_t* row_isq, int32_t* row_flags, void* stream) {
+    RML_REQUIRE(ctx && B >= 0 && X > 0 && Y > 0 && Z > 0, RML_ERR_INVALID, "rml_derive_slice: bad arguments");
+    if (B == 0) return RML_OK;
+    RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_derive_slice: V is NULL");
+    RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_derive_slice: unknown volume dtype %d", vdtype);
+    RML_REQUIRE((mask & RML_MASK_ALL) != 0, RML_ERR_INVALID, "rml_derive_slice: empty projection mask");
+    RML_REQUIRE(num_targets >= 1 && num_targets <= X && num_targets <= Y && num_targets <= Z, RML_ERR_INVALID,
+                "rml_derive_slice: num_targets out of range");
+    RML_REQUIRE(B * (int64_t)num_targets < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_derive_slice: too many rows for one launch");
+    const int64_t D = rml_feature_len(X, Y, Z, mask);
+    RML_REQUIRE(!feat || ld_feat >= D, RML_ERR_INVALID, "rml_derive_slice: ld_feat < D");
+    RML_REQUIRE(!feat_q || (ld_q >= D && ld_q % 4 == 0 && (reinterpret_cast<uintptr_t>(feat_q) & 3) == 0),
+                RML_ERR_INVALID, "rml_derive_slice: feat_q needs ld_q >= D, ld_q %% 4 == 0 and 4-byte alignment");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProjOut o{};
+    rows_out(o, X, Y, Z, mask, scale_div, feat, ld_feat, feat_q, ld_q, row_isum, row_isq, row_flags);
+    int rc = rml_launch_derive_slice(ctx, V, vdtype, B, X, Y, Z, num_targets, ijk, profiles, o, st);
+    if (rc != RML_ERR_UNSUPPORTED) return rc;
+    // shapes without a fused kernel: sum planes -> profiles + top-n, then the slices (the (i,j,k) go through the caller's buffer or
+    // the context's workspace)
+    rml_ctx_guard guard(ctx, st);
+    int32_t* ijk_w = ijk;
+    if (!ijk_w) {
+        // behind the sum planes of derive_two_kernels in the shared workspace
+        const size_t planes = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
+        void* ws = nullptr;
+        rc = rml_ws_reserve(ctx, planes + (size_t)B * num_targets * 3 * sizeof(int32_t), &ws);
+        if (rc) return rc;
+        ijk_w = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(ws) + planes);
+    }
+    rc = derive_two_kernels(ctx, V, vdtype, B, X, Y, Z, num_targets, ijk_w, profiles, st);
+    if (rc) return rc;
+    return rml_launch_project(ctx, V, vdtype, B * num_targets, X, Y, Z, RML_MODE_SLICE, ijk_w, o, st, num_targets);
 }
 
 static int project_rows(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode, int tpf,
@@ -820,7 +904,17 @@ extern "C" int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64
     RML_HIP(hipSetDevice(ctx->device));
     if (B == 0) return RML_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // one pass, no workspace, where the shape has the fused kernel (k_derive_slice without outputs)
+    ProjOut none{};
+    int rc1 = rml_launch_derive_slice(ctx, V, vdtype, B, X, Y, Z, num_targets, ijk, profiles, none, st);
+    if (rc1 != RML_ERR_UNSUPPORTED) return rc1;
     rml_ctx_guard guard(ctx, st);           // shared workspace
+    return derive_two_kernels(ctx, V, vdtype, B, X, Y, Z, num_targets, ijk, profiles, st);
+}
+
+// sum planes through the workspace, then profiles + top-n (any shape); the caller holds the context guard
+static int derive_two_kernels(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets, int32_t* ijk,
+                              float* profiles, hipStream_t st) {
     // workspace: sum planes xz (B,X,Z) and yz (B,Y,Z)
     size_t need = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
     void* ws = nullptr;

@@ -19,6 +19,11 @@ struct ProjParams {
     int rpl;            // k_project_wave: real rows per 64-quad virtual row, decided by the launcher (wave_kernel_rpl)
     ProjOut o;
     int vec_ok[3];   // float4 stores allowed for plane pl (16-B aligned base and stride)
+    // k_derive_slice (project_slice.hip): targets per frame, optional (i,j,k) / profile outputs, LDS bytes per wave
+    int ntgt;
+    int32_t* ijk_out;
+    float* profiles;
+    int wave_lds;
 };
 
 template <int MODE> struct Op;
@@ -282,6 +287,12 @@ template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b
 // project_lin.hip: the linear-plane wave-per-frame kernel for rows that do not fill a load instruction (32 < Z/4 < 64); returns
 // true when it took the launch
 bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st);
+
+// project_slice.hip: mode SLICE with (i,j,k) given (wave per output row), and the fused derive -> slice pass (persistent, wave per
+// frame; pp.ntgt / ijk_out / profiles set by the caller); true when they took the launch
+bool try_launch_slice(const ProjParams& pp, int vbytes, hipStream_t st);
+bool try_launch_derive_slice(const ProjParams& pp, int vbytes, int num_cu, hipStream_t st);
+bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt);
 
 // project_u8.hip: the byte-native max-projection of uint8 volumes (rows of whole 16-byte chunks); true when it took the launch
 bool try_launch_u8_max(const ProjParams& pp, hipStream_t st);

@@ -1,0 +1,434 @@
+// The reference-faithful projection path: plane SLICES through a target voxel, and the derived target itself.
+//
+// Reference sites replaced (paths in goruck/radar-ml):
+//   slices            predict.py:102-107, ground_truth_samples.py:413-419:  yz = V[i,:,:], xz = V[:,j,:], xy = V[:,:,k]
+//   derived targets   common.py:49-80 (DerivedTarget.get_derived_targets): s_theta[i] = sum_jk V, s_phi[j] = sum_ik V,
+//                     s_r[k] = sum_ij V, arg-top-n of each (ascending by value), zipped to (i,j,k) triples
+//   feature assembly  common.py:141-148 at zoom 1 (the shared Emitter: float rows, biased uint8 codes, row statistics)
+//
+// k_slice_rows<VT>: ONE WAVE per output row gathers the three planes.  yz is a contiguous plane (1 KB per load instruction),
+// xz is X contiguous rows of Z values (whole 16-byte quads, lanes run over (row, quad)), xy is the only true gather: X*Y
+// single values one row apart.  A lane takes FOUR consecutive (i,j) cells so that its float / code stores are whole 16- / 4-byte
+// pieces.  Every load of a batch is issued before the first store (the old kernel's scalar loop waited for every element).
+// Algorithmic bytes per row: 4*D read + the outputs.  The floor of what the memory system can do is higher: every xy value
+// lives in its own 128-byte request (rows are >= 512 B apart), so the plane costs X*Y*128 B whatever the kernel does.
+//
+// k_derive_slice<VT, P, U>: persistent, ONE WAVE per frame.  The frame is streamed once as the linear array of quads it is
+// (64 quads = 1 KB per instruction, non-temporal, the next group of U instructions in flight in a second register buffer across
+// plane and frame boundaries -- the structure of k_project_lin), and all three energy profiles come out of that one pass:
+//   s_r[k]      element-wise float4 accumulators: instruction t of a plane holds columns (64 t + lane) mod Z/4, which repeats
+//               with period P = (Z/4) / gcd(Z/4, 64) instructions -> P float4 registers, folded once per frame through LDS;
+//   s_phi[j]    every quad belongs to one row: its horizontal sum goes to a wave-private LDS strip [quad of the plane] with
+//               ds_add_f32 (one lane per address: program order, deterministic), lane j folds row j once per frame;
+//   s_theta[i]  the lane's running sum over the plane, one butterfly over the wave per plane.
+// No sum planes through HBM (the old path wrote X*Z + Y*Z floats per frame and read them back), no second launch for the
+// top-n: the wave does it on its LDS profiles (wave arg-max with shuffles; ties as radarml.h documents: the lower index ranks
+// lower), then gathers the planes of every target with the code above while its next frame's first loads are already in
+// flight, and leaves through the Emitter.  Sums of integer-valued data are exact in float32 in any order (< 2^24): the indices
+// are bit-exact against NumPy; on other data the float32 rounding follows this kernel's (fixed) order.
+#include "project_shared.h"
+
+namespace {
+
+using namespace rmlproj;
+
+template <typename VT> struct Cell;
+template <> struct Cell<float> {
+    typedef float4 Q;
+    static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, const float4& v) { em.put4(pl, idx, v); }
+    static __device__ __forceinline__ float4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+    static __device__ __forceinline__ float4 widen(const float4& v) { return v; }
+};
+template <> struct Cell<uint8_t> {
+    typedef uint32_t Q;
+    static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, uint32_t w) { em.put_bytes4(pl, idx, w); }
+    static __device__ __forceinline__ uint32_t pack(uint8_t a, uint8_t b, uint8_t c, uint8_t d) {
+        return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+    }
+    static __device__ __forceinline__ float4 widen(uint32_t w) { return bytes_to_float4(w); }
+};
+
+// floor(q / d) for 0 <= q < 2^22 through the float reciprocal, corrected by one step either way
+__device__ __forceinline__ int div_small(int q, int d, float rcp) {
+    int r = (int)((float)q * rcp);
+    r = (r * d > q) ? r - 1 : r;
+    r = ((r + 1) * d <= q) ? r + 1 : r;
+    return r;
+}
+
+// the three planes through (i, j, k) of the frame at Vf, by one wave; indices already wrapped into range
+template <typename VT, int UB>
+__device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int j, int k, int X, int Y, int Z, int ZQ,
+                                           Emitter& em, int lane) {
+    typedef typename Cell<VT>::Q QT;
+    const QT* __restrict__ Vq = reinterpret_cast<const QT*>(Vf);
+    const int pq = Y * ZQ;
+    const uint32_t sel = em.a.o.sel;
+    if (sel & 2u) {                                     // yz = V[i, :, :]: the plane as it lies in memory
+        const QT* __restrict__ src = Vq + (int64_t)i * pq;
+        for (int base = 0; base < pq; base += 64 * UB) {
+            QT v[UB];
+            static_for<UB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int q = base + u * 64 + lane;
+                v[u] = src[q < pq ? q : pq - 1];
+            });
+            static_for<UB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int q = base + u * 64 + lane;
+                if (q < pq) Cell<VT>::emit4(em, 1, (int64_t)q * 4, v[u]);
+            });
+        }
+    }
+    if (sel & 1u) {                                     // xz = V[:, j, :]: X rows of Z/4 quads, one plane apart
+        const int n = X * ZQ;
+        const float rcp = 1.0f / (float)ZQ;
+        const QT* __restrict__ src = Vq + (int64_t)j * ZQ;
+        for (int base = 0; base < n; base += 64 * UB) {
+            QT v[UB];
+            static_for<UB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                int q = base + u * 64 + lane;
+                q = q < n ? q : n - 1;
+                const int ii = div_small(q, ZQ, rcp);
+                v[u] = src[(int64_t)ii * pq + (q - ii * ZQ)];
+            });
+            static_for<UB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int q = base + u * 64 + lane;
+                if (q < n) Cell<VT>::emit4(em, 0, (int64_t)q * 4, v[u]);
+            });
+        }
+    }
+    if (sel & 4u) {                                     // xy = V[:, :, k]: one value per row of the volume
+        const int n = X * Y, n4 = n >> 2;
+        const VT* __restrict__ src = Vf + k;
+        constexpr int UG = UB / 2 > 0 ? UB / 2 : 1;
+        for (int base = 0; base < n4; base += 64 * UG) {
+            VT v[UG][4];
+            static_for<UG>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                int q = base + u * 64 + lane;
+                q = q < n4 ? q : n4 - 1;
+                const VT* __restrict__ s4 = src + (int64_t)q * 4 * Z;
+                v[u][0] = s4[0]; v[u][1] = s4[Z]; v[u][2] = s4[2 * (int64_t)Z]; v[u][3] = s4[3 * (int64_t)Z];
+            });
+            static_for<UG>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int q = base + u * 64 + lane;
+                if (q < n4) Cell<VT>::emit4(em, 2, (int64_t)q * 4, Cell<VT>::pack(v[u][0], v[u][1], v[u][2], v[u][3]));
+            });
+        }
+        const int idx = n4 * 4 + lane;
+        if (lane < (n & 3)) em.put1(2, idx, (float)src[(int64_t)idx * Z]);
+    }
+}
+
+// Python's negative-index wrap (the host validated the range; clamp defensively)
+__device__ __forceinline__ int wrap_index(int v, int n) {
+    v = v < 0 ? v + n : v;
+    return min(max(v, 0), n - 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// mode SLICE with (i,j,k) given: one wave per output row (row r reads frame r / tpf)
+// ------------------------------------------------------------------------------------------
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void k_slice_rows(ProjParams a) {
+    if (a.o.skip_if_set && *a.o.skip_if_set) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= a.B) return;
+    const int X = a.X, Y = a.Y, Z = a.Z;
+    const VT* __restrict__ Vf = static_cast<const VT*>(a.V) + (r / a.tpf) * (int64_t)X * Y * Z;
+    const int i = wrap_index(__builtin_amdgcn_readfirstlane(a.ijk[r * 3 + 0]), X);
+    const int j = wrap_index(__builtin_amdgcn_readfirstlane(a.ijk[r * 3 + 1]), Y);
+    const int k = wrap_index(__builtin_amdgcn_readfirstlane(a.ijk[r * 3 + 2]), Z);
+    Emitter em(a, r);
+    slice_emit<VT, 8>(Vf, i, j, k, X, Y, Z, a.ZQ, em, lane);
+    em.finish_wave(lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// derive -> slice, fused: persistent, one wave per frame (see the header comment)
+// ------------------------------------------------------------------------------------------
+template <typename VT, int P, int U>
+__global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
+    static_assert(U % P == 0, "the column of an instruction must be a compile-time function of its slot in the group");
+    typedef typename Quad<VT>::T QT;
+    const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t cf = (int64_t)blockIdx.x * 4 + wave;        // frame being reduced
+    if (cf >= a.B) return;
+    const QT* __restrict__ Vall = reinterpret_cast<const QT*>(a.V);
+    const int pq = Y * ZQ;                              // quads per plane
+    const int64_t fq = (int64_t)X * pq;
+    const int NI = (pq + 63) >> 6;                      // load instructions per plane
+    const int NG = (NI + U - 1) / U;                    // groups of U instructions per plane (the last one may run past it)
+    const int GP = X * NG;                              // groups per frame
+    const int GPe = GP + (GP & 1);                      // the two register buffers alternate statically: an odd frame gets an idle group
+    const int T = a.ntgt;
+    // wave-private LDS: [strip: the row sums per quad of a plane, later the staged s_r accumulators][s_theta | s_phi | s_r][targets]
+    extern __shared__ __align__(16) unsigned char ds_smem[];
+    unsigned char* mine = ds_smem + (size_t)wave * a.wave_lds;
+    float* strip = reinterpret_cast<float*>(mine);
+    const int strip_n = NG * U * 64;
+    const int strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
+    float* prof = strip + strip_alloc;
+    int* tgt = reinterpret_cast<int*>(prof + ((X + Y + Z + 3) & ~3));
+    for (int q = lane; q < strip_n; q += 64) strip[q] = 0.0f;
+
+    // load cursor, one group ahead of the reduction; frames are assigned statically (wave w: w, w + #waves, ...)
+    int64_t lf = cf;
+    int lgi = 0;                                        // group of the frame (0 .. GPe-1)
+    int lg = 0;                                         // group of the plane
+    const QT* __restrict__ lV = Vall + lf * fq;
+    const uint32_t qlast = (uint32_t)(pq - 1);
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++lgi; ++lg;
+        if (lgi >= GP) {
+            if (lgi == GPe) {                           // next frame of this wave; past the end: re-read (never consumed)
+                lgi = 0; lg = 0;
+                const int64_t nf = lf + stride;
+                lf = nf < a.B ? nf : lf;
+                lV = Vall + lf * fq;
+            } else {
+                lg = 0;                                 // the idle group of an odd frame re-reads the last plane's first group
+            }
+        } else if (lg == NG) {
+            lg = 0;
+            lV += pq;
+        }
+    };
+    QT buf[2][U];
+    auto fetch = [&](QT (&dst)[U]) __attribute__((always_inline)) {
+        uint32_t q0 = (uint32_t)(lg * U * 64 + lane);   // opaque per step: no hoisted per-instruction offsets kept alive
+        asm volatile("" : "+v"(q0));
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const uint32_t q = q0 + (uint32_t)(u * 64);
+            // unconditional: lanes past the plane re-read its last quad and are zeroed after the load
+            if constexpr (sizeof(VT) == 4) {
+                typedef float v4f_t __attribute__((ext_vector_type(4)));
+                v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(lV + (q < qlast ? q : qlast)));
+                dst[u] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                dst[u] = __builtin_nontemporal_load(lV + (q < qlast ? q : qlast));
+            }
+        });
+    };
+    Emitter em(a, cf * T);
+    fetch(buf[0]);
+    for (; cf < a.B; cf += stride) {
+        float4 accr[P];
+        static_for<P>([&](auto pc) { accr[decltype(pc)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
+        float th = 0.0f;
+        int ci = 0, cg = 0;
+        for (int gi = 0; gi < GPe; gi += 2) {
+            static_for<2>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                advance();
+                fetch(buf[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the software pipeline as written (see k_project_wave)
+                const int lim = (gi + s) < GP ? pq : 0; // the idle group contributes nothing
+                const int q0 = cg * U * 64 + lane;
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const int q = q0 + u * 64;
+                    float4 v = Cell<VT>::widen(buf[s & 1][u]);
+                    const bool in = q < lim;
+                    v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+                    const float h = (v.x + v.y) + (v.z + v.w);
+                    th += h;
+                    accr[u % P].x += v.x; accr[u % P].y += v.y; accr[u % P].z += v.z; accr[u % P].w += v.w;
+                    asm volatile("" : "+v"(accr[u % P].x), "+v"(accr[u % P].y), "+v"(accr[u % P].z), "+v"(accr[u % P].w));  // pin the update here
+                    __hip_atomic_fetch_add(strip + q, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                });
+                asm volatile("" : "+v"(th));
+                __builtin_amdgcn_sched_barrier(0);
+                if ((gi + s) < GP) {
+                    ++cg;
+                    if (cg == NG) {                     // plane ci of frame cf is complete
+                        float tot = th;                 // butterfly over the wave: a fixed order, every lane ends with the total
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+                        if (lane == 0) prof[ci] = tot;
+                        th = 0.0f;
+                        cg = 0; ++ci;
+                    }
+                }
+            });
+        }
+        // ---- the frame is in: profiles, top-n, planes.  The first group of this wave's next frame is in flight meanwhile. ----
+        // (the LDS hand-offs below are between lanes of ONE wave: the DS unit runs a wave's instructions in order; the fences
+        // only keep the compiler from moving an access across a hand-off)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // s_phi[j]: row j = quads [j Z/4, (j+1) Z/4) of the strip
+        for (int j = lane; j < Y; j += 64) {
+            const float* rowp = strip + j * ZQ;
+            float sum = 0.0f;
+            for (int q = 0; q < ZQ; ++q) sum += rowp[q];
+            prof[X + j] = sum;
+        }
+        // s_r[k]: the P accumulators cover quads 0 .. 64 P - 1 of the linear plane modulo its period; column c = q mod Z/4
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float4* st4 = reinterpret_cast<float4*>(strip);
+        static_for<P>([&](auto pc) { constexpr int p = decltype(pc)::value; st4[p * 64 + lane] = accr[p]; });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int c = lane; c < ZQ; c += 64) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int m = c; m < 64 * P; m += ZQ) {
+                const float4 t = st4[m];
+                sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+            }
+            float* dst = prof + X + Y + 4 * c;          // X + Y need not be a multiple of four: no 16-byte store
+            dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z; dst[3] = sum.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            const int zn = strip_n > P * 256 ? strip_n : P * 256;
+            for (int q = lane; q < zn; q += 64) strip[q] = 0.0f;       // the next frame accumulates into a clean strip
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int NPROF = X + Y + Z;
+        if (a.profiles)
+            for (int t = lane; t < NPROF; t += 64) a.profiles[cf * NPROF + t] = prof[t];
+        // arg-top-T of each profile, ascending by value (largest last); ties: the higher index is the larger (radarml.h)
+        for (int ax = 0; ax < 3; ++ax) {
+            float* sp = prof + (ax == 0 ? 0 : (ax == 1 ? X : X + Y));
+            const int L = ax == 0 ? X : (ax == 1 ? Y : Z);
+            for (int t = 0; t < T; ++t) {
+                float bv = -INFINITY;
+                int bi = -1;
+                for (int q = lane; q < L; q += 64) {
+                    float v = sp[q];
+                    v = (v != v) ? -INFINITY : v;
+                    if (bi < 0 || v >= bv) { bv = v; bi = q; }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off);
+                    const int oi = __shfl_xor(bi, off);
+                    const bool take = (ov > bv) || (ov == bv && oi > bi);
+                    bv = take ? ov : bv;
+                    bi = take ? oi : bi;
+                }
+                const int best = __builtin_amdgcn_readfirstlane(bi);
+                if (lane == 0) {
+                    sp[best] = -INFINITY;
+                    tgt[(T - 1 - t) * 3 + ax] = best;
+                    if (a.ijk_out) a.ijk_out[(cf * T + (T - 1 - t)) * 3 + ax] = best;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        if (a.o.sel) {
+            const VT* __restrict__ Vf = static_cast<const VT*>(a.V) + cf * (int64_t)X * Y * Z;
+            for (int t = 0; t < T; ++t) {
+                const int i = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 0]);
+                const int j = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 1]);
+                const int k = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 2]);
+                em.reset(cf * T + t);
+                slice_emit<VT, 4>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
+                em.finish_wave(lane);
+            }
+        }
+    }
+}
+
+int odd_part(int v) { while (v > 0 && !(v & 1)) v >>= 1; return v; }
+
+struct DeriveGeom { int P, U, NG, strip_alloc; size_t wave_lds; };
+
+bool derive_geom(int X, int Y, int Z, int ntgt, DeriveGeom* g) {
+    if (Z % 4 != 0) return false;
+    const int ZQ = Z / 4;
+    if (ZQ > 64) return false;
+    const int P = odd_part(ZQ);
+    if (P > 15) return false;
+    const int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));
+    const int pq = Y * ZQ;
+    const int NI = (pq + 63) / 64, NG = (NI + U - 1) / U;
+    const int strip_n = NG * U * 64;
+    g->P = P; g->U = U; g->NG = NG;
+    g->strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
+    const size_t bytes = (size_t)g->strip_alloc * 4 + (size_t)((X + Y + Z + 3) & ~3) * 4 + (size_t)ntgt * 12;
+    g->wave_lds = (bytes + 15) & ~(size_t)15;
+    return 4 * g->wave_lds <= 150 * 1024;
+}
+
+template <typename VT, int P, int U>
+void launch_derive_pu(const ProjParams& pp, size_t lds, int num_cu, hipStream_t st) {
+    // persistent grid: as many workgroups per CU as LDS (and at most four: 16 waves stream more than a CU can take) allows
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 512));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const char* env = getenv("RML_DERIVE_PERCU");       // experiment knob
+    if (env && atoi(env) >= 1 && atoi(env) <= 8) per_cu = atoi(env);
+    if (pp.o.share_cu) per_cu = 1;
+    const int64_t want = (pp.B + 3) / 4;
+    const int64_t cap = (int64_t)num_cu * per_cu;
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
+    RML_MAX_DYN_LDS(160 * 1024, &k_derive_slice<VT, P, U>);
+    hipLaunchKernelGGL((k_derive_slice<VT, P, U>), grid, block, lds, st, pp);
+}
+
+template <typename VT>
+bool launch_derive_t(const ProjParams& pp, const DeriveGeom& g, int num_cu, hipStream_t st) {
+    const size_t lds = 4 * g.wave_lds;
+    switch (g.P) {
+        case 1: launch_derive_pu<VT, 1, 8>(pp, lds, num_cu, st); return true;
+        case 3: launch_derive_pu<VT, 3, 9>(pp, lds, num_cu, st); return true;
+        case 5: launch_derive_pu<VT, 5, 10>(pp, lds, num_cu, st); return true;
+        case 7: launch_derive_pu<VT, 7, 7>(pp, lds, num_cu, st); return true;
+        case 9: launch_derive_pu<VT, 9, 9>(pp, lds, num_cu, st); return true;
+        case 11: launch_derive_pu<VT, 11, 11>(pp, lds, num_cu, st); return true;
+        case 13: launch_derive_pu<VT, 13, 13>(pp, lds, num_cu, st); return true;
+        case 15: launch_derive_pu<VT, 15, 15>(pp, lds, num_cu, st); return true;
+        default: return false;
+    }
+}
+
+bool quads_ok(const ProjParams& pp, int vbytes) {
+    // whole quads: rows of a multiple of four voxels, frames that start on a quad
+    return pp.Z % 4 == 0 && (reinterpret_cast<uintptr_t>(pp.V) & (size_t)(4 * vbytes - 1)) == 0;
+}
+
+}  // namespace
+
+namespace rmlproj {
+
+// mode SLICE, (i,j,k) given.  RML_SLICE_WAVE=0 keeps the round-1 workgroup-per-row kernel (A/B knob).
+bool try_launch_slice(const ProjParams& pp, int vbytes, hipStream_t st) {
+    if (!quads_ok(pp, vbytes) || pp.B <= 0) return false;
+    const char* env = getenv("RML_SLICE_WAVE");
+    if (env && atoi(env) == 0) return false;
+    dim3 grid((unsigned)((pp.B + 3) / 4)), block(kThreads);
+    if (vbytes == 1) hipLaunchKernelGGL(k_slice_rows<uint8_t>, grid, block, 0, st, pp);
+    else hipLaunchKernelGGL(k_slice_rows<float>, grid, block, 0, st, pp);
+    return true;
+}
+
+bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt) {
+    DeriveGeom g;
+    const char* env = getenv("RML_DERIVE_FUSED");
+    if (env && atoi(env) == 0) return false;
+    return ntgt >= 1 && derive_geom(X, Y, Z, ntgt, &g);
+}
+
+// derive (-> slice when pp.o.sel != 0) in one pass; pp.B frames, pp.ntgt targets each: outputs have B * ntgt rows.
+// false: the shape has no fused kernel (rows that are not whole quads, Z > 256, odd part of Z/4 above 15)
+bool try_launch_derive_slice(const ProjParams& pp_in, int vbytes, int num_cu, hipStream_t st) {
+    DeriveGeom g;
+    if (!quads_ok(pp_in, vbytes) || pp_in.B <= 0 || pp_in.ntgt < 1) return false;
+    const char* env = getenv("RML_DERIVE_FUSED");
+    if (env && atoi(env) == 0) return false;
+    if (!derive_geom(pp_in.X, pp_in.Y, pp_in.Z, pp_in.ntgt, &g)) return false;
+    ProjParams pp = pp_in;
+    pp.wave_lds = (int)g.wave_lds;
+    return vbytes == 1 ? launch_derive_t<uint8_t>(pp, g, num_cu, st) : launch_derive_t<float>(pp, g, num_cu, st);
+}
+
+}  // namespace rmlproj

@@ -214,10 +214,10 @@ void launch_u8_max_f(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hip
     }
 }
 template <int NM>
-void launch_u8_max(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hipStream_t st) {
+void launch_u8_max(const ProjParams& pp, int CPR, int S, int G, size_t lds_bytes, hipStream_t st) {
     // rows of 128 / 256 voxels: the cross-lane steps on the VALU (RML_U8_XLANE=0: the ds_bpermute path, for A/B)
+    // G: the power-of-two lane geometry try_launch_u8_max chose (0: the row's own chunk count -- S alone cannot tell, 64 / 13 is 4 too)
     static const bool xlane = [] { const char* e = getenv("RML_U8_XLANE"); return !e || atoi(e) != 0; }();
-    const int G = S == 4 ? 16 : (S == 8 ? 8 : 0);     // lane geometry chosen by try_launch_u8_max (S = 64 / lanes per row)
     if (xlane && G == 8) launch_u8_max_f<NM, 8>(pp, CPR, S, lds_bytes, st);
     else if (xlane && G == 16) launch_u8_max_f<NM, 16>(pp, CPR, S, lds_bytes, st);
     else launch_u8_max_f<NM, 0>(pp, CPR, S, lds_bytes, st);
@@ -245,14 +245,14 @@ bool rmlproj::try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
     if (lds_bytes < 64 * 8 + 64) lds_bytes = 64 * 8 + 64;      // Emitter::finish scratch
     if (nm > 8 || lds_bytes > 150 * 1024) return false;
     switch (nm) {       // rows per lane and plane: exact, so that no lane re-reads rows it does not need
-        case 1: launch_u8_max<1>(pg, CPR, S, lds_bytes, st); break;
-        case 2: launch_u8_max<2>(pg, CPR, S, lds_bytes, st); break;
-        case 3: launch_u8_max<3>(pg, CPR, S, lds_bytes, st); break;
-        case 4: launch_u8_max<4>(pg, CPR, S, lds_bytes, st); break;
-        case 5: launch_u8_max<5>(pg, CPR, S, lds_bytes, st); break;
-        case 6: launch_u8_max<6>(pg, CPR, S, lds_bytes, st); break;
-        case 7: launch_u8_max<7>(pg, CPR, S, lds_bytes, st); break;
-        default: launch_u8_max<8>(pg, CPR, S, lds_bytes, st); break;
+        case 1: launch_u8_max<1>(pg, CPR, S, G, lds_bytes, st); break;
+        case 2: launch_u8_max<2>(pg, CPR, S, G, lds_bytes, st); break;
+        case 3: launch_u8_max<3>(pg, CPR, S, G, lds_bytes, st); break;
+        case 4: launch_u8_max<4>(pg, CPR, S, G, lds_bytes, st); break;
+        case 5: launch_u8_max<5>(pg, CPR, S, G, lds_bytes, st); break;
+        case 6: launch_u8_max<6>(pg, CPR, S, G, lds_bytes, st); break;
+        case 7: launch_u8_max<7>(pg, CPR, S, G, lds_bytes, st); break;
+        default: launch_u8_max<8>(pg, CPR, S, G, lds_bytes, st); break;
     }
     return true;
 }

@@ -143,6 +143,11 @@ bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, boo
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);
 
+// k_derive_slice (project_slice.hip): DerivedTarget.get_derived_targets (common.py:49-80) and the slices at the derived (i,j,k) in one
+// pass over the frames; o.sel == 0: derive only.  RML_ERR_UNSUPPORTED (no message set) when the shape has no fused kernel.
+int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,
+                            int32_t* ijk_out, float* profiles, const ProjOut& o, hipStream_t st);
+
 // ---- SVM (svm.hip) ------------------------------------------------------------------------
 struct rml_svm {
     int64_t M = 0, Mpad = 0, D = 0;

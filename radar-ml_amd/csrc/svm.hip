@@ -1870,7 +1870,11 @@ int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu,
         // lockstep (measured: 1.97 rounds per launch 0.47-0.51 of peak, 2.99 rounds 0.54-0.58) -- three twentieths per chunk
         const int64_t total = round_up(rows, kBig);
         int64_t best = -1;
-        for (int64_t c = 4096; c <= 32768; c += kBig) {
+        // digit path: every launched workgroup parks two 256 KiB scratch tiles (carve: ring_grid x 512 KiB per workspace, times the
+        // workspaces in rotation), so the chunk is also capped by a scratch budget of 1 GiB per workspace: 2048 tiles.  M = 2 560
+        // is not touched (32 768 rows = 1 280 tiles); a 20 480-SV model stops at 6 400 rows instead of asking for 5 GiB
+        const int64_t cmax = dig ? std::max<int64_t>(4096 / 4, std::min<int64_t>(32768, (2048 / st2) * kBig)) : 32768;
+        for (int64_t c = std::min<int64_t>(4096, cmax); c <= cmax; c += kBig) {
             const int64_t nfull = total / c, rem = total % c;
             const int64_t cost = 20 * (nfull * rounds(c) + rounds(rem)) + 3 * (nfull + (rem ? 1 : 0));
             if (best < 0 || cost <= best) { best = cost; ch = c; }
@@ -1886,10 +1890,11 @@ struct ChunkWs {
     int32_t* tile_exact; int32_t* all_exact; double* partial;
     int8_t* dig; int64_t dig_plane; double* dnsq; int32_t* dflags;      // multi-digit operand of the general rows (or NULL)
     int32_t* stash;                                                     // scratch tiles of k_svm_gemm_ring<.., 1>
+    int32_t* ijk;                                                       // derived (i,j,k) of the chunk's frames (fused derive -> slice), or NULL
     size_t bytes;
 };
 
-ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32, bool need_dig = false) {
+ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32, bool need_dig = false, bool need_ijk = false) {
     ChunkWs w{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return base ? base + o : (unsigned char*)nullptr; };
@@ -1908,6 +1913,8 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     w.dflags = (int32_t*)take(need_dig ? (size_t)CH * 4 : 0);
     w.stash = (int32_t*)take(need_dig ? (size_t)ring_grid((int)((CH + kBig - 1) / kBig), (int)((m->Mpad + kBig - 1) / kBig)) * 2 * kDigStashBytes : 0);
     if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; w.stash = nullptr; }
+    w.ijk = (int32_t*)take(need_ijk ? (size_t)CH * 12 : 0);
+    if (!need_ijk) w.ijk = nullptr;
     w.bytes = off;
     return w;
 }
@@ -2256,10 +2263,37 @@ extern "C" int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, c
 }
 
 // ---- fused front door: volumes -> projection -> SVM ---------------------------------------
+namespace {
+int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
+                     int mode, const int32_t* ijk, bool derive, int32_t* ijk_out, float scale_div, uint32_t mask,
+                     double* dec_ovo, double* dec_ovr, double* proba,
+                     int32_t* label_vote, int32_t* label_calib, void* stream);
+}
+
 extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                                int mode, const int32_t* ijk, float scale_div, uint32_t mask,
                                double* dec_ovo, double* dec_ovr, double* proba,
                                int32_t* label_vote, int32_t* label_calib, void* stream) {
+    return project_svm_impl(ctx, m, V, vdtype, B, X, Y, Z, mode, ijk, false, nullptr, scale_div, mask, dec_ovo, dec_ovr, proba, label_vote,
+                            label_calib, stream);
+}
+
+extern "C" int rml_derive_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
+                                      float scale_div, uint32_t mask, int32_t* ijk_out,
+                                      double* dec_ovo, double* dec_ovr, double* proba,
+                                      int32_t* label_vote, int32_t* label_calib, void* stream) {
+    RML_REQUIRE(rml_derive_slice_supported(V, vdtype, X, Y, Z, 1) == 1, RML_ERR_UNSUPPORTED,
+                "rml_derive_project_svm: no fused derive kernel for %dx%dx%d (rows of whole quads, Z <= 256, odd part of Z/4 <= 15): "
+                "use rml_derive_targets + rml_project_svm(mode SLICE)", X, Y, Z);
+    return project_svm_impl(ctx, m, V, vdtype, B, X, Y, Z, RML_MODE_SLICE, nullptr, true, ijk_out, scale_div, mask, dec_ovo, dec_ovr, proba,
+                            label_vote, label_calib, stream);
+}
+
+namespace {
+int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
+                     int mode, const int32_t* ijk, bool derive, int32_t* ijk_out, float scale_div, uint32_t mask,
+                     double* dec_ovo, double* dec_ovr, double* proba,
+                     int32_t* label_vote, int32_t* label_calib, void* stream) {
     RML_REQUIRE(ctx && m && B >= 0, RML_ERR_INVALID, "rml_project_svm: bad arguments");
     if (B == 0) return RML_OK;
     RML_REQUIRE(V != nullptr, RML_ERR_INVALID, "rml_project_svm: V is NULL");
@@ -2267,7 +2301,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     RML_REQUIRE(rml_feature_len(X, Y, Z, mask) == m->D, RML_ERR_INVALID, "rml_project_svm: grid/mask give D=%lld, model has D=%lld",
                 (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
-    RML_REQUIRE(mode != RML_MODE_SLICE || ijk, RML_ERR_INVALID, "rml_project_svm: mode SLICE needs ijk");
+    RML_REQUIRE(mode != RML_MODE_SLICE || ijk || derive, RML_ERR_INVALID, "rml_project_svm: mode SLICE needs ijk");
     if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
     // the code grid of the features must be the model's: codes are the unscaled values
     const bool scaled = scale_div > 1.0f;
@@ -2311,7 +2345,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
                        : (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
                        : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
-    ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig);
+    const bool ws_ijk = derive && !ijk_out;             // the derived (i,j,k) stay in the chunk's workspace when the caller does not want them
+    ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig, ws_ijk);
     // workspaces in rotation: 2 (projection of chunk c+1 beside the GEMM of chunk c); RML_NBUF=3 lets the projection run two
     // chunks ahead (experiment knob: loosens the lock-step of the two streams when their per-chunk times are equal)
     const char* nbe = getenv("RML_NBUF");
@@ -2320,7 +2355,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     int rc = rml_ws_reserve(ctx, (size_t)NBUF * probe.bytes, &ws);
     if (rc) return rc;
     ChunkWs w2[3];
-    for (int i = 0; i < NBUF; ++i) w2[i] = carve(m, CH, static_cast<unsigned char*>(ws) + (size_t)i * probe.bytes, grid_ok, true, use_dig);
+    for (int i = 0; i < NBUF; ++i) w2[i] = carve(m, CH, static_cast<unsigned char*>(ws) + (size_t)i * probe.bytes, grid_ok, true, use_dig, ws_ijk);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
     const int64_t frame_elems = (int64_t)X * Y * Z;
     hipStream_t aux = ctx->aux_stream;
@@ -2383,13 +2418,20 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         o.share_cu = part ? 0 : (share_regs ? 2 : 1);
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
+        // fused derive -> slice: the first pass derives (i,j,k) per frame and slices there in one launch; a second pass (float rows
+        // for tiles that left the code grid) is a plain slice at the indices the first one wrote
+        int32_t* ijkd = derive ? (ijk_out ? ijk_out + r0 * 3 : w.ijk) : nullptr;
+        auto first_pass = [&](const ProjOut& po, hipStream_t ps) -> int {
+            if (derive) return rml_launch_derive_slice(ctx, Vc, vdtype, n, X, Y, Z, 1, ijkd, nullptr, po, ps);
+            return rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, po, ps);
+        };
         // uint8 volumes are on the code grid by construction: one projection pass (codes + statistics), the exact GEMM on
         // every tile, no flag kernels, no predicated second pass and no predicated float64 GEMM launch
         const bool u8_exact = grid_ok && vdtype == RML_VOL_U8;
         if (u8_exact) {
             o.row_flags = nullptr;
             rml_prof_mark(ctx, st);
-            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, st);
+            rc = first_pass(o, st);
             rml_prof_mark(ctx, st);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
@@ -2412,7 +2454,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         if (grid_ok) {
             // pass 1: codes + statistics only (the exact path needs nothing else)
             rml_prof_mark(ctx, sp);
-            rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, o, sp);
+            rc = first_pass(o, sp);
             rml_prof_mark(ctx, sp);
             if (ctx->profiling) ctx->prof_frames += n;
             if (rc) return rc;
@@ -2438,7 +2480,8 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
         of.skip_if_set = grid_ok ? w.all_exact : nullptr;
         if (!grid_ok) of.row_flags = w.flags;
         if (!grid_ok) rml_prof_mark(ctx, st);
-        rc = rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, mode, ijkc, of, s2);
+        // (a model off the code grid has no first pass: this one derives as well)
+        rc = (derive && grid_ok) ? rml_launch_project(ctx, Vc, vdtype, n, X, Y, Z, RML_MODE_SLICE, ijkd, of, s2) : first_pass(of, s2);
         if (!grid_ok) { rml_prof_mark(ctx, st); if (ctx->profiling) ctx->prof_frames += n; }
         if (rc) return rc;
         if (use_dig) {
@@ -2491,6 +2534,7 @@ extern "C" int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, in
     }
     return RML_OK;
 }
+}  // namespace
 
 // libsvm's own Platt coefficients (SVC(probability=True): sk:svm/_base.py _probA / _probB, one pair per class pair):
 // uploaded once, at load time, so that rml_svm_pairwise_proba is an ordinary asynchronous launch

@@ -195,7 +195,9 @@ class GpuSVC(_Base):
     def decide_volumes(self, volumes, mode="max", ijk=None, proj_mask=ProjMask(True, True, True), scale=True,
                        want_proba=None):
         """Fused batched path: (B,X,Y,Z) volumes -> projection -> SVM, features never leave the GPU.
-        Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib])."""
+        Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib]); mode='slice' without ``ijk``
+        slices through the strongest derived target of every frame (common.py:49-80) and also returns it as ``ijk`` (B,3)
+        where the one-pass kernel ran."""
         torch = _torch()
         lib = _lib.load()
         from .common import derive_targets, _slice_indices, process_volumes
@@ -209,11 +211,18 @@ class GpuSVC(_Base):
         if want_proba is None:
             want_proba = self.has_calibration
         ijk_t = None
+        fused_derive = False
         if mode == "slice":
             derived = ijk is None
-            if derived:
-                ijk = derive_targets(v, 1)[:, 0, :]      # DerivedTarget.get_derived_targets on the GPU (common.py:49-80)
-            ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
+            # no SDK target: DerivedTarget.get_derived_targets (common.py:49-80) on the GPU -- in the same pass as the slices and
+            # the SVM where the shape has the fused kernel (rml_derive_project_svm), as a launch of its own otherwise
+            fused_derive = derived and bool(lib.rml_derive_slice_supported(_lib.ptr(v), vdt, X, Y, Z, 1))
+            if derived and not fused_derive:
+                ijk = derive_targets(v, 1)[:, 0, :]
+            if fused_derive:
+                T = 1
+            else:
+                ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
             if T > 1:
                 # several targets per frame (predict.py:93-119 classifies every target of one image): slice rows first,
                 # then the SVM on the B*T rows; outputs are (B*T, ...) in frame-major order
@@ -231,6 +240,14 @@ class GpuSVC(_Base):
         if want_proba:
             out["proba"] = torch.empty((B, C_), dtype=torch.float64, device=dev)
             out["label_calib"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        if fused_derive:
+            out["ijk"] = torch.empty((B, 3), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rml_derive_project_svm(
+                    self._ctx, self._h, _lib.ptr(v), vdt, B, X, Y, Z, float(RADAR_MAX) if scale else 0.0, _mask_bits(proj_mask),
+                    _lib.ptr(out["ijk"]), _lib.ptr(out["dec_ovo"]), _lib.ptr(out["dec_ovr"]), _lib.ptr(out.get("proba")),
+                    _lib.ptr(out["label_vote"]), _lib.ptr(out.get("label_calib")), _lib.stream_ptr(dev)), "rml_derive_project_svm")
+            return out
         with torch.cuda.device(dev):
             _lib.check(lib.rml_project_svm(
                 self._ctx, self._h, _lib.ptr(v), vdt, B, X, Y, Z, _lib.MODES[mode], _lib.ptr(ijk_t),

@@ -190,3 +190,27 @@ def test_context_creation_failure_raises_instead_of_deadlocking(monkeypatch):
     t.join(20)
     assert not t.is_alive(), "context() dead-locked on a failing rml_ctx_create"
     assert "rml_ctx_create failed" in res["r"]
+
+
+def test_slice_indices_accept_every_integer_dtype():
+    """common._slice_indices: the range check runs on the caller's integers widened to int64 -- uint8 / int8 / uint16 / int64 index
+    arrays are accepted when in range (a narrow dtype must not wrap the bound: -64 as uint8 is 192; int8 cannot hold Z = 128),
+    out-of-range and wrapped values raise IndexError like NumPy indexing would."""
+    import torch
+    from radar_ml_amd.common import _slice_indices
+    cpu = torch.device("cpu")
+    X, Y, Z = 64, 64, 128
+    base = np.array([[0, 1, 2], [63, 63, 127], [5, 6, 100]])
+    for dt in (np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64):
+        t, T = _slice_indices(base.astype(dt), 3, X, Y, Z, cpu)
+        assert T == 1 and t.dtype == torch.int32 and t.tolist() == base.tolist()
+    t, _ = _slice_indices(np.array([[-64, -1, 100], [3, 4, 5]], dtype=np.int8), 2, X, Y, Z, cpu)     # int8 cannot hold 128
+    assert t.tolist() == [[-64, -1, 100], [3, 4, 5]]
+    t, _ = _slice_indices(torch.tensor([[1, 2, 3]], dtype=torch.uint8), 1, X, Y, Z, cpu)
+    assert t.tolist() == [[1, 2, 3]]
+    for bad in (np.array([[64, 0, 0]], np.uint8), np.array([[0, 0, 128]], np.int64), np.array([[0, -65, 0]], np.int16),
+                np.array([[0, 0, 2 ** 32 + 5]], np.int64), np.array([[0, 0, 2 ** 63 + 5]], np.uint64), np.array([[200, 0, 0]], np.uint8)):
+        with pytest.raises(IndexError):
+            _slice_indices(bad, 1, X, Y, Z, cpu)
+    with pytest.raises(IndexError):
+        _slice_indices(np.array([[0.0, 1.0, 2.0]]), 1, X, Y, Z, cpu)

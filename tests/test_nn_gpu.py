@@ -162,6 +162,53 @@ def test_dnn_trained_model_labels_match_the_oracle_where_its_margin_allows(rml):
     assert err <= DNN_BF16_PROBA_TOL
 
 
+def test_dnn_full_size_batch_size_independent_properties(rml):
+    """BASELINE configs[3] at its stated per-GPU size -- 32 768 frames of the Walabot arena grid through
+    Classifier.predict_volumes (projection -> [-1,1] scaling + bicubic resize -> fused bf16 trunk -> dense tail) -- by
+    properties that need no oracle of that size:
+      * batching independence: the whole batch in one call against the same frames in three ragged calls (other internal batch
+        boundaries, other last-batch sizes): probabilities BIT-identical;
+      * ingest independence: the same frames as uint8 volumes give bit-identical probabilities (the projections are the same
+        float32 values either way);
+      * the float64 NumPy restatement of the chain on 96 frames drawn from the whole range, trained weights with real margins:
+        probabilities within DNN_BF16_PROBA_TOL and the same label wherever the oracle's top-2 margin exceeds 1e-2."""
+    import oracle_np as O
+    import gc
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    cpu, _, _ = _train_classifier_with_margins(dnn)
+    gpu = copy.deepcopy(cpu).to("cuda").eval()
+    frames, (X, Y, Z) = 32768, (22, 31, 176)
+    gc.collect(); torch.cuda.empty_cache()
+    V, _ = rml.synth_volumes(frames, X, Y, Z, seed=31)
+    whole = gpu.predict_volumes(V)
+    assert whole.shape == (frames, 3)
+    cuts = [0, frames // 3 + 777, frames // 3 + 777 + 9999, frames]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = gpu.predict_volumes(V[lo:hi])
+        assert torch.equal(part, whole[lo:hi]), (lo, hi)
+    part = gpu.predict_volumes(V[:5000], batch_size=1024)                  # another internal batch size
+    assert torch.equal(part, whole[:5000])
+    v8 = gpu.predict_volumes(V.to(torch.uint8))
+    assert torch.equal(v8, whole)
+    rng = np.random.default_rng(3)
+    pick = np.unique(np.concatenate([np.arange(32), rng.integers(0, frames, 32), np.arange(frames - 32, frames)]))
+    vh = V[torch.as_tensor(pick, device=V.device)].cpu().numpy()
+    planes = [[], [], []]
+    for v in vh:
+        for i, pr in enumerate(O.project_max(v)):
+            planes[i].append(O.pil_resize_bicubic(O.scale_unit_range(pr), (80, 80)))
+    convs, dense = cpu.keras_weights()
+    want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
+    got = whole[torch.as_tensor(pick, device=V.device)].float().cpu().numpy()
+    srt = np.sort(want, axis=1)
+    confident = (srt[:, -1] - srt[:, -2]) > 1e-2
+    assert np.abs(got - want).max() <= DNN_BF16_PROBA_TOL
+    np.testing.assert_array_equal(got.argmax(1)[confident], want.argmax(1)[confident])
+    assert confident.sum() > len(pick) // 2
+    del V, whole, v8
+    gc.collect(); torch.cuda.empty_cache()
+
+
 # measured on MI355X (printed by the tests with -s): |dp| of the bf16 chains against float32 / float64 is <= 4.8e-4 at random
 # init and 3.4e-3 on the trained model; the tolerances are ~2x the measured worst, not the 3e-2 of round 2
 DNN_BF16_PROBA_TOL = 8e-3            # trained model (outputs away from 1/3): measured 3.4e-3

@@ -259,10 +259,10 @@ def test_empty_batch_and_torch_io(rml):
 
 
 def test_full_size_properties(rml):
-    """Size-independent properties at BASELINE config-2 scale (B=1024 x 64x64x128 here; the bench
-    runs 4096+): every plane has the same global max; plane maxima reduce consistently."""
+    """Size-independent properties at BASELINE configs[1]'s stated size (batch 4096 of 64x64x128): every plane has the same
+    global max; plane maxima reduce consistently; sums agree; a slab against the oracle."""
     import torch
-    B, X, Y, Z = 1024, 64, 64, 128
+    B, X, Y, Z = 4096, 64, 64, 128
     v, cls = rml.synth_volumes(B, X, Y, Z, seed=7)
     xz, yz, xy = rml.project(v, mode="max")
     gmax = v.amax(dim=(1, 2, 3))
@@ -609,3 +609,158 @@ def test_augmentation_kernels_match_the_reference_data_generator(rml):
         for pi in range(3):
             assert t[pi].dtype == np.float32 and t[pi].shape == outs[pi][j].shape
             assert np.abs(t[pi] - outs[pi][j]).max() <= 2e-6, (j, pi)
+
+
+def _tie_free_volumes(rng, B, X, Y, Z, lo=0.3):
+    """Integer volumes 0..255 (exact float32 sums in any order) whose three energy profiles have no exact ties in their
+    leading entries: the reference's argpartition leaves the order of ties open."""
+    v = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
+    v[rng.random((B, X, Y, Z)) < lo] = 0
+    return v
+
+
+DERIVE_SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 12), (3, 70, 24), (2, 3, 256), (16, 16, 64), (9, 130, 32),
+                 (7, 37, 160), (5, 33, 48), (4, 9, 48), (3, 100, 176), (4, 8, 132), (3, 20, 180), (1, 24, 200), (3, 41, 112),
+                 (2, 5, 208), (3, 6, 240), (6, 9, 4), (5, 4, 8), (2, 2, 36), (11, 3, 60)]
+
+
+@pytest.mark.parametrize("shape", DERIVE_SHAPES)
+@pytest.mark.parametrize("nt", [1, 3])
+def test_fused_derive_slice_kernel(rml, shape, nt, monkeypatch):
+    """k_derive_slice (csrc/project_slice.hip): DerivedTarget.get_derived_targets (common.py:49-80) and the slices of
+    predict.py:102-107 at the derived voxels in ONE pass -- every period P of the column accumulators (Z/4 = 2^a * {1,3,...,15}),
+    planes that are not a whole number of load groups, odd frames (the idle group), more frames than resident waves (every wave
+    walks several frames), 1 and 3 targets per frame, float32 and uint8 volumes: the profiles, the indices, the float rows, the
+    codes and their statistics equal the oracle's, and the two-kernel path's (RML_DERIVE_FUSED=0), bit for bit."""
+    import torch
+    X, Y, Z = shape
+    nt = min(nt, X, Y, Z)
+    lib = rml._lib.load()
+    zq = Z // 4
+    while zq % 2 == 0 and zq > 0:
+        zq //= 2
+    fused = zq <= 15                                     # (4,8,132), (3,20,180), (1,24,200): odd part of Z/4 = 33, 45, 25 -> two kernels
+    assert lib.rml_derive_slice_supported(None, 0, X, Y, Z, nt) == int(fused)
+    B = 3000 if X * Y * Z < 30000 else (1300 if X * Y * Z < 200000 else 260)
+    rng = np.random.default_rng(X * 7919 + Y * 31 + Z)
+    v = _tie_free_volumes(rng, B, X, Y, Z)
+    dv = torch.from_numpy(v).cuda()
+    ijk, prof = rml.derive_targets(dv, nt, return_profiles=True)
+    ijk = ijk.cpu().numpy(); prof = prof.cpu().numpy()
+    check = list(range(0, B, max(1, B // 37))) + [B - 1]
+    for b in check:
+        st, sp, sr = O.axis_energy_profiles(v[b])
+        np.testing.assert_array_equal(prof[b], np.concatenate([st, sp, sr]))
+        want = np.array([[t.i, t.j, t.k] for t in O.get_derived_targets(v[b], X, Y, Z, nt)])
+        for ax, s in enumerate((st, sp, sr)):
+            np.testing.assert_array_equal(s[ijk[b, :, ax]], s[want[:, ax]])      # compare by energy: ties are open in the reference
+    # the rows: float (scaled), codes, statistics -- against the oracle's slices at the kernel's own indices
+    feat, q, isum, isq, flags, ijk2 = rml.process_volumes(dv, mode="slice", num_targets=nt, scale=True, codes=True, return_ijk=True)
+    np.testing.assert_array_equal(ijk2.cpu().numpy(), ijk)
+    fh = feat.cpu().numpy(); qh = q.cpu().numpy()
+    D = fh.shape[1]
+    assert fh.shape[0] == B * nt
+    for b in check:
+        for t in range(nt):
+            xz, yz, xy = O.project_slice(v[b], *ijk[b, t])
+            raw = np.concatenate([xz.ravel(), yz.ravel(), xy.ravel()])
+            r = b * nt + t
+            np.testing.assert_array_equal(fh[r], raw / np.float32(255.0))
+            np.testing.assert_array_equal(qh[r, :D] ^ 0x80, raw.astype(np.uint8))
+            assert not qh[r, D:].any()
+            assert int(isum[r]) == int(raw.astype(np.int64).sum()) and int(isq[r]) == int((raw.astype(np.int64) ** 2).sum())
+    assert flags.cpu().numpy().all()
+    # the two-kernel path on the same frames
+    monkeypatch.setenv("RML_DERIVE_FUSED", "0")
+    assert lib.rml_derive_slice_supported(None, 0, X, Y, Z, nt) == 0
+    ijk_old, prof_old = rml.derive_targets(dv, nt, return_profiles=True)
+    np.testing.assert_array_equal(prof_old.cpu().numpy(), prof)
+    for ax in range(3):       # same energies (an exact tie may be resolved alike or not: both follow radarml.h, checked below)
+        off = [0, X, X + Y][ax]
+        a = np.take_along_axis(prof[:, off:off + (X, Y, Z)[ax]], ijk[:, :, ax], 1)
+        bb = np.take_along_axis(prof[:, off:off + (X, Y, Z)[ax]], ijk_old.cpu().numpy()[:, :, ax], 1)
+        np.testing.assert_array_equal(a, bb)
+    np.testing.assert_array_equal(ijk_old.cpu().numpy(), ijk)             # the documented tie rule is the same in both
+    f_old = rml.process_volumes(dv, mode="slice", num_targets=nt, scale=True)
+    assert torch.equal(f_old, feat)
+    monkeypatch.delenv("RML_DERIVE_FUSED")
+    # uint8 volumes: identical
+    d8 = dv.to(torch.uint8)
+    f8, q8, isum8, isq8, fl8, ijk8 = rml.process_volumes(d8, mode="slice", num_targets=nt, scale=True, codes=True, return_ijk=True)
+    assert torch.equal(ijk8, ijk2) and torch.equal(f8, feat) and torch.equal(q8, q) and torch.equal(isum8, isum) and torch.equal(isq8, isq)
+    # codes only (the fused pipeline's first pass) and an xy-only mask
+    lib_ = rml._lib
+    ctx = lib_.context(dv.device)
+    ldq = q.shape[1]
+    q2 = torch.empty_like(q); s2 = torch.empty_like(isum); sq2 = torch.empty_like(isq)
+    lib_.check(lib.rml_derive_slice(ctx, lib_.ptr(dv), 0, B, X, Y, Z, nt, None, None, 255.0, 7, None, 0, lib_.ptr(q2), ldq, lib_.ptr(s2),
+                                    lib_.ptr(sq2), None, lib_.stream_ptr(dv.device)), "rml_derive_slice")
+    assert torch.equal(q2, q) and torch.equal(s2, isum) and torch.equal(sq2, isq)
+    fxy = rml.process_volumes(dv, mode="slice", num_targets=nt, proj_mask=rml.ProjMask(False, False, True)).cpu().numpy()
+    for b in check[:5]:
+        for t in range(nt):
+            np.testing.assert_array_equal(fxy[b * nt + t], O.project_slice(v[b], *ijk[b, t])[2].ravel())
+
+
+def test_derive_tie_rule_and_non_integer_data(rml):
+    """Ties follow radarml.h in the fused kernel as in the two-kernel path (the HIGHER index of equal energies ranks higher),
+    a frame of zeros gives the last indices, and float data that is not integer valued gives profiles within float32 rounding of
+    NumPy's and slices that are bit-exact at the derived indices."""
+    import torch
+    X, Y, Z = 6, 9, 16
+    v = np.zeros((4, X, Y, Z), np.float32)
+    v[1, 2, 3, 5] = 7; v[1, 4, 3, 5] = 7                       # s_theta ties between i = 2 and i = 4
+    v[2, :, :, :] = 1.0                                        # everything ties
+    v[3, 1, 2, 3] = 9; v[3, 1, 6, 3] = 9; v[3, 1, 2, 11] = 9    # phi ties 2/6 (18 vs 9?) -> made unequal below
+    v[3, 1, 6, 11] = 9                                         # now phi: j=2 -> 18, j=6 -> 18 (tie); r: k=3 -> 18, k=11 -> 18 (tie)
+    ijk = rml.derive_targets(v, 2).cpu().numpy()
+    np.testing.assert_array_equal(ijk[0], [[X - 2, Y - 2, Z - 2], [X - 1, Y - 1, Z - 1]])
+    np.testing.assert_array_equal(ijk[1][:, 0], [2, 4])
+    np.testing.assert_array_equal(ijk[2], [[X - 2, Y - 2, Z - 2], [X - 1, Y - 1, Z - 1]])
+    np.testing.assert_array_equal(ijk[3][:, 1], [2, 6])
+    np.testing.assert_array_equal(ijk[3][:, 2], [3, 11])
+    rng = np.random.default_rng(5)
+    for (X, Y, Z) in [(22, 31, 176), (16, 16, 64), (5, 33, 48)]:
+        vf = np.abs(rng.standard_normal((300, X, Y, Z)) * 40).astype(np.float32)
+        ijk, prof = rml.derive_targets(vf, 1, return_profiles=True)
+        ijk = ijk.cpu().numpy()[:, 0]; prof = prof.cpu().numpy()
+        for b in range(0, 300, 29):
+            want = np.concatenate(O.axis_energy_profiles(vf[b]))
+            np.testing.assert_allclose(prof[b], want, rtol=2e-6)
+        feat, ijk2 = rml.process_volumes(vf, mode="slice", return_ijk=True)
+        np.testing.assert_array_equal(ijk2.cpu().numpy()[:, 0], ijk)
+        fh = feat.cpu().numpy()
+        for b in range(0, 300, 29):
+            xz, yz, xy = O.project_slice(vf[b], *ijk[b])
+            np.testing.assert_array_equal(fh[b], np.concatenate([xz.ravel(), yz.ravel(), xy.ravel()]))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 12), (3, 70, 24), (9, 130, 32), (2, 3, 260), (6, 5, 7)])
+def test_slice_rows_kernel_matches_the_general_kernel(rml, shape, monkeypatch):
+    """k_slice_rows (one wave per output row: whole-quad loads for xz / yz, four xy cells per lane) against the oracle and
+    against the round-1 kernel (RML_SLICE_WAVE=0) -- negative indices, several targets per frame, masks, codes, float32 and
+    uint8; (2,3,260) has no whole quads... it has (260 = 65 quads) but (6,5,7) has none and stays on the general kernel."""
+    import torch
+    X, Y, Z = shape
+    B, T = 257, 3
+    rng = np.random.default_rng(X + Y + Z)
+    v = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
+    ijk = np.stack([rng.integers(-X, X, (B, T)), rng.integers(-Y, Y, (B, T)), rng.integers(-Z, Z, (B, T))], -1)
+    out = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("RML_SLICE_WAVE", knob)
+        feat, q, isum, isq, flags = rml.process_volumes(v, mode="slice", ijk=ijk, scale=True, codes=True)
+        f8 = rml.process_volumes(v.astype(np.uint8), mode="slice", ijk=ijk, scale=True)
+        assert torch.equal(f8, feat)
+        planes = rml.project(v, mode="slice", ijk=ijk[:, 0])
+        fm = rml.process_volumes(v, mode="slice", ijk=ijk[:, 1], proj_mask=rml.ProjMask(True, False, True))
+        out[knob] = (feat, q, isum, isq, flags, fm) + tuple(torch.from_numpy(p) for p in planes)
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a.cpu(), b.cpu())
+    fh = out["1"][0].cpu().numpy()
+    for b in range(0, B, 16):
+        for t in range(T):
+            xz, yz, xy = O.project_slice(v[b], *ijk[b, t])
+            np.testing.assert_array_equal(fh[b * T + t], np.concatenate([xz.ravel(), yz.ravel(), xy.ravel()]) / np.float32(255.0))
+    for pl, got in zip(O.project_slice(v[5], *ijk[5, 0]), out["1"][6:]):
+        np.testing.assert_array_equal(got[5].numpy(), pl)

@@ -3,6 +3,8 @@
 
     python tools/kbench.py proj [--grid 64x64x128] [--frames 4096] [--iters 20]
     python tools/kbench.py svm  [--grid 64x64x128] [--frames 8192] [--svs 2048] [--path i8|f32]
+    python tools/kbench.py slice  [--grid ...] [--frames ...] [--u8]     mode SLICE with (i,j,k) given (k_slice_rows)
+    python tools/kbench.py derive [--grid ...] [--frames ...] [--u8]     derive only / derive -> slice in one pass (k_derive_slice)
 """
 import argparse
 import json
@@ -30,7 +32,7 @@ def timeit(torch, fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["proj", "svm", "copy", "gemm"])
+    ap.add_argument("what", choices=["proj", "svm", "copy", "gemm", "slice", "derive"])
     ap.add_argument("--grid", default="64x64x128")
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
@@ -60,6 +62,59 @@ def main():
     if a.u8:
         V = V.to(torch.uint8)
         esz = 1
+    if a.what in ("slice", "derive"):
+        lib = _lib.load(); ctx = _lib.context(dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        vdt = 1 if a.u8 else 0
+        qb = (D + 127) // 128 * 128
+        feat = torch.empty((B, D), dtype=torch.float32, device=dev)
+        q = torch.empty((B, qb), dtype=torch.uint8, device=dev)
+        isum = torch.empty(B, dtype=torch.int32, device=dev); isq = torch.empty(B, dtype=torch.int64, device=dev)
+        flags = torch.empty(B, dtype=torch.int32, device=dev)
+        ijk = torch.empty((B, 3), dtype=torch.int32, device=dev)
+        _lib.check(lib.rml_derive_targets(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, st))
+        frame = esz * X * Y * Z
+        line = 128                                      # bytes per memory request: every xy value has its own (rows are >= 512 B apart)
+        floor_rd = esz * (X * Z + Y * Z) + X * Y * line   # what a slice must fetch whatever the kernel does
+        rows = []
+        if a.what == "slice":
+            def f_rows():
+                _lib.check(lib.rml_project(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), 255.0, 7, feat.data_ptr(), D, None, 0,
+                                           None, None, None, st))
+            def f_codes():
+                _lib.check(lib.rml_project(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), 255.0, 7, None, 0, q.data_ptr(), qb,
+                                           isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st))
+            for knob in ("1", "0"):
+                os.environ["RML_SLICE_WAVE"] = knob
+                for label, fn, alg in (("f32 rows /255", f_rows, esz * D + 4 * D + 12), ("codes+stats", f_codes, esz * D + D + 16 + 12)):
+                    med, mn, _ = timeit(torch, fn, a.iters)
+                    rows.append({"what": "slice (ijk given) %s, %s" % (label, "k_slice_rows" if knob == "1" else "k_project_slice (round 1)"),
+                                 "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4), "rows_per_s": round(B / med * 1e3),
+                                 "alg_bytes_per_row": alg, "alg_GBs": round(B * alg / med / 1e6, 1),
+                                 "request_floor_bytes_per_row": floor_rd + (alg - esz * D), "floor_GBs": round(B * (floor_rd + alg - esz * D) / med / 1e6, 1)})
+            os.environ.pop("RML_SLICE_WAVE", None)
+        else:
+            def f_derive():
+                _lib.check(lib.rml_derive_targets(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, st))
+            def f_fused_codes():
+                _lib.check(lib.rml_derive_slice(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, 255.0, 7, None, 0, q.data_ptr(), qb,
+                                                isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st))
+            def f_fused_rows():
+                _lib.check(lib.rml_derive_slice(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, 255.0, 7, feat.data_ptr(), D, None, 0,
+                                                None, None, None, st))
+            for knob in ("1", "0"):
+                os.environ["RML_DERIVE_FUSED"] = knob
+                os.environ["RML_SLICE_WAVE"] = knob
+                for label, fn, alg in (("derive only", f_derive, frame + 12), ("derive -> slice, codes+stats", f_fused_codes, frame + 16),
+                                       ("derive -> slice, f32 rows", f_fused_rows, frame + 4 * D + 12)):
+                    med, mn, _ = timeit(torch, fn, a.iters)
+                    rows.append({"what": "%s (%s)" % (label, "k_derive_slice" if knob == "1" else "sum planes + k_profiles_topk + k_project_slice"),
+                                 "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4), "ms_min": round(mn, 4), "frames_per_s": round(B / med * 1e3),
+                                 "alg_GBs": round(B * alg / med / 1e6, 1), "frac_of_8TBs": round(B * alg / med / 1e6 / 8000, 4)})
+            os.environ.pop("RML_DERIVE_FUSED", None); os.environ.pop("RML_SLICE_WAVE", None)
+        for r in rows:
+            print(json.dumps(r))
+        return
     if a.what == "gemm":
         # the exact-integer GEMM + finish alone, on code rows (the operand the fused pipeline hands it)
         M = a.svs
