@@ -18,8 +18,11 @@
 // plane and frame boundaries -- the structure of k_project_lin), and all three energy profiles come out of that one pass:
 //   s_r[k]      element-wise float4 accumulators: instruction t of a plane holds columns (64 t + lane) mod Z/4, which repeats
 //               with period P = (Z/4) / gcd(Z/4, 64) instructions -> P float4 registers, folded once per frame through LDS;
-//   s_phi[j]    every quad belongs to one row: its horizontal sum goes to a wave-private LDS strip [quad of the plane] with
-//               ds_add_f32 (one lane per address: program order, deterministic), lane j folds row j once per frame;
+//   s_phi[j]    every quad belongs to one row: its horizontal sum is added to a wave-private LDS strip [lane][instruction of the
+//               plane] by a plain read-add-write of whole float4 (a lane's U slots of a group are contiguous: U/4 ds_read_b128 +
+//               ds_write_b128 per group, conflict-free row stride) -- ds_add_f32 per load instruction, the first version, ran
+//               the whole kernel at 0.40 of 8 TB/s instead of 0.86: LDS atomics are the slowest thing a CU has; lane j folds
+//               row j once per frame;
 //   s_theta[i]  the lane's running sum over the plane, one butterfly over the wave per plane.
 // No sum planes through HBM (the old path wrote X*Z + Y*Z floats per frame and read them back), no second launch for the
 // top-n: the wave does it on its LDS profiles (wave arg-max with shuffles; ties as radarml.h documents: the lower index ranks
@@ -27,6 +30,10 @@
 // flight, and leaves through the Emitter.  Sums of integer-valued data are exact in float32 in any order (< 2^24): the indices
 // are bit-exact against NumPy; on other data the float32 rounding follows this kernel's (fixed) order.
 #include "project_shared.h"
+
+#ifndef RML_DS_ABL
+#define RML_DS_ABL 0      // ablation switches of k_derive_slice (variant builds only)
+#endif
 
 namespace {
 
@@ -175,11 +182,15 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
     extern __shared__ __align__(16) unsigned char ds_smem[];
     unsigned char* mine = ds_smem + (size_t)wave * a.wave_lds;
     float* strip = reinterpret_cast<float*>(mine);
-    const int strip_n = NG * U * 64;
+    constexpr int UP = (U + 3) & ~3;                    // a group's slots in a lane's strip row, padded to whole float4
+    const int RS = NG * UP + 4;                         // row stride in floats: an odd number of float4 (NG * UP / 4 + 1 when that is
+    const int RSo = ((RS / 4) & 1) ? RS : RS + 4;       // odd): the 16 lanes of a b128 access hit 16 different bank groups
+    const int strip_n = 64 * RSo;
     const int strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
     float* prof = strip + strip_alloc;
     int* tgt = reinterpret_cast<int*>(prof + ((X + Y + Z + 3) & ~3));
-    for (int q = lane; q < strip_n; q += 64) strip[q] = 0.0f;
+    for (int q = lane; q < strip_alloc; q += 64) strip[q] = 0.0f;
+    float4* const myrow = reinterpret_cast<float4*>(strip + lane * RSo);
 
     // load cursor, one group ahead of the reduction; frames are assigned statically (wave w: w, w + #waves, ...)
     int64_t lf = cf;
@@ -235,18 +246,42 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
                 __builtin_amdgcn_sched_barrier(0);      // keep the software pipeline as written (see k_project_wave)
                 const int lim = (gi + s) < GP ? pq : 0; // the idle group contributes nothing
                 const int q0 = cg * U * 64 + lane;
+                // the running row sums of this group's slots: read now, written back behind the reduction
+                float4* const slot = myrow + cg * (UP / 4);
+                float hs[UP];
+#if !(RML_DS_ABL & 1)
+                static_for<UP / 4>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    const float4 o = slot[w];
+                    hs[4 * w] = o.x; hs[4 * w + 1] = o.y; hs[4 * w + 2] = o.z; hs[4 * w + 3] = o.w;
+                });
+#else
+                static_for<UP>([&](auto uc) { hs[decltype(uc)::value] = 0.0f; });
+#endif
                 static_for<U>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     const int q = q0 + u * 64;
                     float4 v = Cell<VT>::widen(buf[s & 1][u]);
+#if !(RML_DS_ABL & 2)
                     const bool in = q < lim;
                     v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+#endif
                     const float h = (v.x + v.y) + (v.z + v.w);
                     th += h;
+                    hs[u] += h;
+#if !(RML_DS_ABL & 4)
                     accr[u % P].x += v.x; accr[u % P].y += v.y; accr[u % P].z += v.z; accr[u % P].w += v.w;
                     asm volatile("" : "+v"(accr[u % P].x), "+v"(accr[u % P].y), "+v"(accr[u % P].z), "+v"(accr[u % P].w));  // pin the update here
-                    __hip_atomic_fetch_add(strip + q, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
                 });
+#if !(RML_DS_ABL & 1)
+                static_for<UP / 4>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    slot[w] = make_float4(hs[4 * w], hs[4 * w + 1], hs[4 * w + 2], hs[4 * w + 3]);
+                });
+#else
+                asm volatile("" : "+v"(hs[0]));
+#endif
                 asm volatile("" : "+v"(th));
                 __builtin_amdgcn_sched_barrier(0);
                 if ((gi + s) < GP) {
@@ -268,9 +303,12 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // s_phi[j]: row j = quads [j Z/4, (j+1) Z/4) of the strip
         for (int j = lane; j < Y; j += 64) {
-            const float* rowp = strip + j * ZQ;
             float sum = 0.0f;
-            for (int q = 0; q < ZQ; ++q) sum += rowp[q];
+            for (int c = 0; c < ZQ; ++c) {
+                const int q = j * ZQ + c;                // quad of the plane -> (instruction t, lane l) -> slot (group, u) of lane l's row
+                const int t = q >> 6, l = q & 63;
+                sum += strip[l * RSo + (t / U) * UP + (t % U)];
+            }
             prof[X + j] = sum;
         }
         // s_r[k]: the P accumulators cover quads 0 .. 64 P - 1 of the linear plane modulo its period; column c = q mod Z/4
@@ -288,10 +326,7 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
             dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z; dst[3] = sum.w;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
-            const int zn = strip_n > P * 256 ? strip_n : P * 256;
-            for (int q = lane; q < zn; q += 64) strip[q] = 0.0f;       // the next frame accumulates into a clean strip
-        }
+        for (int q = lane; q < strip_alloc; q += 64) strip[q] = 0.0f;   // the next frame accumulates into a clean strip
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int NPROF = X + Y + Z;
         if (a.profiles)
@@ -352,7 +387,10 @@ bool derive_geom(int X, int Y, int Z, int ntgt, DeriveGeom* g) {
     const int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));
     const int pq = Y * ZQ;
     const int NI = (pq + 63) / 64, NG = (NI + U - 1) / U;
-    const int strip_n = NG * U * 64;
+    const int UP = (U + 3) & ~3;
+    int RS = NG * UP + 4;
+    if (!((RS / 4) & 1)) RS += 4;                       // as the kernel computes it
+    const int strip_n = 64 * RS;
     g->P = P; g->U = U; g->NG = NG;
     g->strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
     const size_t bytes = (size_t)g->strip_alloc * 4 + (size_t)((X + Y + Z + 3) & ~3) * 4 + (size_t)ntgt * 12;
