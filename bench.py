@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-walabot", action="store_true", help="skip the secondary Walabot-arena-grid workload")
     ap.add_argument("--no-u8", action="store_true", help="skip the uint8-ingest row (the same frames as 1-byte voxels)")
+    ap.add_argument("--no-slice", action="store_true", help="skip the slice-projection rows (derive -> slice -> SVM, slice with given ijk)")
     ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
                     help="u8: the headline step itself runs on uint8 volumes (per-workload profiles: tools/profile_round.sh); "
                          "the line's value is then the uint8 rate")
@@ -239,6 +240,60 @@ def run_workload(a, env, grid, frames, primary):
         del V8, out8
         torch.cuda.empty_cache()
 
+    # ---- the reference-faithful projection: plane SLICES through a target voxel
+    #      (predict.py:98-107), with the voxel derived on the GPU (common.py:49-80) or given -- separate roofline rows ----
+    slice_rows = None
+    if not a.no_slice and a.ingest != "u8":
+        slice_rows = {}
+        ijk_dev = rml.derive_targets(V, 1)[:, 0, :].contiguous()           # for the "given" row: what an SDK would report
+
+        def timed_steps(fn):
+            o = fn()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            lib.rml_profile_enable(ctx, 1)
+            t0_ = time.perf_counter()
+            for _ in range(a.steps):
+                o = fn()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            dts = time.perf_counter() - t0_
+            nl_, ms_, nf_ = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+            lib.rml_profile_read(ctx, ctypes.byref(nl_), ctypes.byref(ms_), ctypes.byref(nf_))
+            gr = gemm_roofline(lib, ctx)
+            lib.rml_profile_enable(ctx, 0)
+            tt = torch.tensor([dts], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return o, float(tt.item()), max(1, nl_.value), ms_.value, nf_.value, gr
+
+        for key, fn, kern, alg in (
+                ("derive_slice_svm", lambda: svc.decide_volumes(V, mode="slice", scale=True, want_proba=True),
+                 "k_derive_slice", frame_bytes + 16),
+                ("slice_mode", lambda: svc.decide_volumes(V, mode="slice", ijk=ijk_dev, scale=True, want_proba=True, validate_ijk=False),
+                 "k_slice_rows", 4 * D + 12 + 16)):
+            o_s, dt_s, nl_s, ms_s, nf_s, gr_s = timed_steps(fn)
+            avg_s = ms_s / nl_s
+            ach_s = alg * (nf_s / nl_s) / (avg_s * 1e-3) / 1e9 if avg_s > 0 else 0.0
+            val_s = world * B * a.steps / dt_s
+            slice_rows[key] = {"value": round(val_s, 1), "unit": "frames/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
+                               "hbm_frac_end_to_end": round(val_s / world * alg / 1e9 / HBM_PEAK_GBS, 4),
+                               "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach_s, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(ach_s / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(nl_s),
+                                            "avg_launch_ms": round(avg_s, 4), "frames_per_launch": nf_s / nl_s,
+                                            "algorithmic_bytes_per_frame": alg},
+                               "gemm_roofline": gr_s, "_out": o_s}
+        if "ijk" in slice_rows["derive_slice_svm"]["_out"]:
+            slice_rows["derive_slice_svm"]["ijk_equal_rml_derive_targets"] = bool(
+                torch.equal(slice_rows["derive_slice_svm"]["_out"]["ijk"], ijk_dev))
+        slice_rows["slice_mode"]["request_floor_bytes_per_frame"] = 4 * (X * Z + Y * Z) + 128 * X * Y + D + 16
+        slice_rows["slice_mode"]["note"] = ("algorithmic = 4*D read + 28 B; every xy value lives in its own 128-byte memory request (rows are "
+                                            ">= 512 B apart), so no kernel fetches less than request_floor_bytes_per_frame")
+
     if rank != 0:
         del V, out, svc
         torch.cuda.empty_cache()
@@ -330,11 +385,37 @@ def run_workload(a, env, grid, frames, primary):
                                           np.searchsorted(model["classes"], cls[:npar].cpu().numpy())).mean()),
     }
 
-    # ---- CPU baseline (rank 0, N = 1 only): the reference's own path with the reference's own libraries -- numpy max ->
+    if slice_rows:
+        nsl = int(min(512 if primary else 256, B, npar))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_np as ONP
+        ijk_ref = np.array([[t.i, t.j, t.k] for v in vh[:nsl] for t in ONP.get_derived_targets(v, X, Y, Z)], dtype=np.int32)
+        sxz, syz, sxy = OC.project_slice(vh[:nsl], ijk_ref)
+        sref = OC.svm(OC.features(sxz, syz, sxy, scale=True), sv_f64(model), model["dual_coef"], model["intercept"], model["n_support"],
+                      model["gamma"], "rbf", model["calib_a"], model["calib_b"], threads=threads)
+        for key, r in slice_rows.items():
+            o_s = r.pop("_out")
+            r["parity"] = {
+                "frames": nsl,
+                "label_vote_mismatch": int((o_s["label_vote"][:nsl].cpu().numpy() != sref["label_vote"]).sum()),
+                "label_calib_mismatch": int((o_s["label_calib"][:nsl].cpu().numpy() != sref["label_calib"]).sum()),
+                "dec_ovo_max_abs_err": float(np.abs(o_s["dec_ovo"][:nsl].cpu().numpy() - sref["dec_ovo"]).max()),
+                "proba_max_abs_err": float(np.abs(o_s["proba"][:nsl].cpu().numpy() - sref["proba"]).max())}
+            if "ijk" in o_s:
+                # compared by energy: the reference's argpartition leaves exact ties open
+                gi = o_s["ijk"][:nsl].cpu().numpy()
+                bad = 0
+                for b in range(nsl):
+                    prof = ONP.axis_energy_profiles(vh[b])
+                    bad += int(any(prof[ax][gi[b, ax]] != prof[ax][ijk_ref[b, ax]] for ax in range(3)))
+                r["parity"]["derived_target_mismatch"] = bad
+            del o_s
+
+    # ---- CPU baseline (rank 0): the reference's own path with the reference's own libraries -- numpy max ->
     #      scipy.ndimage.zoom(.,1.0) + concatenate (common.process_samples) -> sklearn CalibratedClassifierCV(SVC(rbf)).predict
     #      (SURVEY.md §8d), single-process and on all host cores; the C port of the oracle is kept as a second figure ---
     cpu = None
-    if not a.no_cpu and world == 1:
+    if not a.no_cpu:                    # rank 0, every N (north_star: "timed in the same run"); the other ranks wait at the next barrier
         BS = _bench_support()
         gl = out["label_calib"][:npar].cpu().numpy()
         try:
@@ -370,7 +451,7 @@ def run_workload(a, env, grid, frames, primary):
                    if world > 1 else "single GPU"},
         "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roofline, "gemm_roofline": groof, "projection_only": proj_only, "cpu_baseline": cpu, "parity": parity,
-        "uint8_ingest": u8,
+        "uint8_ingest": u8, "slice_rows": slice_rows,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
     del V, out, svc
@@ -761,6 +842,10 @@ def main():
             cfgs.append({"tag": tag + "_f32", "grid": g, "frames": int(r["roofline"]["frames_per_launch"]), "u8": False})
             if r.get("uint8_ingest"):
                 cfgs.append({"tag": tag + "_u8", "grid": g, "frames": int(r["uint8_ingest"]["roofline"]["frames_per_launch"]), "u8": True})
+            for key, mode in (("derive_slice_svm", "derive_slice"), ("slice_mode", "slice")):
+                if r.get("slice_rows"):
+                    cfgs.append({"tag": tag + "_" + key, "grid": g, "frames": int(r["slice_rows"][key]["roofline"]["frames_per_launch"]),
+                                 "u8": False, "mode": mode})
         tr = None
         try:
             torch.cuda.empty_cache()
@@ -779,12 +864,18 @@ def main():
                 if t and r.get("uint8_ingest"):
                     r["uint8_ingest"]["roofline"]["traffic"] = t["hbm_bytes"]
                     r["uint8_ingest"]["roofline"]["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "kernel", "source")}
+                for key in ("derive_slice_svm", "slice_mode"):
+                    t = tr.get(tag + "_" + key)
+                    if t and r.get("slice_rows"):
+                        rr = r["slice_rows"][key]["roofline"]
+                        rr["traffic"] = t["hbm_bytes"]
+                        rr["traffic_over_algorithmic"] = round(t["hbm_bytes"] / (rr["algorithmic_bytes_per_frame"] * rr["frames_per_launch"]), 3)
+                        rr["traffic_detail"] = {k: t[k] for k in ("fetch_bytes", "write_bytes", "kernel")}
 
     if rank == 0 and world > 1:
         for r in (res, wal):
             if r is not None:
                 r["roofline"]["traffic_note"] = "not measured at N > 1: the PMC passes run a single-process child; see the N = 1 line"
-                r["cpu_baseline_note"] = "timed at N = 1 only"
 
     gen_row = None
     if not a.no_general:
@@ -829,28 +920,111 @@ def main():
             res["roofline"]["frac_of_measured_copy"] = round(res["roofline"]["achieved"] / copy_gbs, 4)
         except Exception:
             pass
+        # ---- the line.  The driver keeps only the LAST kilobytes of stdout, so the verbose material goes FIRST (under "doc") and
+        #      the contract keys, the compact roofline / cpu_baseline objects and a one-screen summary of every row go last ----
+        doc = {"config_detail": res["config"], "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"],
+               "cpu_baseline": res["cpu_baseline"], "parity": res["parity"], "projection_only_configs1": res["projection_only"],
+               "uint8_ingest": res["uint8_ingest"], "slice_rows": res.get("slice_rows"), "model": res["model"]}
+        if wal is not None:
+            doc["walabot_grid"] = wal
+        if gen_row:
+            doc["general_rows"] = gen_row
+        if dnn_row is not None:
+            doc["dnn_forward"] = dnn_row
+        if sgan_row is not None:
+            doc["sgan_train_step"] = sgan_row
+
+        # parity gate ("mismatch counts must be 0"): any label mismatch or a decision value off by more than 1e-5 on
+        # any SVM row fails the run (exit status 3, after the line is printed)
+        fails = []
+
+        def gate(name, par):
+            if not par:
+                return
+            for k in ("label_vote_mismatch", "label_calib_mismatch", "derived_target_mismatch"):
+                if par.get(k, 0) != 0:
+                    fails.append("%s.%s=%d" % (name, k, par[k]))
+            if "dec_ovo_max_abs_err" in par and not (par["dec_ovo_max_abs_err"] <= 1e-5):
+                fails.append("%s.dec_ovo_max_abs_err=%.3g" % (name, par["dec_ovo_max_abs_err"]))
+
+        def compact(r):
+            """value / end-to-end HBM fraction / in-situ roofline fraction of the dominant kernel / parity counts of one workload row"""
+            if r is None:
+                return None
+            c = {"v": r["value"], "e2e": r["hbm_frac_end_to_end"], "roof": r["roofline"]["frac"], "k": r["roofline"]["kernel"]}
+            if r["roofline"].get("traffic") is not None and r["roofline"].get("frames_per_launch"):
+                c["traffic_x"] = round(r["roofline"]["traffic"] / (r["roofline"]["algorithmic_bytes_per_frame"] * r["roofline"]["frames_per_launch"]), 3)
+            par = r.get("parity")
+            if par:
+                c["par"] = [par["frames"], par["label_vote_mismatch"], par["label_calib_mismatch"], float("%.2g" % par["dec_ovo_max_abs_err"])]
+            if r.get("gemm_roofline"):
+                c["gemm"] = r["gemm_roofline"]["frac"]
+            return c
+
+        summ = {}
+        for tag, r in (("g64x64x128" if grid == (64, 64, 128) else "x".join(map(str, grid)), res), ("walabot_22x31x176", wal)):
+            if r is None:
+                continue
+            gate(tag, r["parity"])
+            row = {"f32": compact(r)}
+            u8r = r.get("uint8_ingest")
+            if u8r:
+                row["u8"] = {"v": u8r["value"], "e2e": u8r["hbm_frac_end_to_end"], "roof": u8r["roofline"]["frac"], "same_bits": u8r["identical_to_f32_ingest"]}
+                if not u8r["labels_identical"]:
+                    fails.append(tag + ".uint8_ingest.labels_differ")
+            for key, sr in (r.get("slice_rows") or {}).items():
+                gate(tag + "." + key, sr.get("parity"))
+                row[key] = compact(sr)
+            summ[tag] = row
+        if res["projection_only"]:
+            summ["proj_only_configs1"] = {k: v["frac"] for k, v in res["projection_only"].items()}
+        if gen_row:
+            for tag, g in (("general_rows", gen_row), ("general_rows_walabot", gen_row.get("walabot_grid"))):
+                if not g:
+                    continue
+                gate(tag, g["parity"]); gate(tag + ".f64", g["float64_mfma_path"]["parity"]); gate(tag + ".from_volumes", g["from_volumes"]["parity"])
+                summ[tag] = {"v": g["value"], "mfma": g["roofline"]["frac"], "f64_v": g["float64_mfma_path"]["value"], "from_vol_v": g["from_volumes"]["value"],
+                             "par": [g["parity"]["frames"], g["parity"]["label_vote_mismatch"], g["parity"]["label_calib_mismatch"],
+                                     float("%.2g" % g["parity"]["dec_ovo_max_abs_err"])]}
+        if dnn_row is not None:
+            dp = dnn_row["parity"]
+            if dp["label_mismatch_where_oracle_margin_gt_1e-2"] != 0:
+                fails.append("dnn.label_mismatch_where_oracle_margin_gt_1e-2=%d" % dp["label_mismatch_where_oracle_margin_gt_1e-2"])
+            summ["dnn_configs3"] = {"v": dnn_row["value"], "v_u8": dnn_row["value_uint8_volumes"], "mfma": dnn_row["roofline"]["frac"],
+                                    "par": [dp["frames"], dp["label_mismatch_where_oracle_margin_gt_1e-2"], float("%.2g" % dp["proba_max_abs_err_vs_float64_oracle"])]}
+        if sgan_row is not None and "value" in sgan_row:
+            summ["sgan_configs4"] = {"v": sgan_row["value"], "ms": sgan_row["ms_per_step"], "same": sgan_row["replicas_identical"]}
+        summ["parity_gate"] = "pass" if not fails else fails
+        rf = res["roofline"]
+        cb = res["cpu_baseline"]
         line = {
+            "doc": doc,
             "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 volumes -> u8 codes, i8 MFMA (exact int32 dot), f64 epilogue", "data": "synthetic",
-            "config": res["config"], "hbm_frac_end_to_end": res["hbm_frac_end_to_end"],
-            "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"], "cpu_baseline": res["cpu_baseline"],
-            "parity": res["parity"], "projection_only_configs1": res["projection_only"],
-            "uint8_ingest": res["uint8_ingest"], "model": res["model"], "labels_crc32": res["labels_crc32"],
+            "config": {"workload": res["config"]["workload"], "parallelism": res["config"]["parallelism"],
+                       "global_frames": res["config"]["global_frames"],
+                       "collective_backend": (dist.get_backend() if world > 1 else None)},
+            "hbm_frac_end_to_end": res["hbm_frac_end_to_end"], "labels_crc32": res["labels_crc32"],
+            "roofline": {"bound": "hbm", "achieved": rf["achieved"], "peak": rf["peak"], "unit": "GB/s", "frac": rf["frac"],
+                         "traffic": rf.get("traffic"), "kernel": rf["kernel"], "avg_launch_ms": rf["avg_launch_ms"],
+                         "frames_per_launch": rf["frames_per_launch"], "algorithmic_bytes_per_frame": rf["algorithmic_bytes_per_frame"]},
+            "cpu_baseline": None if cb is None else {"value": cb.get("value"), "unit": "frames/s", "cores": cb.get("cores"), "kind": cb.get("kind", "port"),
+                                                     "sample": (cb.get("sample") or cb.get("error") or "")[:160],
+                                                     "label_mismatch_vs_gpu": cb.get("label_mismatch_vs_gpu")},
+            "summary": summ,
         }
-        if wal is not None:
-            line["walabot_grid"] = wal
-        if gen_row:
-            line["general_rows"] = gen_row
-        if dnn_row is not None:
-            line["dnn_forward"] = dnn_row
-        if sgan_row is not None:
-            line["sgan_train_step"] = sgan_row
         print(json.dumps(line))
+        sys.stdout.flush()
+        gate_failed = bool(fails)
+    else:
+        gate_failed = False
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if gate_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

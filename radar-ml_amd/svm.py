@@ -193,11 +193,12 @@ class GpuSVC(_Base):
         return ovo, ovr, vote, proba, lab
 
     def decide_volumes(self, volumes, mode="max", ijk=None, proj_mask=ProjMask(True, True, True), scale=True,
-                       want_proba=None):
+                       want_proba=None, validate_ijk=True):
         """Fused batched path: (B,X,Y,Z) volumes -> projection -> SVM, features never leave the GPU.
         Returns a dict of CUDA tensors (dec_ovo, dec_ovr, label_vote[, proba, label_calib]); mode='slice' without ``ijk``
         slices through the strongest derived target of every frame (common.py:49-80) and also returns it as ``ijk`` (B,3)
-        where the one-pass kernel ran."""
+        where the one-pass kernel ran.  ``validate_ijk=False``: the caller vouches that a DEVICE ``ijk`` is within
+        [-size, size) -- the range check of a device tensor costs a synchronising read-back per call."""
         torch = _torch()
         lib = _lib.load()
         from .common import derive_targets, _slice_indices, process_volumes
@@ -222,7 +223,7 @@ class GpuSVC(_Base):
             if fused_derive:
                 T = 1
             else:
-                ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
+                ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=validate_ijk and not derived)
             if T > 1:
                 # several targets per frame (predict.py:93-119 classifies every target of one image): slice rows first,
                 # then the SVM on the B*T rows; outputs are (B*T, ...) in frame-major order

@@ -53,16 +53,63 @@ def test_two_rank_bench_on_one_device_matches_the_single_process_run():
                          stderr=subprocess.PIPE, timeout=1500)
     assert two.returncode == 0, two.stderr.decode()[-3000:]
     l2 = _line(two.stdout.decode())
+    _check_pair(l1, l2, per_rank)
+    assert l2["config"]["collective_backend"] == "gloo"
+
+
+def _check_pair(l1, l2, per_rank):
+    """l1: the single-process line of the global batch, l2: the two-rank line (bench.py prints the verbose rows under "doc" and
+    the compact ones last)."""
     assert l2["n_gpus"] == 2 and l2["config"]["global_frames"] == 2 * per_rank == l1["config"]["global_frames"]
     # every rank classified its slab of the same global batch: gathered labels == single-process labels, both grids
     assert l2["labels_crc32"] == l1["labels_crc32"]
-    assert l2["walabot_grid"]["labels_crc32"] == l1["walabot_grid"]["labels_crc32"]
+    assert l2["doc"]["walabot_grid"]["labels_crc32"] == l1["doc"]["walabot_grid"]["labels_crc32"]
     for ln in (l1, l2):
-        assert ln["parity"]["label_calib_mismatch"] == 0 and ln["parity"]["label_vote_mismatch"] == 0
-        assert ln["parity"]["dec_ovo_max_abs_err"] <= 1e-5
-        assert ln["general_rows"]["parity"]["label_calib_mismatch"] == 0 and ln["general_rows"]["parity"]["dec_ovo_max_abs_err"] <= 1e-5
-    sg = l2["sgan_train_step"]
+        d = ln["doc"]
+        assert d["parity"]["label_calib_mismatch"] == 0 and d["parity"]["label_vote_mismatch"] == 0
+        assert d["parity"]["dec_ovo_max_abs_err"] <= 1e-5
+        assert d["general_rows"]["parity"]["label_calib_mismatch"] == 0 and d["general_rows"]["parity"]["dec_ovo_max_abs_err"] <= 1e-5
+        # the reference-faithful rows (derive -> slice -> SVM in one pass; slices at given voxels): parity against the oracle
+        for g in (d, d["walabot_grid"]):
+            for key in ("derive_slice_svm", "slice_mode"):
+                par = g["slice_rows"][key]["parity"]
+                assert par["label_calib_mismatch"] == 0 and par["label_vote_mismatch"] == 0 and par["dec_ovo_max_abs_err"] <= 1e-5
+            assert g["slice_rows"]["derive_slice_svm"]["parity"]["derived_target_mismatch"] == 0
+        assert ln["summary"]["parity_gate"] == "pass"
+        # the compact objects at the END of the line (the driver keeps the last kilobytes): standard keys + summary within 4 KB
+        tail = json.dumps({k: v for k, v in ln.items() if k != "doc"})
+        assert len(tail) < 4096, len(tail)
+        assert list(ln.keys())[0] == "doc" and list(ln.keys())[-1] == "summary"
+    sg = l2["doc"]["sgan_train_step"]
     assert "error" not in sg, sg
     assert sg["replicas_identical"] is True and sg["hip_graph"] is True and sg["n_gpus"] == 2
-    assert l2["roofline"].get("traffic") is None and "traffic_note" in l2["roofline"]
-    assert l2["dnn_forward"]["parity"]["label_mismatch"] <= 2
+    assert l2["roofline"].get("traffic") is None and "traffic_note" in l2["doc"]["roofline"]
+    assert l2["doc"]["dnn_forward"]["parity"]["label_mismatch"] <= 2
+
+
+def test_two_rank_bench_over_rccl_when_two_devices_are_visible():
+    """The same comparison on TWO devices over RCCL (backend "nccl"): the all_gather_into_tensor of the labels and the flat-bucket
+    gradient all-reduce beside HIP-graph replay on a real communicator.  Arms itself where the box has >= 2 GPUs (the build
+    boxes have one: skipped there), so that the first multi-GPU run of the driver is not also the first RCCL run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices (RCCL refuses two ranks on one)")
+    per_rank = 1024
+    common = ["--steps", "2", "--warmup", "1", "--train", "1500", "--no-cpu", "--no-pmc", "--no-u8", "--parity", "256",
+              "--general-frames", "512", "--dnn-frames", "512", "--dnn-parity", "64"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RML_BENCH_ONE_DEVICE", None)
+    import tempfile
+    env["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="rml_miopen_db_")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", str(2 * per_rank),
+                          "--walabot-frames", str(2 * per_rank)] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=1500)
+    assert one.returncode == 0, one.stderr.decode()[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", str(per_rank),
+                          "--walabot-frames", str(per_rank)] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=1500)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    l1, l2 = _line(one.stdout.decode()), _line(two.stdout.decode())
+    _check_pair(l1, l2, per_rank)
+    assert l2["config"]["collective_backend"] == "nccl"           # = RCCL on ROCm

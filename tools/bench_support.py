@@ -271,7 +271,7 @@ def measure_traffic(configs, timeout_s=240):
             db = _find_db(out)
             if db is None or order is None:
                 return None
-            rows = [x for x in _read_counter(db, counter) if "k_project" in x[0]]
+            rows = [x for x in _read_counter(db, counter) if any(k in x[0] for k in ("k_project", "k_derive_slice", "k_slice_rows"))]
             # the child launches every configuration `reps` times in order and nothing else that is called k_project*
             reps = order["reps"]
             if len(rows) != reps * len(order["tags"]):

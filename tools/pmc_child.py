@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Child of tools/bench_support.measure_traffic, run under `rocprofv3 --kernel-trace --pmc <counter>`: launches the
 projection kernel of the fused pipeline's first pass (codes + row statistics, csrc/project.hip) for every configuration
-in argv[1] (JSON list of {"tag", "grid", "frames", "u8"}), `reps` times each, and prints the launch order."""
+in argv[1] (JSON list of {"tag", "grid", "frames", "u8"[, "mode": "max" | "derive_slice" | "slice"]}), `reps` times each, and prints the launch order."""
 import json
 import os
 import sys
@@ -32,10 +32,19 @@ def main():
         isum = torch.empty(B, dtype=torch.int32, device=dev)
         isq = torch.empty(B, dtype=torch.int64, device=dev)
         flags = torch.empty(B, dtype=torch.int32, device=dev)
+        mode = c.get("mode", "max")
+        ijk = torch.tensor([[X // 2, Y // 2, Z // 2]], dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
         torch.cuda.synchronize()
         for _ in range(reps):
-            _lib.check(lib.rml_project(ctx, V.data_ptr(), 1 if c["u8"] else 0, B, X, Y, Z, 0, None, 255.0, 7, None, 0, q.data_ptr(), ldq,
-                                       isum.data_ptr(), isq.data_ptr(), None if c["u8"] else flags.data_ptr(), st), "rml_project")
+            if mode == "derive_slice":          # k_derive_slice: derive + slices, codes + statistics (the pipeline's first pass)
+                _lib.check(lib.rml_derive_slice(ctx, V.data_ptr(), 1 if c["u8"] else 0, B, X, Y, Z, 1, ijk.data_ptr(), None, 255.0, 7, None, 0,
+                                                q.data_ptr(), ldq, isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st), "rml_derive_slice")
+            elif mode == "slice":               # k_slice_rows at a given voxel
+                _lib.check(lib.rml_project(ctx, V.data_ptr(), 1 if c["u8"] else 0, B, X, Y, Z, 1, ijk.data_ptr(), 255.0, 7, None, 0, q.data_ptr(),
+                                           ldq, isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st), "rml_project")
+            else:
+                _lib.check(lib.rml_project(ctx, V.data_ptr(), 1 if c["u8"] else 0, B, X, Y, Z, 0, None, 255.0, 7, None, 0, q.data_ptr(), ldq,
+                                           isum.data_ptr(), isq.data_ptr(), None if c["u8"] else flags.data_ptr(), st), "rml_project")
         torch.cuda.synchronize()
         del V, q
         torch.cuda.empty_cache()
