@@ -102,6 +102,13 @@ int rml_ctx_create(int device, rml_ctx** out);
 int rml_ctx_destroy(rml_ctx* ctx);
 int rml_ctx_device(const rml_ctx* ctx);
 
+/* Context options.  RML_OPT_PROJECT_SHARE_CU (0 / 1, default 0): the stand-alone projection entry points (rml_project,
+ * rml_project_planes, rml_project_slices) launch their persistent kernels the way the fused pipeline does beside its GEMM --
+ * one workgroup per CU with a padded LDS request -- so that a kernel the caller runs on ANOTHER stream (the CNN path runs the
+ * bicubic resize of batch b beside the projection of batch b+1: radar-ml_amd/dnn.py) finds room on every CU.  Same results. */
+#define RML_OPT_PROJECT_SHARE_CU 1
+int rml_ctx_set_option(rml_ctx* ctx, int option, int value);
+
 /* In-situ timing of the projection launches issued by rml_project_svm (bench.py's roofline line):
  * while enabled, a hipEvent pair is recorded around every projection launch on the stream it is
  * launched on.  rml_profile_read synchronises, returns the number of launches, the summed

@@ -31,6 +31,7 @@ SIGNATURES = {
     "rml_ctx_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "rml_ctx_destroy": (c_int, [c_void_p]),
     "rml_ctx_device": (c_int, [c_void_p]),
+    "rml_ctx_set_option": (c_int, [c_void_p, c_int, c_int]),
     "rml_profile_enable": (c_int, [c_void_p, c_int]),
     "rml_profile_read": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_int64)]),
     "rml_profile_read_gemm": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_double)]),
@@ -91,6 +92,7 @@ SIGNATURES = {
 }
 
 MODE_MAX, MODE_SLICE, MODE_SUM, MODE_MAX_NAN = 0, 1, 2, 3
+OPT_PROJECT_SHARE_CU = 1
 AUG_ROTATE, AUG_ZOOM, AUG_NOISE = 0, 1, 2
 VOL_F32, VOL_U8 = 0, 1
 MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM, "max_nan": MODE_MAX_NAN}

@@ -191,3 +191,12 @@ extern "C" int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_m
 }
 
 extern "C" int rml_ctx_device(const rml_ctx* ctx) { return ctx ? ctx->device : RML_ERR_INVALID; }
+
+extern "C" int rml_ctx_set_option(rml_ctx* ctx, int option, int value) {
+    RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_ctx_set_option: ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    switch (option) {
+        case RML_OPT_PROJECT_SHARE_CU: ctx->opt_project_share_cu = value ? 1 : 0; return RML_OK;
+        default: RML_REQUIRE(false, RML_ERR_INVALID, "rml_ctx_set_option: unknown option %d", option);
+    }
+}

@@ -724,6 +724,7 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     fill_params(pp, V, B, X, Y, Z, ijk, o);       // B counts output rows
     pp.tpf = targets_per_frame;
     if (getenv("RML_WAVE_SHARE")) pp.o.share_cu = 1;    // measurement knob: the pipeline's kernel configuration in a stand-alone launch
+    if (ctx && ctx->opt_project_share_cu) pp.o.share_cu = 1;      // rml_ctx_set_option(RML_OPT_PROJECT_SHARE_CU)
     // with a CU partition (RML_GEMM_CUS) the masked projection stream owns 32 - g CUs of every XCD: persistent grids are sized for them
     const int num_cu = !ctx ? 256 : ((ctx->gemm_cus_per_xcd > 0 && st == ctx->proj_stream) ? 8 * (32 - ctx->gemm_cus_per_xcd) : ctx->num_cu);
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);

@@ -17,21 +17,18 @@ namespace {
 
 using namespace rmlproj;
 
-// BALLAST: 64 extra live registers (260 in all): two of these waves can then not share a SIMD's 512 registers while a
-// 128-register GEMM wave still fits beside one -- the pipeline's way of getting exactly one projection workgroup per CU when the
-// GEMM workgroup beside it needs half of the LDS itself (k_svm_gemm_ring128: 80 KiB), so that an LDS pad cannot do it.
-template <int MODE, int NI, int RG, int NGRP, bool PRED, bool BALLAST>
-__global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams a) {
+// ZQ4 = Z/16 (float4 of per-quad partials per row), NI = instructions per group of RG rows (RG * Z/4 = NI * 64), NGRP groups per
+// plane (even: the two register buffers alternate statically), NMASK = trailing groups of a plane that may run past it (their
+// loads clamp to the plane's last quad, their values are replaced by the identity): 1 when only the last group can be partial,
+// 2 when the plane may end inside the second to last group (the last one is then empty)
+template <int MODE, int ZQ4, int NI, int RG, int NGRP, int NMASK, bool PRED>
+__global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
 #ifdef RML_PRIO_PROJ
     __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
 #endif
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
-    float ballast[BALLAST ? 64 : 1];
-    if constexpr (BALLAST) {
-#pragma unroll
-        for (int i = 0; i < 64; ++i) ballast[i] = __int_as_float((int)threadIdx.x + i);
-    }
-    static_assert(NGRP == 2 && RG % 8 == 0, "two groups per plane (the row buffers alternate statically); xz folds 8 rows per wait");
+    static_assert(NGRP % 2 == 0 && RG % 8 == 0 && NMASK >= 1 && NMASK <= NGRP,
+                  "an even number of groups per plane (the row buffers alternate statically); xz folds 8 rows per wait");
     constexpr int NT = NI * NGRP;                       // load instructions per plane
     const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
     const int lane = threadIdx.x & 63;
@@ -74,17 +71,13 @@ __global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams
         static_for<NI>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const uint32_t q = (uint32_t)((g * NI + u) * 64) + lane_t;
-            if constexpr (g == NGRP - 1) dst[u] = ld_stream(lV + (q < qlast ? q : qlast));
-            else dst[u] = ld_stream(lV + q);            // every group but the last is whole
+            if constexpr (g >= NGRP - NMASK) dst[u] = ld_stream(lV + (q < qlast ? q : qlast));
+            else dst[u] = ld_stream(lV + q);            // the leading groups are whole
         });
     };
     Emitter em(a, cf);
     fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
     for (; cf < a.B; cf += stride) {
-        if constexpr (BALLAST) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(ballast[i]));
-        }
         em.reset(cf);
         float4 yz[NT];
         static_for<NT>([&](auto tc) { yz[decltype(tc)::value] = id4; });
@@ -103,7 +96,7 @@ __global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams
                     float4 v = buf[g & 1][u];
                     // quads past the plane (only in its last group) hold the identity: xz folds whole rows of the image.
                     // Branch-free: a branch around the select makes hipcc drain vmcnt after every load of the group
-                    if constexpr (g == NGRP - 1) {
+                    if constexpr (g >= NGRP - NMASK) {
                         const bool in = t * 64 + lane < pq;
                         v.x = in ? v.x : id; v.y = in ? v.y : id; v.z = in ? v.z : id; v.w = in ? v.w : id;
                     }
@@ -136,9 +129,9 @@ __global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams
                     if (lane_e < Y) {
                         const float* rowp = xyl + lane_e * ZQ;      // row j = quads [j ZQ, (j+1) ZQ), one float per quad
                         float m = id;
-                        float4 r4[NI];                              // ZQ / 4 = NI float4 per row (44 quads: 11)
-                        static_for<NI>([&](auto qc) { constexpr int q = decltype(qc)::value; r4[q] = *reinterpret_cast<const float4*>(rowp + 4 * q); });
-                        static_for<NI>([&](auto qc) {
+                        float4 r4[ZQ4];                             // Z/16 float4 of per-quad partials per row (44 quads: 11)
+                        static_for<ZQ4>([&](auto qc) { constexpr int q = decltype(qc)::value; r4[q] = *reinterpret_cast<const float4*>(rowp + 4 * q); });
+                        static_for<ZQ4>([&](auto qc) {
                             constexpr int q = decltype(qc)::value;
                             m = Op<MODE>::f(m, Op<MODE>::f(Op<MODE>::f(r4[q].x, r4[q].y), Op<MODE>::f(r4[q].z, r4[q].w)));
                         });
@@ -159,52 +152,62 @@ __global__ __launch_bounds__(256, BALLAST ? 1 : 2) void k_project_lin(ProjParams
         });
         em.finish_wave(lane_f);
     }
-    if constexpr (BALLAST) {                            // a use the compiler cannot remove (never true: the values are small integers' bits)
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) { asm volatile("" : "+v"(ballast[i])); acc += ballast[i]; }
-        if (acc == 123456.789f && a.o.row_flags) a.o.row_flags[0] = 0;
-    }
 }
 
-template <int MODE, bool BALLAST>
+template <int MODE, int ZQ4, int NI, int RG, int NGRP, int NMASK>
 void launch_lin(const ProjParams& pp, int num_cu, hipStream_t st) {
-    constexpr int NI = 11, RG = 16, NGRP = 2;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
     const int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
     const int64_t want = (pp.B + 3) / 4;
-    const int64_t cap = (int64_t)num_cu * (BALLAST ? 1 : per_cu);
+    const int64_t cap = (int64_t)num_cu * per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
-    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) = 66 KB.  Beside a GEMM (share_cu = 1) the request is padded past
-    // half of the CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see launch_wave);
-    // share_cu = 2: the BALLAST variant does that with registers and asks for its own 66 KB only
+    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) (44 quads: 66 KB).  Beside a GEMM (share_cu = 1) the request is
+    // padded past half of the CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see
+    // launch_wave)
     const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
-    const size_t lds = (!BALLAST && pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 81 * 1024) ? 81 * 1024 : mine;
+    const size_t lds = (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 81 * 1024) ? 81 * 1024 : mine;
     if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>);
-        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, true, BALLAST>), grid, block, lds, st, pp);
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>);
+        hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>), grid, block, lds, st, pp);
     } else {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, NI, RG, NGRP, false, BALLAST>);
-        hipLaunchKernelGGL((k_project_lin<MODE, NI, RG, NGRP, false, BALLAST>), grid, block, lds, st, pp);
+        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>);
+        hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>), grid, block, lds, st, pp);
     }
+}
+
+// rows of ZQ = 40 / 48 / 56 quads in groups of 8 rows (5 / 6 / 7 whole instructions), mode MAX
+template <int ZQ>
+bool launch_lin8(const ProjParams& pp, int num_cu, hipStream_t st) {
+    if (pp.Y > 8 && pp.Y <= 16) { launch_lin<RML_MODE_MAX, ZQ / 4, ZQ / 8, 8, 2, 1>(pp, num_cu, st); return true; }
+    if (pp.Y > 16 && pp.Y <= 32) { launch_lin<RML_MODE_MAX, ZQ / 4, ZQ / 8, 8, 4, 2>(pp, num_cu, st); return true; }
+    return false;
 }
 
 }  // namespace
 
 namespace rmlproj {
 
-// rows of 44 quads in groups of 16 (11 whole instructions); two groups: 17..32 rows.  float32 volumes, modes MAX and SUM.
+// Rows that do not fill a load instruction, loaded as the linear array of quads a plane is.  44 quads (the Walabot arena grid) in
+// groups of 16 rows (11 whole instructions), two groups: 17..32 rows, modes MAX and SUM; 40 / 48 / 56 quads (Z = 160 / 192 / 224:
+// other arenas the reference resizes to, predict.py:34-54) in groups of 8 rows, 9..32 rows, mode MAX.  float32 volumes.
 // RML_LINPLANE=0 turns it off (k_project_wave takes the shape then).
 bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st) {
-    if (pp.ZQ != 44 || pp.Y <= 16 || pp.Y > 32 || pp.Z != 4 * pp.ZQ) return false;
+    if (pp.Z != 4 * pp.ZQ) return false;
     if (pp.B < 2 * (int64_t)num_cu) return false;       // small batches stay on the workgroup-per-frame kernels (latency)
     const char* env = getenv("RML_LINPLANE");
     if (env && atoi(env) == 0) return false;
-    const bool ballast = pp.o.share_cu == 2;
-    if (mode == RML_MODE_MAX) { if (ballast) launch_lin<RML_MODE_MAX, true>(pp, num_cu, st); else launch_lin<RML_MODE_MAX, false>(pp, num_cu, st); }
-    else if (mode == RML_MODE_SUM) { if (ballast) launch_lin<RML_MODE_SUM, true>(pp, num_cu, st); else launch_lin<RML_MODE_SUM, false>(pp, num_cu, st); }
-    else return false;
-    return true;
+    if (pp.ZQ == 44) {
+        if (pp.Y <= 16 || pp.Y > 32) return false;
+        if (mode == RML_MODE_MAX) launch_lin<RML_MODE_MAX, 11, 11, 16, 2, 1>(pp, num_cu, st);
+        else if (mode == RML_MODE_SUM) launch_lin<RML_MODE_SUM, 11, 11, 16, 2, 1>(pp, num_cu, st);
+        else return false;
+        return true;
+    }
+    if (mode != RML_MODE_MAX) return false;
+    if (pp.ZQ == 40) return launch_lin8<40>(pp, num_cu, st);
+    if (pp.ZQ == 48) return launch_lin8<48>(pp, num_cu, st);
+    if (pp.ZQ == 56) return launch_lin8<56>(pp, num_cu, st);
+    return false;
 }
 
 }  // namespace rmlproj

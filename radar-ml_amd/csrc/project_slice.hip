@@ -31,6 +31,9 @@
 // are bit-exact against NumPy; on other data the float32 rounding follows this kernel's (fixed) order.
 #include "project_shared.h"
 
+#ifndef RML_DERIVE_UB
+#define RML_DERIVE_UB 8     // quads per gather batch of k_derive_slice (variant builds: 4, 16)
+#endif
 #ifndef RML_DS_ABL
 #define RML_DS_ABL 0      // ablation switches of k_derive_slice (variant builds only)
 #endif
@@ -63,71 +66,74 @@ __device__ __forceinline__ int div_small(int q, int d, float rcp) {
     return r;
 }
 
-// the three planes through (i, j, k) of the frame at Vf, by one wave; indices already wrapped into range
+// the three planes through (i, j, k) of the frame at Vf, by one wave; indices already wrapped into range.  Every address is the
+// wave-uniform frame base plus a 32-bit element offset (a frame is far below 4 G elements): the loads take the scalar-base form
+// and need one offset register each instead of a 64-bit pointer pair
 template <typename VT, int UB>
 __device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int j, int k, int X, int Y, int Z, int ZQ,
                                            Emitter& em, int lane) {
     typedef typename Cell<VT>::Q QT;
     const QT* __restrict__ Vq = reinterpret_cast<const QT*>(Vf);
-    const int pq = Y * ZQ;
+    const uint32_t pq = (uint32_t)(Y * ZQ);
     const uint32_t sel = em.a.o.sel;
+    const uint32_t ul = (uint32_t)lane;
     if (sel & 2u) {                                     // yz = V[i, :, :]: the plane as it lies in memory
-        const QT* __restrict__ src = Vq + (int64_t)i * pq;
-        for (int base = 0; base < pq; base += 64 * UB) {
+        const uint32_t o0 = (uint32_t)i * pq;
+        for (uint32_t base = 0; base < pq; base += 64 * UB) {
             QT v[UB];
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const int q = base + u * 64 + lane;
-                v[u] = src[q < pq ? q : pq - 1];
+                const uint32_t q = base + u * 64 + ul;
+                v[u] = Vq[o0 + (q < pq ? q : pq - 1)];
             });
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const int q = base + u * 64 + lane;
+                const uint32_t q = base + u * 64 + ul;
                 if (q < pq) Cell<VT>::emit4(em, 1, (int64_t)q * 4, v[u]);
             });
         }
     }
     if (sel & 1u) {                                     // xz = V[:, j, :]: X rows of Z/4 quads, one plane apart
-        const int n = X * ZQ;
+        const uint32_t n = (uint32_t)(X * ZQ);
         const float rcp = 1.0f / (float)ZQ;
-        const QT* __restrict__ src = Vq + (int64_t)j * ZQ;
-        for (int base = 0; base < n; base += 64 * UB) {
+        const uint32_t o0 = (uint32_t)(j * ZQ);
+        for (uint32_t base = 0; base < n; base += 64 * UB) {
             QT v[UB];
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                int q = base + u * 64 + lane;
+                uint32_t q = base + u * 64 + ul;
                 q = q < n ? q : n - 1;
-                const int ii = div_small(q, ZQ, rcp);
-                v[u] = src[(int64_t)ii * pq + (q - ii * ZQ)];
+                const uint32_t ii = (uint32_t)div_small((int)q, ZQ, rcp);
+                v[u] = Vq[o0 + ii * pq + (q - ii * (uint32_t)ZQ)];
             });
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const int q = base + u * 64 + lane;
+                const uint32_t q = base + u * 64 + ul;
                 if (q < n) Cell<VT>::emit4(em, 0, (int64_t)q * 4, v[u]);
             });
         }
     }
     if (sel & 4u) {                                     // xy = V[:, :, k]: one value per row of the volume
-        const int n = X * Y, n4 = n >> 2;
-        const VT* __restrict__ src = Vf + k;
+        const uint32_t n = (uint32_t)(X * Y), n4 = n >> 2;
+        const uint32_t uz = (uint32_t)Z, uk = (uint32_t)k;
         constexpr int UG = UB / 2 > 0 ? UB / 2 : 1;
-        for (int base = 0; base < n4; base += 64 * UG) {
+        for (uint32_t base = 0; base < n4; base += 64 * UG) {
             VT v[UG][4];
             static_for<UG>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                int q = base + u * 64 + lane;
+                uint32_t q = base + u * 64 + ul;
                 q = q < n4 ? q : n4 - 1;
-                const VT* __restrict__ s4 = src + (int64_t)q * 4 * Z;
-                v[u][0] = s4[0]; v[u][1] = s4[Z]; v[u][2] = s4[2 * (int64_t)Z]; v[u][3] = s4[3 * (int64_t)Z];
+                const uint32_t e0 = q * 4 * uz + uk;
+                v[u][0] = Vf[e0]; v[u][1] = Vf[e0 + uz]; v[u][2] = Vf[e0 + 2 * uz]; v[u][3] = Vf[e0 + 3 * uz];
             });
             static_for<UG>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const int q = base + u * 64 + lane;
+                const uint32_t q = base + u * 64 + ul;
                 if (q < n4) Cell<VT>::emit4(em, 2, (int64_t)q * 4, Cell<VT>::pack(v[u][0], v[u][1], v[u][2], v[u][3]));
             });
         }
-        const int idx = n4 * 4 + lane;
-        if (lane < (n & 3)) em.put1(2, idx, (float)src[(int64_t)idx * Z]);
+        const uint32_t idx = n4 * 4 + ul;
+        if (ul < (n & 3)) em.put1(2, idx, (float)Vf[idx * uz + uk]);
     }
 }
 
@@ -161,14 +167,15 @@ __global__ __launch_bounds__(kThreads) void k_slice_rows(ProjParams a) {
 // derive -> slice, fused: persistent, one wave per frame (see the header comment)
 // ------------------------------------------------------------------------------------------
 template <typename VT, int P, int U>
-__global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
+__global__ __launch_bounds__(512) void k_derive_slice(ProjParams a) {
     static_assert(U % P == 0, "the column of an instruction must be a compile-time function of its slot in the group");
     typedef typename Quad<VT>::T QT;
     const int X = a.X, Y = a.Y, Z = a.Z, ZQ = a.ZQ;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t cf = (int64_t)blockIdx.x * 4 + wave;        // frame being reduced
+    const int wpb = (int)(blockDim.x >> 6);             // 4 waves per workgroup; 8 beside a GEMM (one workgroup per CU)
+    const int64_t stride = (int64_t)gridDim.x * wpb;
+    int64_t cf = (int64_t)blockIdx.x * wpb + wave;      // frame being reduced
     if (cf >= a.B) return;
     const QT* __restrict__ Vall = reinterpret_cast<const QT*>(a.V);
     const int pq = Y * ZQ;                              // quads per plane
@@ -176,126 +183,103 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
     const int NI = (pq + 63) >> 6;                      // load instructions per plane
     const int NG = (NI + U - 1) / U;                    // groups of U instructions per plane (the last one may run past it)
     const int GP = X * NG;                              // groups per frame
-    const int GPe = GP + (GP & 1);                      // the two register buffers alternate statically: an odd frame gets an idle group
     const int T = a.ntgt;
     // wave-private LDS: [strip: the row sums per quad of a plane, later the staged s_r accumulators][s_theta | s_phi | s_r][targets]
     extern __shared__ __align__(16) unsigned char ds_smem[];
     unsigned char* mine = ds_smem + (size_t)wave * a.wave_lds;
     float* strip = reinterpret_cast<float*>(mine);
     constexpr int UP = (U + 3) & ~3;                    // a group's slots in a lane's strip row, padded to whole float4
+    constexpr int PH = (P + 1) / 2;                     // the s_r accumulators are staged through the strip in two halves
     const int RS = NG * UP + 4;                         // row stride in floats: an odd number of float4 (NG * UP / 4 + 1 when that is
     const int RSo = ((RS / 4) & 1) ? RS : RS + 4;       // odd): the 16 lanes of a b128 access hit 16 different bank groups
     const int strip_n = 64 * RSo;
-    const int strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
+    const int strip_alloc = strip_n > PH * 256 ? strip_n : PH * 256;
     float* prof = strip + strip_alloc;
     int* tgt = reinterpret_cast<int*>(prof + ((X + Y + Z + 3) & ~3));
     for (int q = lane; q < strip_alloc; q += 64) strip[q] = 0.0f;
     float4* const myrow = reinterpret_cast<float4*>(strip + lane * RSo);
 
-    // load cursor, one group ahead of the reduction; frames are assigned statically (wave w: w, w + #waves, ...)
+    // load cursor: the group whose loads are in flight; frames are assigned statically (wave w: w, w + #waves, ...).  ONE register
+    // buffer of U quads: slot u is refilled with the next group's quad right behind its reduction, so U loads (U KB) are in
+    // flight per wave at any time, across plane and frame boundaries (the first version alternated two buffers filled in bursts:
+    // twice the registers for between U and 2 U loads in flight)
     int64_t lf = cf;
-    int lgi = 0;                                        // group of the frame (0 .. GPe-1)
+    int lgi = 0;                                        // group of the frame
     int lg = 0;                                         // group of the plane
     const QT* __restrict__ lV = Vall + lf * fq;
     const uint32_t qlast = (uint32_t)(pq - 1);
     auto advance = [&]() __attribute__((always_inline)) {
         ++lgi; ++lg;
-        if (lgi >= GP) {
-            if (lgi == GPe) {                           // next frame of this wave; past the end: re-read (never consumed)
-                lgi = 0; lg = 0;
-                const int64_t nf = lf + stride;
-                lf = nf < a.B ? nf : lf;
-                lV = Vall + lf * fq;
-            } else {
-                lg = 0;                                 // the idle group of an odd frame re-reads the last plane's first group
-            }
+        if (lgi == GP) {                                // next frame of this wave; past the end: re-read (never consumed)
+            lgi = 0; lg = 0;
+            const int64_t nf = lf + stride;
+            lf = nf < a.B ? nf : lf;
+            lV = Vall + lf * fq;
         } else if (lg == NG) {
             lg = 0;
             lV += pq;
         }
     };
-    QT buf[2][U];
-    auto fetch = [&](QT (&dst)[U]) __attribute__((always_inline)) {
-        uint32_t q0 = (uint32_t)(lg * U * 64 + lane);   // opaque per step: no hoisted per-instruction offsets kept alive
-        asm volatile("" : "+v"(q0));
-        static_for<U>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            const uint32_t q = q0 + (uint32_t)(u * 64);
-            // unconditional: lanes past the plane re-read its last quad and are zeroed after the load
-            if constexpr (sizeof(VT) == 4) {
-                typedef float v4f_t __attribute__((ext_vector_type(4)));
-                v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(lV + (q < qlast ? q : qlast)));
-                dst[u] = make_float4(t.x, t.y, t.z, t.w);
-            } else {
-                dst[u] = __builtin_nontemporal_load(lV + (q < qlast ? q : qlast));
-            }
-        });
+    // unconditional: lanes past the plane re-read its last quad and are zeroed after the load
+    auto load1 = [&](const QT* __restrict__ base, uint32_t q) __attribute__((always_inline)) -> QT {
+        if constexpr (sizeof(VT) == 4) {
+            typedef float v4f_t __attribute__((ext_vector_type(4)));
+            v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(base + (q < qlast ? q : qlast)));
+            return make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            return __builtin_nontemporal_load(base + (q < qlast ? q : qlast));
+        }
     };
+    QT buf[U];
+    static_for<U>([&](auto uc) { constexpr int u = decltype(uc)::value; buf[u] = load1(lV, (uint32_t)(u * 64 + lane)); });
     Emitter em(a, cf * T);
-    fetch(buf[0]);
     for (; cf < a.B; cf += stride) {
         float4 accr[P];
         static_for<P>([&](auto pc) { accr[decltype(pc)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
         float th = 0.0f;
         int ci = 0, cg = 0;
-        for (int gi = 0; gi < GPe; gi += 2) {
-            static_for<2>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                advance();
-                fetch(buf[(s + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);      // keep the software pipeline as written (see k_project_wave)
-                const int lim = (gi + s) < GP ? pq : 0; // the idle group contributes nothing
-                const int q0 = cg * U * 64 + lane;
-                // the running row sums of this group's slots: read now, written back behind the reduction
-                float4* const slot = myrow + cg * (UP / 4);
-                float hs[UP];
-#if !(RML_DS_ABL & 1)
-                static_for<UP / 4>([&](auto wc) {
-                    constexpr int w = decltype(wc)::value;
-                    const float4 o = slot[w];
-                    hs[4 * w] = o.x; hs[4 * w + 1] = o.y; hs[4 * w + 2] = o.z; hs[4 * w + 3] = o.w;
-                });
-#else
-                static_for<UP>([&](auto uc) { hs[decltype(uc)::value] = 0.0f; });
-#endif
-                static_for<U>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const int q = q0 + u * 64;
-                    float4 v = Cell<VT>::widen(buf[s & 1][u]);
-#if !(RML_DS_ABL & 2)
-                    const bool in = q < lim;
-                    v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
-#endif
-                    const float h = (v.x + v.y) + (v.z + v.w);
-                    th += h;
-                    hs[u] += h;
-#if !(RML_DS_ABL & 4)
-                    accr[u % P].x += v.x; accr[u % P].y += v.y; accr[u % P].z += v.z; accr[u % P].w += v.w;
-                    asm volatile("" : "+v"(accr[u % P].x), "+v"(accr[u % P].y), "+v"(accr[u % P].z), "+v"(accr[u % P].w));  // pin the update here
-#endif
-                });
-#if !(RML_DS_ABL & 1)
-                static_for<UP / 4>([&](auto wc) {
-                    constexpr int w = decltype(wc)::value;
-                    slot[w] = make_float4(hs[4 * w], hs[4 * w + 1], hs[4 * w + 2], hs[4 * w + 3]);
-                });
-#else
-                asm volatile("" : "+v"(hs[0]));
-#endif
-                asm volatile("" : "+v"(th));
-                __builtin_amdgcn_sched_barrier(0);
-                if ((gi + s) < GP) {
-                    ++cg;
-                    if (cg == NG) {                     // plane ci of frame cf is complete
-                        float tot = th;                 // butterfly over the wave: a fixed order, every lane ends with the total
-#pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
-                        if (lane == 0) prof[ci] = tot;
-                        th = 0.0f;
-                        cg = 0; ++ci;
+        for (int gi = 0; gi < GP; ++gi) {
+            advance();                                  // the group that refills the slots
+            const QT* __restrict__ nV = lV;
+            uint32_t nq0 = (uint32_t)(lg * U * 64 + lane);
+            asm volatile("" : "+v"(nq0));               // opaque per step: no hoisted per-instruction offsets kept alive
+            const int q0 = cg * U * 64 + lane;
+            // the running row sums of this group's slots live in the lane's strip row: float4 by float4, read one ahead
+            float4* const slot = myrow + cg * (UP / 4);
+            float4 o = slot[0];
+            static_for<UP / 4>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                float4 on = o;
+                if constexpr (w + 1 < UP / 4) on = slot[w + 1];
+                static_for<4>([&](auto kc) {
+                    constexpr int u = 4 * w + decltype(kc)::value;
+                    if constexpr (u < U) {
+                        float4 v = Cell<VT>::widen(buf[u]);
+                        const bool in = q0 + u * 64 < pq;
+                        v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+                        const float h = (v.x + v.y) + (v.z + v.w);
+                        th += h;
+                        if constexpr (u % 4 == 0) o.x += h; else if constexpr (u % 4 == 1) o.y += h; else if constexpr (u % 4 == 2) o.z += h; else o.w += h;
+                        accr[u % P].x += v.x; accr[u % P].y += v.y; accr[u % P].z += v.z; accr[u % P].w += v.w;
+                        asm volatile("" : "+v"(accr[u % P].x), "+v"(accr[u % P].y), "+v"(accr[u % P].z), "+v"(accr[u % P].w));  // pin the update here
+                        buf[u] = load1(nV, nq0 + (uint32_t)(u * 64));
                     }
-                }
+                });
+                slot[w] = o;
+                o = on;
+                asm volatile("" : "+v"(th));
+                // keep the software pipeline as written: left alone hipcc renames the refills into fresh registers and hoists them
+                __builtin_amdgcn_sched_barrier(0);
             });
+            ++cg;
+            if (cg == NG) {                             // plane ci of frame cf is complete
+                float tot = th;                         // butterfly over the wave: a fixed order, every lane ends with the total
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+                if (lane == 0) prof[ci] = tot;
+                th = 0.0f;
+                cg = 0; ++ci;
+            }
         }
         // ---- the frame is in: profiles, top-n, planes.  The first group of this wave's next frame is in flight meanwhile. ----
         // (the LDS hand-offs below are between lanes of ONE wave: the DS unit runs a wave's instructions in order; the fences
@@ -311,19 +295,29 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
             }
             prof[X + j] = sum;
         }
-        // s_r[k]: the P accumulators cover quads 0 .. 64 P - 1 of the linear plane modulo its period; column c = q mod Z/4
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // s_r[k]: the P accumulators cover quads 0 .. 64 P - 1 of the linear plane modulo its period; column c = q mod Z/4.  Staged
+        // through the strip in two halves (PH accumulators each), folded in ascending quad order
         float4* st4 = reinterpret_cast<float4*>(strip);
-        static_for<P>([&](auto pc) { constexpr int p = decltype(pc)::value; st4[p * 64 + lane] = accr[p]; });
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int c = lane; c < ZQ; c += 64) {
-            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int m = c; m < 64 * P; m += ZQ) {
-                const float4 t = st4[m];
-                sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+        float4 srs = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int csr = lane < ZQ ? lane : ZQ - 1;       // Z/4 <= 64: one column per lane
+        static_for<2>([&](auto hc) {
+            constexpr int hh = decltype(hc)::value;
+            if constexpr (hh * PH < P) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                static_for<P>([&](auto pc) { constexpr int p = decltype(pc)::value; if constexpr (p / PH == hh) st4[(p - hh * PH) * 64 + lane] = accr[p]; });
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int lo = hh * PH * 64, hi = (hh + 1) * PH * 64 < P * 64 ? (hh + 1) * PH * 64 : P * 64;
+                int m = csr + ((lo - csr + ZQ - 1) / ZQ) * ZQ;      // first quad >= lo of column csr (lo >= 0 > csr - ZQ)
+                if (lo <= csr) m = csr;
+                for (; m < hi; m += ZQ) {
+                    const float4 t = st4[m - lo];
+                    srs.x += t.x; srs.y += t.y; srs.z += t.z; srs.w += t.w;
+                }
             }
-            float* dst = prof + X + Y + 4 * c;          // X + Y need not be a multiple of four: no 16-byte store
-            dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z; dst[3] = sum.w;
+        });
+        if (lane < ZQ) {
+            float* dst = prof + X + Y + 4 * lane;       // X + Y need not be a multiple of four: no 16-byte store
+            dst[0] = srs.x; dst[1] = srs.y; dst[2] = srs.z; dst[3] = srs.w;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int q = lane; q < strip_alloc; q += 64) strip[q] = 0.0f;   // the next frame accumulates into a clean strip
@@ -367,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void k_derive_slice(ProjParams a) {
                 const int j = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 1]);
                 const int k = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 2]);
                 em.reset(cf * T + t);
-                slice_emit<VT, 4>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
+                slice_emit<VT, RML_DERIVE_UB>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
                 em.finish_wave(lane);
             }
         }
@@ -384,45 +378,56 @@ bool derive_geom(int X, int Y, int Z, int ntgt, DeriveGeom* g) {
     if (ZQ > 64) return false;
     const int P = odd_part(ZQ);
     if (P > 15) return false;
-    const int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));
+    int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));
+    const char* ue = getenv("RML_DERIVE_U2");           // experiment knob: two periods in flight per wave (P = 1: 16, P = 11: 22)
+    if (ue && atoi(ue) == 1 && (P == 1 || P == 11)) U *= 2;
     const int pq = Y * ZQ;
     const int NI = (pq + 63) / 64, NG = (NI + U - 1) / U;
-    const int UP = (U + 3) & ~3;
+    const int UP = (U + 3) & ~3, PH = (P + 1) / 2;
     int RS = NG * UP + 4;
     if (!((RS / 4) & 1)) RS += 4;                       // as the kernel computes it
     const int strip_n = 64 * RS;
     g->P = P; g->U = U; g->NG = NG;
-    g->strip_alloc = strip_n > P * 256 ? strip_n : P * 256;
+    g->strip_alloc = strip_n > PH * 256 ? strip_n : PH * 256;
     const size_t bytes = (size_t)g->strip_alloc * 4 + (size_t)((X + Y + Z + 3) & ~3) * 4 + (size_t)ntgt * 12;
     g->wave_lds = (bytes + 15) & ~(size_t)15;
     return 4 * g->wave_lds <= 150 * 1024;
 }
 
 template <typename VT, int P, int U>
-void launch_derive_pu(const ProjParams& pp, size_t lds, int num_cu, hipStream_t st) {
-    // persistent grid: as many workgroups per CU as LDS (and at most four: 16 waves stream more than a CU can take) allows
+void launch_derive_pu(const ProjParams& pp, size_t wave_lds, int num_cu, hipStream_t st) {
+    // persistent grid: as many 4-wave workgroups per CU as LDS allows (at most five; the registers decide what is resident).
+    // Beside a GEMM (share_cu, the fused pipeline): ONE workgroup of eight waves per CU, its LDS request padded past half of the
+    // CU's LDS so that the dispatcher cannot put two on one CU and none on another, while a 128x128 GEMM workgroup (69.6 KB, 128
+    // registers) still fits next to it (see launch_wave in project.hip)
+    const bool share = pp.o.share_cu != 0;
+    const int wpb = (share && 8 * wave_lds <= 150 * 1024) ? 8 : 4;
+    size_t lds = (size_t)wpb * wave_lds;
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 512));
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 5 ? 5 : per_cu);
     const char* env = getenv("RML_DERIVE_PERCU");       // experiment knob
     if (env && atoi(env) >= 1 && atoi(env) <= 8) per_cu = atoi(env);
-    if (pp.o.share_cu) per_cu = 1;
-    const int64_t want = (pp.B + 3) / 4;
+    if (share) {
+        per_cu = 1;
+        if (!pp.o.no_pad && lds < 81 * 1024) lds = 81 * 1024;
+    }
+    const int64_t want = (pp.B + wpb - 1) / wpb;
     const int64_t cap = (int64_t)num_cu * per_cu;
-    dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
+    dim3 grid((unsigned)(want < cap ? want : cap)), block((unsigned)(64 * wpb));
     RML_MAX_DYN_LDS(160 * 1024, &k_derive_slice<VT, P, U>);
     hipLaunchKernelGGL((k_derive_slice<VT, P, U>), grid, block, lds, st, pp);
 }
 
 template <typename VT>
 bool launch_derive_t(const ProjParams& pp, const DeriveGeom& g, int num_cu, hipStream_t st) {
-    const size_t lds = 4 * g.wave_lds;
+    const size_t lds = g.wave_lds;                      // per wave; the launcher multiplies by its waves per workgroup
     switch (g.P) {
-        case 1: launch_derive_pu<VT, 1, 8>(pp, lds, num_cu, st); return true;
+        case 1: if (g.U == 16) launch_derive_pu<VT, 1, 16>(pp, lds, num_cu, st); else launch_derive_pu<VT, 1, 8>(pp, lds, num_cu, st); return true;
         case 3: launch_derive_pu<VT, 3, 9>(pp, lds, num_cu, st); return true;
         case 5: launch_derive_pu<VT, 5, 10>(pp, lds, num_cu, st); return true;
         case 7: launch_derive_pu<VT, 7, 7>(pp, lds, num_cu, st); return true;
         case 9: launch_derive_pu<VT, 9, 9>(pp, lds, num_cu, st); return true;
-        case 11: launch_derive_pu<VT, 11, 11>(pp, lds, num_cu, st); return true;
+        case 11: if (g.U == 22) launch_derive_pu<VT, 11, 22>(pp, lds, num_cu, st); else launch_derive_pu<VT, 11, 11>(pp, lds, num_cu, st); return true;
         case 13: launch_derive_pu<VT, 13, 13>(pp, lds, num_cu, st); return true;
         case 15: launch_derive_pu<VT, 15, 15>(pp, lds, num_cu, st); return true;
         default: return false;

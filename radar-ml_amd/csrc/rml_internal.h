@@ -41,6 +41,10 @@ struct rml_ctx {
     size_t prof_used_g = 0;
     double prof_ops_g = 0.0;
     std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
+    // RML_OPT_PROJECT_SHARE_CU: stand-alone projection launches (rml_project*) use the configuration the fused pipeline uses
+    // beside a GEMM -- one persistent workgroup per CU, LDS request padded -- so that another kernel of the caller's (on another
+    // stream) finds room on every CU
+    int opt_project_share_cu = 0;
     // Entry points that use the shared workspace / events / caches take `mu` for the duration of the call and order
     // their stream behind the previous user's work (ev_last), so calls from several host threads or on several
     // streams cannot interleave on the workspace (rml_ctx_guard below).

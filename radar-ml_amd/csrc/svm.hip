@@ -448,162 +448,6 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_svm_gemm_lite<PT>: the exact 128 x 128 tile in 40 KB of LDS -- the GEMM of the fused pipeline's second stream.  Beside a
-// persistent projection workgroup (66-81 KB of LDS per CU) only ONE k_svm_gemm workgroup (70 KB) fits a CU: one wave per SIMD, a
-// barrier per K-step, nothing to overlap a stall with -- and when the GEMM's workgroups happen to reach a CU before the
-// projection's, two of them take the LDS and the projection's workgroup waits (the bimodal results of RML_PIPE_SPLIT).  Here a
-// K-step is 64 B per row (two stages of 2 x 8 KiB) and the accumulators go through LDS in two halves of 32 KiB, so that two of
-// these workgroups and the projection's always fit together.  The image is [128 rows][64 B] with the 16-byte chunk index XORed
-// by (row >> 2) & 3 (rows r, r+4, r+8, r+12 of a 16-lane group share the 64 B bank window: four chunk positions, four rows).
-// Same arithmetic and the same summation order as k_svm_gemm<PATH_I8> (a thread sums its 64 SV rows in order, half 0 + half 1):
-// bit-identical partial sums.
-// ------------------------------------------------------------------------------------------
-constexpr int kLiteStep = 64;                          // K bytes per row and step
-constexpr int kLiteOp = kTile * kLiteStep;             // 8 KiB per operand and stage
-
-template <int PT>
-__global__ __launch_bounds__(256, 2) void k_svm_gemm_lite(GemmArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int XPX = (a.FT + 7) >> 3;
-    const int ftile = (slot % XPX) * 8 + xcd;
-    const int stile = slot / XPX;
-    if (ftile >= a.FT) return;
-    if (a.tile_exact && a.tile_exact[ftile] != a.want) return;
-    const int64_t f0 = (int64_t)ftile * kTile;
-    const int64_t m0 = (int64_t)stile * kTile;
-
-    // LDS: [2 stages][SV 8 KiB | samples 8 KiB] = 32 KiB (later: 64 x 128 accumulators), then the per-SV table and the exp table
-    double* svw = reinterpret_cast<double*>(smem + 4 * kLiteOp);
-    const double* etab = svw + kTile * (1 + PT);
-    exp_tab_init(svw + kTile * (1 + PT), tid);
-    for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
-        int m = idx / (1 + PT), c = idx - m * (1 + PT);
-        svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
-    }
-
-    // staging: 8 wave-instructions of 1 KiB per operand tile and stage, 2 per wave
-    const uint8_t* gsv[2];
-    const uint8_t* gx[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = (wave * 2 + q) * 64 + lane;    // 16-byte slot in the LDS image
-        const int r = s >> 2;
-        const int c = (s & 3) ^ ((r >> 2) & 3);      // inverse swizzle on the source
-        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
-        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
-        gx[q] = a.x + xr * a.ld_x + c * 16;
-    }
-    auto stage = [&](int kt, int buf) {
-        unsigned char* base = smem + buf * 2 * kLiteOp;
-        const int64_t ko = (int64_t)kt * kLiteStep;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            glds16(gsv[q] + ko, base + (wave * 2 + q) * 1024);
-            glds16(gx[q] + ko, base + kLiteOp + (wave * 2 + q) * 1024);
-        }
-    };
-    int aoff[2], asw[2], boff[2], bsw[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ra = wr * 64 + t * 32 + (lane & 31);
-        const int rb = wc * 64 + t * 32 + (lane & 31);
-        aoff[t] = ra * kLiteStep; asw[t] = (ra >> 2) & 3;
-        boff[t] = rb * kLiteStep; bsw[t] = (rb >> 2) & 3;
-    }
-    const int chalf = lane >> 5;
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    const int KT = a.KT * (kStepBytes / kLiteStep);  // a.KT counts 128-byte steps
-    stage(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* sA = smem + (kt & 1) * 2 * kLiteOp;
-        const unsigned char* sB = sA + kLiteOp;
-        v4i af[2][2], bf[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ch = 2 * kk + chalf;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[kk][t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
-                bf[kk][t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
-    }
-
-    // ---- fused float64 epilogue, one SV half (64 rows x 128 samples x 4 B = 32 KiB) at a time; threads 0..127 own a sample
-    // column each and sum its 64 rows in order -- the order, and therefore the bits, of k_svm_gemm's thread (n, h)
-    const bool rbf = (a.kernel == RML_KERNEL_RBF);
-    const int nl = tid & 127;
-    const int64_t n = f0 + nl;
-    const int64_t nc = n < a.N ? n : a.N - 1;
-    const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
-    double S[2][PT];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int p = 0; p < PT; ++p) S[h][p] = 0.0;
-    int* gl = reinterpret_cast<int*>(smem);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();                       // the tile images (h = 0) / the first half (h = 1) are consumed
-        if (wr == h) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;      // row within the half
-                        const int nn = wc * 64 + j * 32 + (lane & 31);
-                        gl[ml * kTile + nn] = acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int* gcol = gl + nl;
-#pragma unroll 2
-            for (int mm = 0; mm < 64; ++mm) {
-                const double* e = svw + (h * 64 + mm) * (1 + PT);
-                const double g = (double)gcol[mm * kTile];
-                double kv;
-                if (rbf) {
-                    double d2 = xt + e[0] - 2.0 * g;
-                    d2 = d2 > 0.0 ? d2 : 0.0;
-                    kv = rml_exp_neg(-a.gs * d2, etab);
-                } else {
-                    kv = (g + xt + e[0]) * a.gs;
-                }
-#pragma unroll
-                for (int p = 0; p < PT; ++p) S[h][p] = fma(e[1 + p], kv, S[h][p]);
-            }
-        }
-    }
-    if (tid < 128 && n < a.N) {
-#pragma unroll
-        for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[0][p] + S[1][p];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // I8 hot path, large batches: 256 SVs x 256 samples per workgroup (512 threads, 8 waves as 2 x 4, wave tile 128 x 64 =
 // 4 x 2 MFMA tiles of 32x32, 128 accumulator registers), K-step 128 B per row, two 64 KiB stages.
 //
@@ -617,185 +461,14 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm_lite(GemmArgs a) {
 // 2*stile+1 carry the two 128-row halves, summed exactly like the 128x128 kernel sums them.
 // ------------------------------------------------------------------------------------------
 constexpr int kBig = 256;
-constexpr int kBigStageBytes = 2 * kBig * kStepBytes;     // 64 KiB: [SV 256 x 128 B][samples 256 x 128 B]
 
-// (Round 3 measured this kernel against three issue schedules, tools/exp/README.md: it stays as the RML_GEMM_RING=0 arm of
-// tools/gemm_ab.py; the default for large batches is k_svm_gemm_ring below.)
-template <int PT>
-__global__ __launch_bounds__(512, 2) void k_svm_gemm_i8_256(GemmArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves; wave tile = 128 SVs x 64 samples
-    // XCD-aware mapping, sample tiles fastest (see k_svm_gemm)
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int FT2 = (a.FT + 1) >> 1;                   // 256-sample tiles (a.FT counts 128-sample tiles)
-    const int XPX = (FT2 + 7) >> 3;
-    const int ftile = (slot % XPX) * 8 + xcd;
-    const int stile = slot / XPX;
-    if (ftile >= FT2) return;
-    if (a.tile_exact && a.tile_exact[2 * ftile] != a.want) return;
-    const int64_t f0 = (int64_t)ftile * kBig;
-    const int64_t m0 = (int64_t)stile * kBig;
-
-    double* svw = reinterpret_cast<double*>(smem + 2 * kBigStageBytes);    // [256][1+PT]; rows past Mpad carry W = 0
-    const double* etab = svw + kBig * (1 + PT);
-    exp_tab_init(svw + kBig * (1 + PT), tid);
-    for (int idx = tid; idx < kBig * (1 + PT); idx += 512) {
-        int m = idx / (1 + PT), c = idx - m * (1 + PT);
-        const bool in = m0 + m < a.Mpad;
-        svw[idx] = !in ? 0.0 : ((c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m]);
-    }
-
-    // staging: each operand image is 2048 16-byte slots = 32 wave-instructions of 1 KiB, 4 per wave
-    const uint8_t* gsv[4];
-    const uint8_t* gx[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int s = (wave * 4 + q) * 64 + lane;
-        int r = s >> 3;
-        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
-        int64_t mr = m0 + r; mr = mr < a.sv_rows ? mr : a.sv_rows - 1;
-        gsv[q] = a.sv + mr * a.ld_sv + c * 16;
-        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
-        gx[q] = a.x + xr * a.ld_x + c * 16;
-    }
-    auto stage = [&](int kt, int buf) {
-        unsigned char* base = smem + buf * kBigStageBytes;
-        const int64_t ko = (int64_t)kt * kStepBytes;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            glds16(gsv[q] + ko, base + (wave * 4 + q) * 1024);
-            glds16(gx[q] + ko, base + kBig * kStepBytes + (wave * 4 + q) * 1024);
-        }
-    };
-
-    int aoff[4], asw[4], boff[2], bsw[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        int ra = wr * 128 + t * 32 + (lane & 31);
-        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int rb = wc * 64 + t * 32 + (lane & 31);
-        boff[t] = kBig * kStepBytes + rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
-    }
-    const int chalf = lane >> 5;
-
-    v16i acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    // Measured on this kernel (16 384 x 2 562 x 20 480, tools/kbench.py gemm): 0.96 ms as written; MFMAs removed 0.82 ms;
-    // staging removed 0.75 ms -- the L2 -> LDS delivery of a stage (~1.7 us per 64 KiB) and the matrix work of a step
-    // (~1.1 us) overlap only partly with ONE stage of look-ahead, and a third 64 KiB stage does not fit the 160 KiB of LDS.
-    // Tried and measured slower: issuing the stage in four slices between the MFMA groups (1.11 ms: it lands later), touching
-    // the lines of stage kt+3 with one dword load per lane to make the later DMA an L2 hit (0.99 ms).
-    stage(0, 0);
-    for (int kt = 0; kt < a.KT; ++kt) {
-        __syncthreads();                               // DMA of step kt landed and visible; other buffer free
-        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* sb = smem + (kt & 1) * kBigStageBytes;
-        // two fragment register sets: reads of sub-step kk+1 are in flight under the MFMAs of kk
-        v4i af[2][4], bf[2][2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[0][t] = *reinterpret_cast<const v4i*>(sb + aoff[t] + ((chalf ^ asw[t]) << 4));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bf[0][t] = *reinterpret_cast<const v4i*>(sb + boff[t] + ((chalf ^ bsw[t]) << 4));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
-                const int ch = 2 * (kk + 1) + chalf;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    af[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(sb + aoff[t] + ((ch ^ asw[t]) << 4));
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    bf[(kk + 1) & 1][t] = *reinterpret_cast<const v4i*>(sb + boff[t] + ((ch ^ bsw[t]) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#if RML_GEMM_ABL == 3
-                    acc[i][j][0] += af[kk & 1][i][0] ^ bf[kk & 1][j][1];
-#else
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-#endif
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- fused float64 epilogue: G[256 SVs][128 samples] int32 through LDS, one 128-sample half at a time ----
-    const bool rbf = (a.kernel == RML_KERNEL_RBF);
-    int* gl = reinterpret_cast<int*>(smem);
-    const int nl = tid & 127, h = tid >> 7;            // sample column of the half, SV quarter (64 rows)
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();                               // tile images / previous exchange consumed
-        if ((wc >> 1) == pass) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                        const int nn = (wc & 1) * 64 + j * 32 + (lane & 31);
-                        gl[ml * kTile + nn] = acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-        const int64_t n = f0 + pass * kTile + nl;
-        const int64_t nc = n < a.N ? n : a.N - 1;
-        const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
-        double S[PT];
-#pragma unroll
-        for (int p = 0; p < PT; ++p) S[p] = 0.0;
-        const int* gcol = gl + nl;
-#pragma unroll 2
-        for (int mm = 0; mm < 64; ++mm) {
-            const int ml = h * 64 + mm;
-            const double* e = svw + ml * (1 + PT);
-            const double g = (double)gcol[ml * kTile];
-            double kv;
-            if (rbf) {
-                double d2 = xt + e[0] - 2.0 * g;
-                d2 = d2 > 0.0 ? d2 : 0.0;
-                kv = rml_exp_neg(-a.gs * d2, etab);
-            } else {
-                kv = (g + xt + e[0]) * a.gs;
-            }
-#pragma unroll
-            for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
-        }
-        __syncthreads();                               // G half consumed: reuse its LDS for the exchange
-        double* x4 = reinterpret_cast<double*>(smem);  // [4][128][PT]
-#pragma unroll
-        for (int p = 0; p < PT; ++p) x4[(h * kTile + nl) * PT + p] = S[p];
-        __syncthreads();
-        if (h == 0 && n < a.N) {
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                // one partial per 128 SV rows, summed like the 128 x 128 kernel sums them (see k_svm_gemm_ring)
-                a.partial[((int64_t)(2 * stile) * a.Npart + n) * PT + p] = x4[(0 * kTile + nl) * PT + p] + x4[(1 * kTile + nl) * PT + p];
-                if (2 * stile + 1 < a.ST)
-                    a.partial[((int64_t)(2 * stile + 1) * a.Npart + n) * PT + p] = x4[(2 * kTile + nl) * PT + p] + x4[(3 * kTile + nl) * PT + p];
-            }
-        }
-    }
-}
+// (The two-stage 64 KiB kernel that first ran this tile -- k_svm_gemm_i8_256, rounds 2-3: 0.46-0.50 of the int8 peak -- lost to the
+// ring schedule below in every same-process A/B and left the tree in round 4; its numbers are in tools/exp/README.md.)
 
 // ------------------------------------------------------------------------------------------
 // k_svm_gemm_ring<PT, DIG>: the 256 x 256 tile with a 5-slot operand-stage ring and interleaved DMA issue (round 3).
 //
-// What limited the two-stage kernel above (A/B in one process, tools/gemm_ab.py, 16 384 x 2 562 x 20 480): all 64 DMA
+// What limited the two-stage kernel that ran this tile in round 2 (A/B in one process, tools/gemm_ab.py, 16 384 x 2 562 x 20 480): all 64 DMA
 // instructions of a stage leave in one burst after the barrier; the burst fills the CU's VMEM queue, every wave sits in its
 // in-order issue stage until its eight instructions are accepted (~100 cycles each) and no MFMA is issued meanwhile:
 // step = burst (~800-1000 cycles) + 2048 MFMA cycles.  Spreading the instructions between the MFMAs hides their issue under
@@ -1210,188 +883,6 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_svm_gemm_ring128<PT>: the ring schedule on the 128 x 128 tile, for the fused pipeline, where ONE GEMM workgroup per CU runs
-// beside a persistent projection workgroup.  There the two-stage 128 x 128 kernel is bound by the latency of a stage under the
-// projection's HBM stream (one workgroup per CU: nothing else covers it); the ring gives every stage 1 to 1.5 steps to land.
-// 4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 MFMA tiles; operand stage = 128 rows x 128 B = 16 KiB, 5 slots = 80 KiB (the
-// projection workgroup beside it keeps its own 34-66 KiB; it is kept from doubling up on a CU by registers, not by an LDS pad:
-// see ProjOut::share_cu).  Per step a wave issues 16 MFMAs and 8 DMA instructions (one after every two MFMAs), same rotation by
-// one MFMA group as k_svm_gemm_ring.  Epilogue and partial sums exactly as k_svm_gemm<I8> (bit-identical outputs).
-// ------------------------------------------------------------------------------------------
-constexpr int kOp128Bytes = kTile * kStepBytes;           // 16 KiB
-
-template <int PT>
-__global__ __launch_bounds__(256, 2) void k_svm_gemm_ring128(RingArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    int ftile, stile;
-    if (!ring_tile(blockIdx.x, a.FT, a.ST, ftile, stile)) return;
-    if (a.tile_exact && a.tile_exact[ftile] != a.want) return;
-    const int64_t f0 = (int64_t)ftile * kTile;
-    const int64_t m0 = (int64_t)stile * kTile;
-
-    const uint8_t* gsv[4];
-    const uint8_t* gx[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int s = (wave * 4 + q) * 64 + lane;          // 16-byte slot in the 16 KiB image
-        int r = s >> 3;
-        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
-        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
-        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
-        gx[q] = a.x + xr * a.ld_x + c * 16;
-    }
-    int aoff[2], asw[2], boff[2], bsw[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int ra = wr * 64 + t * 32 + (lane & 31);
-        int rb = wc * 64 + t * 32 + (lane & 31);
-        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
-        boff[t] = rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
-    }
-    const int chalf = lane >> 5;
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    const int TT = a.KT;
-    int64_t ox = 0, os = 0;                            // K offsets of the next sample stage / SV stage to send
-    auto burst = [&](const uint8_t* const (&g)[4], int64_t off, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(g[q] + off, smem + slot * kOp128Bytes + wave * 4096 + q * 1024);
-    };
-    burst(gsv, 0, 0); burst(gx, 0, 1);                 // SV_0, X_0
-    os = kStepBytes; ox = kStepBytes;
-    if (TT > 1) { burst(gsv, os, 2); os += kStepBytes; }
-    int sa = 0, sx = 3, ss = 4, t = 0;
-    v4i af[2][2], bf[2][2];
-    auto mfma_half = [&](int set, int half) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            acc[half][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set][half], bf[set][j], acc[half][j], 0, 0, 0);
-    };
-    auto step = [&](auto first_) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_)::value;
-        const bool hx = t + 1 < TT, hs = t + 2 < TT;
-        if (hx) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int sbx = sa + 1 == kRingSlots ? 0 : sa + 1;
-        const unsigned char* pa = smem + sa * kOp128Bytes;
-        const unsigned char* pb = smem + sbx * kOp128Bytes;
-        sa = sa + 2 >= kRingSlots ? sa + 2 - kRingSlots : sa + 2;
-        unsigned char* dx = smem + sx * kOp128Bytes + wave * 4096;
-        unsigned char* dsv = smem + ss * kOp128Bytes + wave * 4096;
-        sx = sx + 2 >= kRingSlots ? sx + 2 - kRingSlots : sx + 2;
-        ss = ss + 2 >= kRingSlots ? ss + 2 - kRingSlots : ss + 2;
-        const int64_t offx = ox, offs = os;
-        auto reads = [&](int set, int kk) __attribute__((always_inline)) {
-            const int ch = 2 * kk + chalf;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                af[set][u] = *reinterpret_cast<const v4i*>(pa + aoff[u] + ((ch ^ asw[u]) << 4));
-                bf[set][u] = *reinterpret_cast<const v4i*>(pb + boff[u] + ((ch ^ bsw[u]) << 4));
-            }
-        };
-        auto dma = [&](int g) __attribute__((always_inline)) {
-            if (g < 4) { if (hx) glds16(gx[g] + offx, dx + g * 1024); }
-            else       { if (hs) glds16(gsv[g - 4] + offs, dsv + (g - 4) * 1024); }
-        };
-        reads(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int set = (r + 1) & 1;                // r = 0: the deferred kk = 3 of the previous step (set 1)
-            if (r >= 1) {
-                reads(r & 1, r);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (!(FIRST && r == 0)) mfma_half(set, half);
-                __builtin_amdgcn_sched_barrier(0);
-                dma(2 * r + half);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (hx) ox += kStepBytes;
-        if (hs) os += kStepBytes;
-        ++t;
-    };
-    step(std::true_type{});
-    for (int n = TT - 1; n > 0; --n) step(std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(1, 0); mfma_half(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- epilogue of k_svm_gemm<I8>: G[128][128] int32 through slots 0-3, the per-SV table in slot 4 ----
-    const bool rbf = (a.kernel == RML_KERNEL_RBF);
-    double* svw = reinterpret_cast<double*>(smem + 4 * kOp128Bytes);
-    const double* etab = svw + kTile * (1 + PT);
-    __syncthreads();
-    exp_tab_init(svw + kTile * (1 + PT), tid);
-    for (int idx = tid; idx < kTile * (1 + PT); idx += 256) {
-        int m = idx / (1 + PT), c = idx - m * (1 + PT);
-        svw[idx] = (c == 0) ? a.sv_term[m0 + m] : a.W[(int64_t)(c - 1) * a.Mpad + m0 + m];
-    }
-    {
-        int* gl = reinterpret_cast<int*>(smem);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                    const int nn = wc * 64 + j * 32 + (lane & 31);
-                    gl[ml * kTile + nn] = acc[i][j][r];
-                }
-    }
-    __syncthreads();
-    const int nl = tid & 127, h = tid >> 7;
-    const int64_t n = f0 + nl;
-    const int64_t nc = n < a.N ? n : a.N - 1;
-    const double xt = rbf ? (double)(a.x_isq[nc] - 256 * (int64_t)a.x_isum[nc]) : 128.0 * (double)a.x_isum[nc];
-    double S[PT];
-#pragma unroll
-    for (int p = 0; p < PT; ++p) S[p] = 0.0;
-    const int* gcol = reinterpret_cast<const int*>(smem) + nl;
-#pragma unroll 2
-    for (int mm = 0; mm < 64; ++mm) {
-        const int ml = h * 64 + mm;
-        const double* e = svw + ml * (1 + PT);
-        const double g = (double)gcol[ml * kTile];
-        double kv;
-        if (rbf) {
-            double d2 = xt + e[0] - 2.0 * g;
-            d2 = d2 > 0.0 ? d2 : 0.0;
-            kv = rml_exp_neg(-a.gs * d2, etab);
-        } else {
-            kv = (g + xt + e[0]) * a.gs;
-        }
-#pragma unroll
-        for (int p = 0; p < PT; ++p) S[p] = fma(e[1 + p], kv, S[p]);
-    }
-    __syncthreads();
-    double* xch = reinterpret_cast<double*>(smem);
-    if (h == 1) {
-#pragma unroll
-        for (int p = 0; p < PT; ++p) xch[nl * PT + p] = S[p];
-    }
-    __syncthreads();
-    if (h == 0 && n < a.N) {
-#pragma unroll
-        for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[p] + xch[nl * PT + p];
-    }
-}
-
 // digit planes of float32 rows: one workgroup per row, a thread takes 4 consecutive features per step.
 // ok[row] = every feature is finite and inside the model's fixed-point range.
 __global__ __launch_bounds__(256) void k_digit_rows(const float* f32, int64_t ld, int64_t D, int64_t Dq, int64_t plane, int8_t* dig,
@@ -1756,21 +1247,6 @@ int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     return RML_OK;
 }
 
-// the 40 KB version of the exact 128 x 128 kernel (k_svm_gemm_lite): beside a persistent projection in the fused pipeline
-int launch_gemm_lite(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
-    const size_t lds = 4 * kLiteOp + (size_t)kTile * (1 + m->PT) * sizeof(double) + kExpTabBytes;
-    const int FT8 = (int)round_up(ga.FT, 8);
-    dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
-    switch (m->PT) {
-        case 1: hipLaunchKernelGGL((k_svm_gemm_lite<1>), grid, block, lds, st, ga); break;
-        case 3: hipLaunchKernelGGL((k_svm_gemm_lite<3>), grid, block, lds, st, ga); break;
-        case 6: hipLaunchKernelGGL((k_svm_gemm_lite<6>), grid, block, lds, st, ga); break;
-        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the lite kernel");
-    }
-    RML_HIP(hipGetLastError());
-    return RML_OK;
-}
-
 template <int DIG>
 int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
     const int FT2 = (ra.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
@@ -1792,61 +1268,13 @@ int launch_gemm_ring(const rml_svm* m, const RingArgs& ra, hipStream_t st) {
     return RML_OK;
 }
 
-// the 128 x 128 tile with the ring schedule (k_svm_gemm_ring128): what the fused pipeline runs beside the projection
-int launch_gemm_ring128(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
+int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
     RingArgs ra{};
     ra.sv = ga.sv; ra.x = ga.x; ra.ld_sv = ga.ld_sv; ra.ld_x = ga.ld_x; ra.KT = ga.KT;
     ra.N = ga.N; ra.Mpad = ga.Mpad; ra.sv_rows = ga.sv_rows; ra.ST = ga.ST; ra.FT = ga.FT;
     ra.tile_exact = ga.tile_exact; ra.want = ga.want; ra.x_isum = ga.x_isum; ra.x_isq = ga.x_isq;
     ra.sv_term = ga.sv_term; ra.W = ga.W; ra.gs = ga.gs; ra.kernel = ga.kernel; ra.partial = ga.partial; ra.Npart = ga.Npart;
-    dim3 grid(ring_grid(ga.FT, ga.ST)), block(256);
-    const size_t lds = (size_t)kRingSlots * kOp128Bytes;
-#define RML_R128_CASE(PTV)                                                                                         \
-    case PTV: {                                                                                                    \
-        RML_MAX_DYN_LDS(160 * 1024, &k_svm_gemm_ring128<PTV>);                                                     \
-        hipLaunchKernelGGL((k_svm_gemm_ring128<PTV>), grid, block, lds, st, ra);                                   \
-    } break;
-    switch (m->PT) {
-        RML_R128_CASE(1)
-        RML_R128_CASE(3)
-        RML_R128_CASE(6)
-        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 128x128 ring kernel");
-    }
-#undef RML_R128_CASE
-    RML_HIP(hipGetLastError());
-    return RML_OK;
-}
-
-int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
-    // RML_GEMM_RING (read per call: tests and A/B runs flip it): unset / 1 = k_svm_gemm_ring (5-slot operand-stage ring,
-    // interleaved DMA issue), 0 = the two-stage kernel of round 2
-    const char* re = getenv("RML_GEMM_RING");
-    const int ring = re ? atoi(re) : 1;
-    if (ring != 0) {
-        RingArgs ra{};
-        ra.sv = ga.sv; ra.x = ga.x; ra.ld_sv = ga.ld_sv; ra.ld_x = ga.ld_x; ra.KT = ga.KT;
-        ra.N = ga.N; ra.Mpad = ga.Mpad; ra.sv_rows = ga.sv_rows; ra.ST = ga.ST; ra.FT = ga.FT;
-        ra.tile_exact = ga.tile_exact; ra.want = ga.want; ra.x_isum = ga.x_isum; ra.x_isq = ga.x_isq;
-        ra.sv_term = ga.sv_term; ra.W = ga.W; ra.gs = ga.gs; ra.kernel = ga.kernel; ra.partial = ga.partial; ra.Npart = ga.Npart;
-        return launch_gemm_ring<0>(m, ra, st);
-    }
-    const size_t lds = 2 * (size_t)kBigStageBytes + (size_t)kBig * (1 + m->PT) * sizeof(double) + kExpTabBytes;
-    const int FT2 = (ga.FT + 1) / 2, ST2 = (int)((m->Mpad + kBig - 1) / kBig);
-    dim3 grid((unsigned)(round_up(FT2, 8) * ST2)), block(512);
-#define RML_BIG_CASE(PTV)                                                                                          \
-    case PTV: {                                                                                                    \
-        RML_MAX_DYN_LDS(160 * 1024, &k_svm_gemm_i8_256<PTV>);                                                      \
-        hipLaunchKernelGGL((k_svm_gemm_i8_256<PTV>), grid, block, lds, st, ga);                                    \
-    } break;
-    switch (m->PT) {
-        RML_BIG_CASE(1)
-        RML_BIG_CASE(3)
-        RML_BIG_CASE(6)
-        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count for the 256x256 kernel");
-    }
-#undef RML_BIG_CASE
-    RML_HIP(hipGetLastError());
-    return RML_OK;
+    return launch_gemm_ring<0>(m, ra, st);
 }
 
 // Rows per chunk of the chunked front doors.  Where the 256x256 ring kernel runs (an exact model, or the multi-digit path) a
@@ -1951,7 +1379,7 @@ int run_finish(const rml_svm* m, int64_t n, const int32_t* flags, const ChunkWs&
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
               const int32_t* flags, const float* f32, const double* nsq, const ChunkWs& w, const DecisionOut& out, hipStream_t st,
               bool tiles_done = false, double* kmat = nullptr, int64_t ld_k = 0, bool all_exact_known = false, bool allow_big = true,
-              bool dig_ready = false, bool defer_finish = false, bool lite_gemm = false) {
+              bool dig_ready = false, bool defer_finish = false) {
     const int FT = (int)((n + kTile - 1) / kTile);
     const int ST = (int)(m->Mpad / kTile);
     // policy: RML_PATH_AUTO (i8 on exact tiles, f64 elsewhere) / _F32 / _I8 / _F64 (forced)
@@ -1982,14 +1410,7 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
-        // RML_GEMM_RING128 (read per call): 1 = the small tile with the ring schedule
-        const char* r128 = getenv("RML_GEMM_RING128");
-        const bool ring128 = !kmat && !big && m->PT <= 6 && r128 && atoi(r128) == 1;
-        const char* lt2 = getenv("RML_GEMM_LITE");                     // 2: every small exact GEMM (tests, tools/gemm_ab.py)
-        const bool lite = !kmat && !big && !ring128 && (lite_gemm || (lt2 && atoi(lt2) == 2)) && m->PT <= 6;
-        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st)
-                      : (big ? launch_gemm_big(m, ga, st)
-                             : (ring128 ? launch_gemm_ring128(m, ga, st) : (lite ? launch_gemm_lite(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st))));
+        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st));
         if (rc) return rc;
     }
     if (run_dig) {
@@ -2317,7 +1738,11 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
-    const bool wave_proj = rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
+    // derive -> slice: the persistent k_derive_slice takes the same pairing (one 8-wave workgroup per CU beside 128x128 GEMM
+    // workgroups, 8 192-frame chunks); RML_DERIVE_PIPE=0: the ring GEMM in whole-round chunks, the two kernels taking turns
+    static const bool derive_pair = [] { const char* e = getenv("RML_DERIVE_PIPE"); return !e || atoi(e) != 0; }();
+    const bool wave_proj = derive ? derive_pair
+                                  : rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
     // Byte volumes (k_project_u8_max): the GEMM is a third of the step there, and since the projection's cross-lane steps left the
     // LDS pipe (round 3: 0.59 -> 0.71 of 8 TB/s alone) each kernel is worth more alone than beside the other: the 256x256 ring
     // kernel in whole-round chunks, the projection between its rounds (64x64x128 uint8, same box: 6.5-6.9 -> 7.4-7.5 M frames/s;
@@ -2370,10 +1795,6 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // one, -1.6 / +4.8 % on another, +0.7 % over five interleaved rounds on a third (bimodal: 10.8 or 10.2 M frames/s, depending
     // on which kernel's workgroups reach the CUs first); 64x64x128 -5 % (2.79 vs 2.93 M).  Not a default.
     static const bool split_env = [] { const char* e = getenv("RML_PIPE_SPLIT"); return e && atoi(e) == 1; }();
-    // RML_GEMM_LITE=1 (read per call): the 40 KB version of the exact 128 x 128 kernel beside the projection (two of its workgroups
-    // and the projection's fit a CU together)
-    const char* lte = getenv("RML_GEMM_LITE");
-    const bool lite = small_gemm && grid_ok && lte && atoi(lte) == 1;
     const bool split = split_env && grid_ok && vdtype != RML_VOL_U8 && !part && ctx->side_stream != nullptr;
     hipStream_t side = split ? ctx->side_stream : aux;
     hipEvent_t* ev_flags = ctx->ev_flags;
@@ -2411,11 +1832,8 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
-        // share mode 2: one projection workgroup per CU by registers (its BALLAST variant) instead of an LDS pad -- what the
-        // 128 x 128 ring GEMM (80 KiB of LDS) needs to fit beside it.  Only the linear-plane kernel has that variant so far.
-        const char* r128 = getenv("RML_GEMM_RING128");
-        const bool share_regs = !part && r128 && atoi(r128) == 1 && vdtype == RML_VOL_F32 && Z == 176 && Y > 16 && Y <= 32;
-        o.share_cu = part ? 0 : (share_regs ? 2 : 1);
+        o.share_cu = part ? 0 : 1;
+        if (derive && !small_gemm) o.share_cu = 0;       // taking turns with the ring GEMM: the stand-alone configuration
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // fused derive -> slice: the first pass derives (i,j,k) per frame and slices there in one launch; a second pass (float rows
@@ -2508,7 +1926,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig,
-                       /*defer_finish=*/split, /*lite_gemm=*/lite);
+                       /*defer_finish=*/split);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;

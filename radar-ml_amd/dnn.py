@@ -201,24 +201,100 @@ class Classifier(_module_base()):
             lg = self.fc3(h)
         return torch.softmax(lg.float(), dim=-1)
 
-    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192):
+    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=True, trunk_events=None):
         """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
         projections (csrc/project.hip) -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused
         conv trunk (csrc/dnn.hip) -> dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor.
-        One stream: alternating batches between two streams was measured slower (PyTorch's caching allocator cannot
-        reuse blocks across streams without synchronising) and hipBLASLt hung when driven from two streams."""
+
+        Two streams (``overlap``): the projection of batch b+2 (HBM-bound) runs on a second stream beside the dense tail of batch
+        b and the resize of batch b+1 (float64 VALU work) -- the projection in its one-workgroup-per-CU configuration
+        (RML_OPT_PROJECT_SHARE_CU), so that the resize workgroups find room on every CU -- and the trunk, which needs a whole
+        CU's LDS, runs alone between two projection launches (the projection waits for it, it waits for the projection).  The
+        projection rows ping-pong between two buffers allocated once per call (round 2 alternated whole batches between two
+        streams through PyTorch's caching allocator, which cannot reuse a block across streams without synchronising: slower;
+        hipBLASLt is driven from the caller's stream only).  ``trunk_events``: a list that receives one
+        (start, stop) torch.cuda.Event pair per trunk launch (bench.py's in-situ roofline of k_dnn_trunk_rf)."""
         import torch
-        from . import common, nn_common
-        outs = []
+        from . import common, nn_common, _lib
+        if not isinstance(volumes, torch.Tensor):
+            volumes = torch.as_tensor(volumes)
+        n = int(volumes.shape[0])
         X, Y, Z = (int(v) for v in volumes.shape[1:])
-        with torch.no_grad():
-            for s0 in range(0, volumes.shape[0], batch_size):
-                feat = common.process_volumes(volumes[s0:s0 + batch_size], mode=mode, scale=False)
-                xz, yz, xy = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
-                outs.append(self.forward_fused(xz, yz, xy))
-        if outs:
-            return torch.cat(outs)
-        return torch.zeros((0, self.n_classes), device=volumes.device if isinstance(volumes, torch.Tensor) else "cuda")
+        if n == 0:
+            return torch.zeros((0, self.n_classes), device=volumes.device if volumes.is_cuda else "cuda")
+        if not volumes.is_cuda:
+            volumes = volumes.to(next(self.parameters()).device)
+        dev = volumes.device
+        bs = int(min(batch_size, n))
+        nb = (n + bs - 1) // bs
+        D = common.feature_len(X, Y, Z)
+        overlap = bool(overlap) and nb > 1
+        out = torch.empty((n, self.n_classes), dtype=torch.float32, device=dev)
+        with torch.no_grad(), torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            if not overlap:
+                for b in range(nb):
+                    s0, s1 = b * bs, min(n, (b + 1) * bs)
+                    feat = common.process_volumes(volumes[s0:s1], mode=mode, scale=False)
+                    xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
+                    out[s0:s1] = self._forward_timed(xs, trunk_events)
+                return out
+            lib = _lib.load()
+            ctx = _lib.context(dev)
+            sp = getattr(self, "_proj_stream", None)
+            if sp is None or sp.device != dev:
+                sp = self._proj_stream = torch.cuda.Stream(device=dev)
+            feats = [torch.empty((bs, D), dtype=torch.float32, device=dev) for _ in range(2)]
+            ev_proj = [torch.cuda.Event(), torch.cuda.Event()]
+            ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+            sp.wait_stream(cur)                         # the volumes (and the fresh buffers) are the caller's stream's
+            _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 1), "rml_ctx_set_option")
+            ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]
+            try:
+                def project(b):
+                    k = b & 1
+                    s0, s1 = b * bs, min(n, (b + 1) * bs)
+                    with torch.cuda.stream(sp):
+                        if b >= 2:
+                            # not before the trunk of batch b-2 is done: the trunk needs a whole CU's LDS, and a projection launch
+                            # that reaches the CUs first keeps it waiting (two persistent kernels taking turns CU by CU: measured
+                            # slower than one stream).  That trunk is also behind the resizes that read this buffer.
+                            sp.wait_event(ev_trunk[k])
+                        common.process_volumes(volumes[s0:s1], mode=mode, scale=False, out=feats[k][:s1 - s0])
+                        ev_proj[k].record(sp)
+                project(0)
+                if nb > 1:
+                    project(1)
+                for b in range(nb):
+                    k = b & 1
+                    s0, s1 = b * bs, min(n, (b + 1) * bs)
+                    cur.wait_event(ev_proj[k])
+                    xs = nn_common.preprocess_features(feats[k][:s1 - s0], (X, Y, Z), rescale, out_dtype="bfloat16")
+                    if b + 1 < nb:
+                        cur.wait_event(ev_proj[(b + 1) & 1])    # the trunk could not start beside the running projection anyway
+                    fv = self._features_timed(xs, trunk_events)
+                    ev_trunk[k].record(cur)
+                    if b + 2 < nb:
+                        project(b + 2)                  # runs beside this batch's dense tail and the next batch's resize
+                    out[s0:s1] = self.dense_tail(fv)
+            finally:
+                _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0), "rml_ctx_set_option")
+            cur.wait_stream(sp)
+        return out
+
+    def _features_timed(self, xs, trunk_events):
+        import torch
+        if trunk_events is None:
+            return self.features_fused(*xs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fv = self.features_fused(*xs)
+        e1.record()
+        trunk_events.append((e0, e1, int(fv.shape[0])))
+        return fv
+
+    def _forward_timed(self, xs, trunk_events):
+        return self.dense_tail(self._features_timed(xs, trunk_events))
 
     def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""

@@ -167,7 +167,8 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     Classifier.predict_volumes (projection -> [-1,1] scaling + bicubic resize -> fused bf16 trunk -> dense tail) -- by
     properties that need no oracle of that size:
       * batching independence: the whole batch in one call against the same frames in three ragged calls (other internal batch
-        boundaries, other last-batch sizes): probabilities BIT-identical;
+        boundaries, other last-batch sizes): probabilities equal to bf16 round-off (2e-3; hipBLASLt picks its kernel by the
+        batch's row count), labels equal outside the 1e-2 margin; the same batches again, on one stream or two: BIT-identical;
       * ingest independence: the same frames as uint8 volumes give bit-identical probabilities (the projections are the same
         float32 values either way);
       * the float64 NumPy restatement of the chain on 96 frames drawn from the whole range, trained weights with real margins:
@@ -182,14 +183,24 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     V, _ = rml.synth_volumes(frames, X, Y, Z, seed=31)
     whole = gpu.predict_volumes(V)
     assert whole.shape == (frames, 3)
+
+    def same(a, b, what):
+        # the dense tail runs on hipBLASLt, which picks its kernel (and with it the order of the K = 38 400 sum) by the batch's row
+        # count: a batch of another size gives the same probabilities to bf16 round-off, not the same bits
+        a, b = a.float(), b.float()
+        assert float((a - b).abs().max()) <= 2e-3, (what, float((a - b).abs().max()))
+        srt = torch.sort(b, dim=1).values
+        conf = (srt[:, -1] - srt[:, -2]) > 1e-2
+        assert torch.equal(a.argmax(1)[conf], b.argmax(1)[conf]), what
+
     cuts = [0, frames // 3 + 777, frames // 3 + 777 + 9999, frames]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
-        part = gpu.predict_volumes(V[lo:hi])
-        assert torch.equal(part, whole[lo:hi]), (lo, hi)
-    part = gpu.predict_volumes(V[:5000], batch_size=1024)                  # another internal batch size
-    assert torch.equal(part, whole[:5000])
+        same(gpu.predict_volumes(V[lo:hi]), whole[lo:hi], (lo, hi))
+    same(gpu.predict_volumes(V[:5000], batch_size=1024), whole[:5000], "batch 1024")       # another internal batch size
+    assert torch.equal(gpu.predict_volumes(V[:16384]), whole[:16384])                       # the same batches: the same bits
+    assert torch.equal(gpu.predict_volumes(V[:16384], overlap=False), whole[:16384])        # one stream or two: the same bits
     v8 = gpu.predict_volumes(V.to(torch.uint8))
-    assert torch.equal(v8, whole)
+    assert torch.equal(v8, whole)                                                           # uint8 ingest: the same projections
     rng = np.random.default_rng(3)
     pick = np.unique(np.concatenate([np.arange(32), rng.integers(0, frames, 32), np.arange(frames - 32, frames)]))
     vh = V[torch.as_tensor(pick, device=V.device)].cpu().numpy()

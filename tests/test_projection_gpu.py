@@ -86,7 +86,11 @@ def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
         np.testing.assert_array_equal(g, w)
 
 
-@pytest.mark.parametrize("shape", [(22, 31, 176), (4, 20, 176), (3, 32, 176), (5, 17, 176), (1, 31, 176)])
+@pytest.mark.parametrize("shape", [(22, 31, 176), (4, 20, 176), (3, 32, 176), (5, 17, 176), (1, 31, 176),
+                                   # rows of 40 / 48 / 56 quads in groups of 8 rows (round 4): two groups (9..16 rows), four groups with
+                                   # the plane ending in the last (25..32 rows) or in the second to last group (17..24 rows)
+                                   (22, 31, 160), (22, 31, 192), (16, 24, 224), (5, 12, 160), (3, 16, 192), (4, 9, 224), (2, 20, 160),
+                                   (3, 17, 192), (2, 25, 224), (3, 32, 160)])
 @pytest.mark.parametrize("share", ["0", "1"])
 def test_linear_plane_kernel_many_frames(rml, shape, share, monkeypatch):
     """k_project_lin (csrc/project_lin.hip): rows of 44 quads loaded as the contiguous array of quads a plane is (the Walabot
@@ -100,14 +104,14 @@ def test_linear_plane_kernel_many_frames(rml, shape, share, monkeypatch):
     else:
         monkeypatch.delenv("RML_WAVE_SHARE", raising=False)
     X, Y, Z = shape
-    B = 2600
+    B = 2600 if X * Y * Z < 60000 else 1300
     rng = np.random.default_rng(X * 1000 + Y)
     v = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
     v[rng.random((B, X, Y, Z)) < 0.7] = 0
     got = rml.project(v, mode="max")
     for g, w in zip(got, O.project_max(v)):
         np.testing.assert_array_equal(g, w)
-    got = rml.project(v, mode="sum")
+    got = rml.project(v, mode="sum")                   # (rows of 40 / 48 / 56 quads: the wave kernel; the linear one is MAX only there)
     for g, w in zip(got, O.project_sum(v)):
         np.testing.assert_array_equal(g, w)
     feat, q, isum, isq, flags = rml.process_volumes(v, mode="max", scale=True, codes=True)

@@ -514,10 +514,11 @@ def test_pairwise_proba_is_asynchronous_and_needs_platt_coefficients(rml):
 
 @pytest.mark.parametrize("name", ["svm_small.npz", "svm_walabot.npz", "svm_small_linear.npz", "svm_small_binary.npz"])
 def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
-    """k_svm_gemm_i8_256 (256 SVs x 256 samples per workgroup, L2 touch-prefetch) is what large batches run on; forced
+    """k_svm_gemm_ring (256 SVs x 256 samples per workgroup, 5-slot operand-stage ring) is what large batches run on; forced
     here (RML_GEMM_BIG=1) on ragged batches: a row count that is no multiple of 256, an SV count that is no multiple of
     256, and -- through the float rows -- sample tiles that are NOT on the code grid, which must fall to the float64
-    kernel pair-wise (tile flags are decided per 256 samples then)."""
+    kernel pair-wise (tile flags are decided per 256 samples then).  Against the oracle, and BIT-identical to the 128 x 128
+    kernel (RML_GEMM_BIG=0): the same int32 dot products, one float64 partial per 128 SV rows summed in the same order."""
     g = load_golden(name)
     svc, m = _model(rml, g)
     X0 = _test_rows(g, name)
@@ -527,38 +528,16 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     C = len(m["classes"])
     want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
     outs = {}
-    for big in ("0", "1", "ring"):
-        # "ring": the 256 x 256 tile with the 5-slot operand-stage ring, counted vmcnt and interleaved DMA issue
-        # (k_svm_gemm_ring, the default); "1": the two-stage 256 x 256 kernel; "0": the 128 x 128 kernel
-        monkeypatch.setenv("RML_GEMM_BIG", "1" if big == "ring" else big)
-        monkeypatch.setenv("RML_GEMM_RING", "1" if big == "ring" else "0")
+    for big in ("0", "1"):
+        monkeypatch.setenv("RML_GEMM_BIG", big)
         svc.decision_function_shape = "ovo"
         got = svc.decision_function(X)
         got = got.reshape(len(X), -1)
         ref = want if C > 2 else -want
         assert np.abs(got - ref).max() <= _tol(m, ref), big
         outs[big] = (got, svc.predict(X), rml.GpuCalibratedClassifier(svc).predict_proba(X))
-    monkeypatch.delenv("RML_GEMM_RING")
-    # the 128 x 128 tile with the ring schedule (what the pipeline can run beside the projection): the same bits again
-    monkeypatch.setenv("RML_GEMM_BIG", "0")
-    monkeypatch.setenv("RML_GEMM_RING128", "1")
-    svc.decision_function_shape = "ovo"
-    got128 = svc.decision_function(X).reshape(len(X), -1)
-    np.testing.assert_array_equal(got128, outs["0"][0])
-    np.testing.assert_array_equal(rml.GpuCalibratedClassifier(svc).predict_proba(X), outs["0"][2])
-    monkeypatch.delenv("RML_GEMM_RING128")
-    # k_svm_gemm_lite (64-byte K-steps, the accumulators through LDS in two halves: 40 KB instead of 70): the same bits once more
-    monkeypatch.setenv("RML_GEMM_LITE", "2")
-    svc.decision_function_shape = "ovo"
-    got_lite = svc.decision_function(X).reshape(len(X), -1)
-    np.testing.assert_array_equal(got_lite, outs["0"][0])
-    np.testing.assert_array_equal(rml.GpuCalibratedClassifier(svc).predict_proba(X), outs["0"][2])
-    monkeypatch.delenv("RML_GEMM_LITE")
     np.testing.assert_array_equal(outs["0"][1], outs["1"][1])
-    # both 256 x 256 kernels produce the same int32 dot products and sum the same tiles in the same order: identical bits
-    np.testing.assert_array_equal(outs["1"][0], outs["ring"][0])
-    np.testing.assert_array_equal(outs["1"][2], outs["ring"][2])
-    # exact tiles give the same integers on every kernel, and the 256 x 256 kernels write one partial per 128 SV rows summed
+    # exact tiles give the same integers on both kernels, and the 256 x 256 kernel writes one partial per 128 SV rows summed
     # like the 128 x 128 kernel's: the decision values do not depend on the tile size (batch size, chunking, ingest dtype)
     np.testing.assert_array_equal(outs["0"][0], outs["1"][0])
     np.testing.assert_array_equal(outs["0"][2], outs["1"][2])

@@ -68,8 +68,7 @@ def main():
             qq[:, D:] = 0
             os.environ["RML_CHUNK"] = str((B + 127) // 128 * 128)
             fn = lambda: svc.decide_codes(qq, isum[:B], isq[:B], flags[:B], want_proba=True)
-            arms = {"ring": {"RML_GEMM_BIG": "1", "RML_GEMM_RING": "1"}, "big2stage": {"RML_GEMM_BIG": "1", "RML_GEMM_RING": "0"},
-                    "tile128": {"RML_GEMM_BIG": "0", "RML_GEMM_RING": "1"}}
+            arms = {"ring": {"RML_GEMM_BIG": "1"}, "tile128": {"RML_GEMM_BIG": "0"}}       # (the two-stage 256 x 256 arm left the tree in round 4)
             res = {k: [] for k in arms}
             outs = {}
             for r in range(a.rounds):
@@ -86,8 +85,7 @@ def main():
                 m = float(np.median(res[name]))
                 row[name] = {"ms": round(m, 4), "ms_min": round(float(np.min(res[name])), 4), "POPs": round(ops / m / 1e12, 3),
                              "frac_of_3944": round(ops / m / 1e9 / 3944, 4)}
-            row["ring_equals_2stage_bits"] = bool(np.array_equal(outs["big2stage"], outs["ring"]))
-            row["max_abs_diff_128_vs_256"] = float(np.abs(outs["big2stage"] - outs["tile128"]).max())
+            row["max_abs_diff_128_vs_256"] = float(np.abs(outs["ring"] - outs["tile128"]).max())
             print(json.dumps(row), flush=True)
             del qq
     else:

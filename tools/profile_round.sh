@@ -41,23 +41,21 @@ done
 cd $R
 python tools/prof_summary.py pmc gpurun_out/prof_FETCH_SIZE/k_results.db gpurun_out/prof_WRITE_SIZE/k_results.db > gpurun_out/${TAG}_pmc.txt
 cp profiles/pmc_latest.json gpurun_out/pmc_latest.json 2>/dev/null
-# matrix-core / issue counters of the exact GEMMs alone (ring 256x256, two-stage 256x256, 128x128) and their FETCH
+# matrix-core / issue counters of the exact GEMMs alone (ring 256x256, 128x128) and their FETCH
 cd /tmp
 GEMM="python $R/tools/kbench.py gemm --grid 64x64x128 --frames 23808 --svs 2562 --iters 6"
 CNT="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 RML_CHUNK=23808 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/prof_mfma -o k -- $GEMM > /dev/null 2> $R/gpurun_out/prof_mfma.err
-RML_CHUNK=23808 RML_GEMM_RING=0 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/prof_mfma_2stage -o k -- $GEMM > /dev/null 2>> $R/gpurun_out/prof_mfma.err
 RML_CHUNK=23808 RML_GEMM_BIG=0 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/prof_mfma_small -o k -- $GEMM > /dev/null 2>> $R/gpurun_out/prof_mfma.err
 RML_CHUNK=23808 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_gemm_fetch -o k -- $GEMM > /dev/null 2>> $R/gpurun_out/prof_mfma.err
 RML_CHUNK=23808 RML_GEMM_BIG=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_gemm_fetch_small -o k -- $GEMM > /dev/null 2>> $R/gpurun_out/prof_mfma.err
 ( echo "# rocprofv3 --pmc (kernel trace only) on tools/kbench.py gemm --grid 64x64x128 --frames 23808 --svs 2562 (one chunk): per-kernel averages"
   echo "# --- k_svm_gemm_ring<PT,0> (256x256, 5-slot ring: the default for large batches)"; python $R/tools/pmc_query.py $R/gpurun_out/prof_mfma/k_results.db "%svm_gemm%"
-  echo "# --- k_svm_gemm_i8_256 (256x256, two stages: RML_GEMM_RING=0)"; python $R/tools/pmc_query.py $R/gpurun_out/prof_mfma_2stage/k_results.db "%svm_gemm%"
   echo "# --- k_svm_gemm<I8> 128x128 (RML_GEMM_BIG=0)"; python $R/tools/pmc_query.py $R/gpurun_out/prof_mfma_small/k_results.db "%svm_gemm%"
   echo "# --- FETCH_SIZE (KB as reported; x2 = bytes / 1024 on gfx950): ring, then 128x128"
   python $R/tools/pmc_query.py $R/gpurun_out/prof_gemm_fetch/k_results.db "%svm_gemm%"; python $R/tools/pmc_query.py $R/gpurun_out/prof_gemm_fetch_small/k_results.db "%svm_gemm%" ) > $R/gpurun_out/${TAG}_pmc_gemm.txt 2>&1
 cd $R
-rm -rf gpurun_out/prof_FETCH_SIZE gpurun_out/prof_WRITE_SIZE gpurun_out/prof_mfma gpurun_out/prof_mfma_2stage gpurun_out/prof_mfma_small gpurun_out/prof_gemm_fetch gpurun_out/prof_gemm_fetch_small
+rm -rf gpurun_out/prof_FETCH_SIZE gpurun_out/prof_WRITE_SIZE gpurun_out/prof_mfma gpurun_out/prof_mfma_small gpurun_out/prof_gemm_fetch gpurun_out/prof_gemm_fetch_small
 for f in gpurun_out/${TAG}_stats_*.txt; do echo "== $f"; head -6 $f | cut -c1-170; done
 head -12 gpurun_out/${TAG}_pmc.txt | cut -c1-170
 cat gpurun_out/${TAG}_pmc_gemm.txt | cut -c1-170
