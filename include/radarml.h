@@ -318,7 +318,6 @@ int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, in
  * (out_bf16 = 0) or bf16 (out_bf16 = 1, the operand type of rml_dnn_trunk). */
 int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stride, int64_t B, int H, int W, int out_h, int out_w,
                        float sub, float div, void* out, int out_bf16, void* stream);
-
 /* ---- dnn.py convolutional trunk (dnn.py:45-52,68-76), fused ----------------------------------------------
  * Per branch Conv2D(1->64,3x3,s2,'same',relu) -> Conv2D(64->32,3x3,s2,'same',relu); the three branches concatenated
  * on channels and flattened NHWC: feat[b][(h*(W/4)+w)*96 + branch*32 + n], bf16.  Inputs (B,H,W) already scaled to

@@ -199,7 +199,8 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
                     out=None, codes=False, num_targets=1, device=None, return_ijk=False):
     """Fused batched front door: (B,X,Y,Z) volumes -> (B,D) float32 feature rows in one pass over
     the volumes (projection + ``process_samples`` at zoom 1).  Returns a CUDA tensor; with
-    ``codes=True`` returns ``(feat, codes_u8, row_isum, row_isq, row_flags)`` for the exact SVM path.
+    ``codes=True`` returns ``(feat, codes_u8, row_isum, row_isq, row_flags)`` for the exact SVM path; ``codes='only'`` writes no float
+    rows at all (``feat`` is None).
 
     mode='slice' takes ``ijk`` as (B,3) or -- several targets per frame, the reference's ``for target in targets`` over one
     image (predict.py:93-119) -- (B,T,3): the result then has B*T rows, frame-major (row b*T+t), and no volume is
@@ -233,11 +234,17 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
         if not fused_derive:
             ijk_t, T = _slice_indices(ijk, B, X, Y, Z, dev, validate=not derived)
     R = B * T                           # output rows
-    feat = out if out is not None else torch.empty((R, D), dtype=torch.float32, device=dev)
-    if feat.shape[0] != R or feat.shape[1] < D or feat.device != dev:
+    feat = out if (out is not None or codes == "only") else torch.empty((R, D), dtype=torch.float32, device=dev)
+    if feat is not None and (feat.shape[0] != R or feat.shape[1] < D or feat.device != dev):
         raise ValueError("out must be a (%d, >=%d) float32 tensor on %s" % (R, D, dev))
     q = isum = isq = flags = None
     ldq = 0
+    if codes == "only":
+        # the projections as uint8 codes and nothing else (+ their statistics and the per-row "all integers in [0,255]" flags):
+        # the operand of the exact SVM path without the float rows through HBM
+        if out is not None:
+            raise ValueError("codes='only' writes no float rows")
+        feat = None
     if codes:
         ldq = (D + 127) // 128 * 128
         q = torch.empty((R, ldq), dtype=torch.uint8, device=dev)
@@ -248,15 +255,15 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
         if fused_derive:
             ijk_t = torch.empty((B, T, 3), dtype=torch.int32, device=dev) if return_ijk else None
             _lib.check(lib.rml_derive_slice(ctx, _lib.ptr(v), vdt, B, X, Y, Z, T, _lib.ptr(ijk_t), None, float(RADAR_MAX) if scale else 0.0,
-                                            bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                            bits, _lib.ptr(feat), feat.stride(0) if feat is not None else 0, _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                             _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_derive_slice")
         elif T > 1:
             _lib.check(lib.rml_project_slices(ctx, _lib.ptr(v), vdt, B, X, Y, Z, T, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
-                                              bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                              bits, _lib.ptr(feat), feat.stride(0) if feat is not None else 0, _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                               _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project_slices")
         else:
             _lib.check(lib.rml_project(ctx, _lib.ptr(v), vdt, B, X, Y, Z, m, _lib.ptr(ijk_t), float(RADAR_MAX) if scale else 0.0,
-                                       bits, _lib.ptr(feat), feat.stride(0), _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
+                                       bits, _lib.ptr(feat), feat.stride(0) if feat is not None else 0, _lib.ptr(q), ldq, _lib.ptr(isum), _lib.ptr(isq),
                                        _lib.ptr(flags), _lib.stream_ptr(dev)), "rml_project")
     res = (feat, q, isum, isq, flags) if codes else feat
     if return_ijk:

@@ -191,29 +191,40 @@ class Classifier(_module_base()):
         """Class probabilities with the fused HIP trunk + bf16 dense tail (hipBLASLt through PyTorch)."""
         return self.dense_tail(self.features_fused(xz, yz, xy))
 
+    def _tail_weights(self):
+        """bf16 copies of the dense kernels (float32 biases), cached until a parameter is written: autocast re-casts the three
+        weight matrices on every call (six element-wise launches of ~6 us per batch in the round-3 profile)."""
+        import torch
+        key = tuple((p._version, p.data_ptr()) for fc in (self.fc1, self.fc2, self.fc3) for p in (fc.weight, fc.bias))
+        if getattr(self, "_tail_pack_key", None) != key:
+            self._tail_pack_key = key
+            self._tail_pack = [(fc.weight.detach().to(torch.bfloat16).contiguous(), fc.bias.detach().to(torch.bfloat16).contiguous())
+                               for fc in (self.fc1, self.fc2, self.fc3)]
+        return self._tail_pack
+
     def dense_tail(self, fv):
-        """Dense 64 relu, Dense 64 relu, Dense n softmax (dnn.py:78-88) on bf16 feature rows."""
+        """Dense 64 relu, Dense 64 relu, Dense n softmax (dnn.py:78-88) on bf16 feature rows: the arithmetic of the autocast
+        region it replaces (bf16 operands, float32 accumulation, bf16 activations), without its per-call casts."""
         import torch
         import torch.nn.functional as F
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            h = F.relu(self.fc1(fv))
-            h = F.relu(self.fc2(h))
-            lg = self.fc3(h)
+        (w1, b1), (w2, b2), (w3, b3) = self._tail_weights()
+        h = F.relu(F.linear(fv, w1, b1))
+        h = F.relu(F.linear(h, w2, b2))
+        lg = F.linear(h, w3, b3)
         return torch.softmax(lg.float(), dim=-1)
 
-    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=True, trunk_events=None):
+    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=False, trunk_events=None):
         """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
         projections (csrc/project.hip) -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused
         conv trunk (csrc/dnn.hip) -> dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor.
 
-        Two streams (``overlap``): the projection of batch b+2 (HBM-bound) runs on a second stream beside the dense tail of batch
-        b and the resize of batch b+1 (float64 VALU work) -- the projection in its one-workgroup-per-CU configuration
-        (RML_OPT_PROJECT_SHARE_CU), so that the resize workgroups find room on every CU -- and the trunk, which needs a whole
-        CU's LDS, runs alone between two projection launches (the projection waits for it, it waits for the projection).  The
-        projection rows ping-pong between two buffers allocated once per call (round 2 alternated whole batches between two
-        streams through PyTorch's caching allocator, which cannot reuse a block across streams without synchronising: slower;
-        hipBLASLt is driven from the caller's stream only).  ``trunk_events``: a list that receives one
-        (start, stop) torch.cuda.Event pair per trunk launch (bench.py's in-situ roofline of k_dnn_trunk_rf)."""
+        ``overlap`` (off): the projection of batch b+2 on a second stream beside the resize of batch b+1, the trunk (a whole CU's
+        LDS) and the dense tail (hipBLASLt: 135 KB of LDS) alone between two projection launches.  Measured in round 4 (three
+        schedules, kernel timeline in tools/exp/README.md): no gain -- beside the projection the resize kernels take 3 x as long
+        (both live on the LDS pipe and the issue ports) and the projection 1.25 x, so the pair costs what the two cost in turn:
+        4.6-4.7 against 4.7-4.8 M frames/s.  Kept as a knob.  ``trunk_events``: a list that receives one (start, stop, frames)
+        torch.cuda.Event triple per trunk launch (bench.py's in-situ roofline of k_dnn_trunk_rf).
+        """
         import torch
         from . import common, nn_common, _lib
         if not isinstance(volumes, torch.Tensor):
@@ -246,7 +257,6 @@ class Classifier(_module_base()):
                 sp = self._proj_stream = torch.cuda.Stream(device=dev)
             feats = [torch.empty((bs, D), dtype=torch.float32, device=dev) for _ in range(2)]
             ev_proj = [torch.cuda.Event(), torch.cuda.Event()]
-            ev_free = [torch.cuda.Event(), torch.cuda.Event()]
             sp.wait_stream(cur)                         # the volumes (and the fresh buffers) are the caller's stream's
             _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 1), "rml_ctx_set_option")
             ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]
@@ -262,20 +272,27 @@ class Classifier(_module_base()):
                             sp.wait_event(ev_trunk[k])
                         common.process_volumes(volumes[s0:s1], mode=mode, scale=False, out=feats[k][:s1 - s0])
                         ev_proj[k].record(sp)
-                project(0)
-                if nb > 1:
-                    project(1)
-                for b in range(nb):
+                def resize(b):
                     k = b & 1
                     s0, s1 = b * bs, min(n, (b + 1) * bs)
                     cur.wait_event(ev_proj[k])
-                    xs = nn_common.preprocess_features(feats[k][:s1 - s0], (X, Y, Z), rescale, out_dtype="bfloat16")
+                    return nn_common.preprocess_features(feats[k][:s1 - s0], (X, Y, Z), rescale, out_dtype="bfloat16")
+                project(0)
+                if nb > 1:
+                    project(1)
+                xs = resize(0)
+                for b in range(nb):
+                    k = b & 1
+                    s0, s1 = b * bs, min(n, (b + 1) * bs)
                     if b + 1 < nb:
                         cur.wait_event(ev_proj[(b + 1) & 1])    # the trunk could not start beside the running projection anyway
                     fv = self._features_timed(xs, trunk_events)
                     ev_trunk[k].record(cur)
                     if b + 2 < nb:
-                        project(b + 2)                  # runs beside this batch's dense tail and the next batch's resize
+                        project(b + 2)                  # second stream: behind this trunk
+                    if b + 1 < nb:
+                        xs = resize(b + 1)              # float64 VALU work beside the streaming projection of batch b+2
+                    # the dense tail last: hipBLASLt's kernel wants 135 KB of LDS and waits for the projection to leave the CUs
                     out[s0:s1] = self.dense_tail(fv)
             finally:
                 _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0), "rml_ctx_set_option")
