@@ -159,3 +159,54 @@ def test_round2_entry_points_reject_bad_arguments(rml):
     for t in ts:
         t.join(120)
     assert not errs, errs
+
+
+def test_round4_entry_points_reject_bad_arguments_and_options(rml):
+    """rml_derive_slice / rml_derive_project_svm / rml_derive_slice_supported / rml_ctx_set_option through the C ABI: status
+    codes and messages for bad arguments, the support predicate, and the projection option (same results with it on)."""
+    import torch
+    from radar_ml_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.context()
+    st = _lib.stream_ptr()
+    X, Y, Z = 4, 6, 16
+    D = X * Z + Y * Z + X * Y
+    v = torch.zeros((3, X, Y, Z), device="cuda")
+    feat = torch.empty((3, D), device="cuda")
+    ijk = torch.empty((3, 3), dtype=torch.int32, device="cuda")
+    ok = lambda nt, mask=7, ld=D, vol=v: lib.rml_derive_slice(ctx, _lib.ptr(vol), 0, 3, X, Y, Z, nt, _lib.ptr(ijk), None, 0.0, mask,
+                                                              _lib.ptr(feat), ld, None, 0, None, None, None, st)
+    assert ok(1) == 0
+    assert ok(0) == -1 and b"num_targets" in lib.rml_last_error()
+    assert ok(5) == -1                                                   # more targets than X
+    assert ok(1, mask=0) == -1 and b"mask" in lib.rml_last_error()
+    assert ok(1, ld=D - 1) == -1 and b"ld_feat" in lib.rml_last_error()
+    assert ok(1, vol=None) == -1
+    assert lib.rml_derive_slice(ctx, None, 0, 0, X, Y, Z, 1, None, None, 0.0, 7, None, 0, None, 0, None, None, None, st) == 0      # B == 0
+    assert lib.rml_derive_slice(ctx, _lib.ptr(v), 7, 3, X, Y, Z, 1, None, None, 0.0, 7, _lib.ptr(feat), D, None, 0, None, None, None, st) == -1
+    # support predicate: whole quads, Z <= 256, odd part of Z/4 <= 15, aligned base
+    assert lib.rml_derive_slice_supported(None, 0, 22, 31, 176, 1) == 1 and lib.rml_derive_slice_supported(None, 1, 64, 64, 128, 3) == 1
+    assert lib.rml_derive_slice_supported(None, 0, 4, 4, 18, 1) == 0 and lib.rml_derive_slice_supported(None, 0, 4, 4, 132, 1) == 0
+    assert lib.rml_derive_slice_supported(None, 0, 4, 4, 260, 1) == 0 and lib.rml_derive_slice_supported(None, 9, 4, 4, 16, 1) == 0
+    assert lib.rml_derive_slice_supported(_lib.c_void_p(v.data_ptr() + 4), 0, X, Y, Z, 1) == 0
+    # rml_derive_project_svm refuses a shape without the fused kernel with a message that names the way out
+    import numpy as np
+    sv = np.zeros((4, 4 * 18 + 4 * 18 + 16)); dc = np.zeros((2, 4)); ic = np.zeros(3); ns = np.array([2, 1, 1], dtype=np.int32)
+    h = C.c_void_p()
+    assert lib.rml_svm_load(ctx, sv.ctypes.data, 4, sv.shape[1], dc.ctypes.data, ic.ctypes.data, ns.ctypes.data, 3, 0, 0.1, 255.0, None, None, C.byref(h)) == 0
+    v18 = torch.zeros((2, 4, 4, 18), device="cuda")
+    lab = torch.empty((2,), dtype=torch.int32, device="cuda")
+    assert lib.rml_derive_project_svm(ctx, h, _lib.ptr(v18), 0, 2, 4, 4, 18, 255.0, 7, None, None, None, None, _lib.ptr(lab), None, st) == -2
+    assert b"rml_derive_targets" in lib.rml_last_error()
+    lib.rml_svm_free(ctx, h)
+    # options
+    assert lib.rml_ctx_set_option(ctx, 99, 1) == -1 and b"option" in lib.rml_last_error()
+    assert lib.rml_ctx_set_option(None, _lib.OPT_PROJECT_SHARE_CU, 1) == -1
+    V, _ = rml.synth_volumes(1500, 22, 31, 176, seed=2)
+    a = rml.process_volumes(V, mode="max", scale=True)
+    assert lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 1) == 0
+    try:
+        b = rml.process_volumes(V, mode="max", scale=True)
+    finally:
+        assert lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0) == 0
+    assert torch.equal(a, b)
