@@ -318,6 +318,29 @@ int rml_linear_decision(rml_ctx* ctx, const rml_linear* m, const float* feat, in
  * (out_bf16 = 0) or bf16 (out_bf16 = 1, the operand type of rml_dnn_trunk). */
 int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stride, int64_t B, int H, int W, int out_h, int out_w,
                        float sub, float div, void* out, int out_bf16, void* stream);
+/* ---- the same preprocessing for the bf16 conv trunk, all three projections of a feature row in ONE launch ------------
+ * dnn.py:200-254 ((p - 127.5) / 127.5, then the bicubic resize of xz (X x Z), yz (Y x Z) and xy (X x Y) to out_h x out_w) with
+ * bf16 outputs (the operand type of rml_dnn_trunk).  Pillow's windows and normalised weights -- the tables of
+ * rml_resize_bicubic -- applied in float32 (fused multiply-adds, partial sums): NOT bit-identical to Pillow, within ~1e-6 of it
+ * before the bf16 rounding (the bf16 value differs from the rounded exact one by at most one bf16 ulp on a small fraction of
+ * the pixels); rml_resize_bicubic stays the Pillow-exact surface.  Input per row: the float32 feature row [xz | yz | xy]
+ * (rows, ld floats apart) and / or the biased uint8 code row rml_project writes (codes, ldq bytes apart, 16-byte aligned);
+ * with both given, flags[b] != 0 selects the code row of row b (the per-row "every value is an integer in [0, 255]" flag of
+ * rml_project); codes alone: always the code row.  Outputs: (B, out_h, out_w) bf16, 8-byte aligned.
+ * Shapes: Z % 16 == 0, out_w % 4 == 0, out_w <= 256, out_h >= X and >= Y (no vertical shrink), (X + Y) * Z <= 16 384,
+ * X * Y <= 4 096 -- rml_dnn_preprocess_supported says; others: RML_ERR_UNSUPPORTED (rml_resize_bicubic per projection). */
+int rml_dnn_preprocess_supported(int X, int Y, int Z, int out_h, int out_w);
+int rml_dnn_preprocess_rows(rml_ctx* ctx, const float* rows, int64_t ld, const uint8_t* codes, int64_t ldq, const int32_t* flags,
+                            int64_t B, int X, int Y, int Z, int out_h, int out_w, uint16_t* xz, uint16_t* yz, uint16_t* xy,
+                            void* stream);
+/* Volumes -> trunk inputs (the front of BASELINE configs[3]): projection (mode as rml_project; ijk for RML_MODE_SLICE) into code rows
+ * + row flags (no float rows through HBM), for float32 volumes a float-row pass predicated ON THE DEVICE on "some row left the
+ * code grid" (it exits at once for radar data, integers 0..255: common.py:30-31), then rml_dnn_preprocess_rows.  Scratch is the
+ * caller's: codes B x ldq bytes (ldq >= D, % 16 == 0), flags B + 1 int32 (flags[B]: every row on the grid), rows B x ld float32
+ * (float32 volumes only; NULL for uint8 volumes, which cannot leave the grid). */
+int rml_dnn_preprocess_volumes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode, const int32_t* ijk,
+                               uint8_t* codes, int64_t ldq, int32_t* flags, float* rows, int64_t ld, int out_h, int out_w,
+                               uint16_t* xz, uint16_t* yz, uint16_t* xy, void* stream);
 /* ---- dnn.py convolutional trunk (dnn.py:45-52,68-76), fused ----------------------------------------------
  * Per branch Conv2D(1->64,3x3,s2,'same',relu) -> Conv2D(64->32,3x3,s2,'same',relu); the three branches concatenated
  * on channels and flattened NHWC: feat[b][(h*(W/4)+w)*96 + branch*32 + n], bf16.  Inputs (B,H,W) already scaled to
@@ -327,6 +350,29 @@ int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stride, int64_t
 int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H, int W,
                   const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
                   uint16_t* feat, void* stream);
+/* The same values in the layout rml_dnn_dense_tail streams best ("K-block"): feat[kb][b][64] bf16 with the K axis ordered (branch,
+ * pixel, channel) -- element (branch, pixel, channel) of sample b at block kb = (branch * P + pixel) / 2, offset (pixel & 1) * 32 +
+ * channel, P = (H/4) * (W/4) even.  A 128-sample tile of one K-step is then 16 KB of contiguous memory (row-major rows put those
+ * 128 pieces of 128 B 76.8 KB apart: every piece its own DRAM page, 3.3-3.6 TB/s for every GEMM that was tried on it).
+ * RML_ERR_UNSUPPORTED for planes the register-resident trunk kernel does not take. */
+int rml_dnn_trunk_kblock(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H, int W,
+                         const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                         uint16_t* feat, void* stream);
+
+/* ---- dnn.py dense tail (dnn.py:78-88), fused -----------------------------------------------------------------
+ * Dense 64 relu -> Dense 64 relu -> Dense n_classes softmax on the bf16 feature rows of rml_dnn_trunk (Dropout is inactive at
+ * inference): proba[b][c] float32.  The first layer runs on the bf16 matrix cores (float32 accumulation, split-K with the partial
+ * sums added in a fixed order: deterministic), the two small layers and the softmax in float32.  feat: N rows of K bf16, ld_feat
+ * elements apart (kblock = 0; K % 64 == 0, ld_feat % 8 == 0, 16-byte aligned), or the [K/64][N][64] layout of rml_dnn_trunk_kblock
+ * (kblock = 1: w1 is then blocked the same way, [K/64][64 out][64], the K axis in the (branch, pixel, channel) order); w1 [64][K]
+ * bf16 (kblock = 0: torch Linear layout, out x in), b1 [64];
+ * w2t [64 in][64 out] float32 -- the TRANSPOSE of torch's (out, in) = the Keras kernel layout (in, out) --, b2 [64]; w3
+ * [n_classes][64] float32 (torch layout), b3 [n_classes]; n_classes <= 16.  workspace: rml_dnn_dense_workspace_bytes(ctx, N, K)
+ * bytes of device memory, 16-byte aligned (the split-K partial sums). */
+int64_t rml_dnn_dense_workspace_bytes(rml_ctx* ctx, int64_t N, int64_t K);
+int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld_feat, int kblock, int64_t N, int64_t K, const uint16_t* w1, const float* b1,
+                       const float* w2t, const float* b2, const float* w3, const float* b3, int n_classes, float* workspace,
+                       int64_t workspace_bytes, float* proba, void* stream);
 
 /* ---- SGAN discriminator branches: fused BatchNorm(train) + LeakyReLU + 'same' pad (sgan.py:137-158) -------------
  * x: N x H x W x C (NHWC, dense) float16 (dtype 0) or bfloat16 (dtype 1), the convolution output; y: N x (H+pad_h) x

@@ -114,6 +114,7 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_ev_g) (void)hipEventDestroy(e);
     for (const rml_resize_tab& t : ctx->resize_tabs) (void)hipFree(const_cast<double*>(t.kk));
+    for (const rml_pre_tab& t : ctx->pre_tabs) (void)hipFree(t.dev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->proj_stream) (void)hipStreamDestroy(ctx->proj_stream);
     delete ctx;

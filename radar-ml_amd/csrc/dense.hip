@@ -1,0 +1,269 @@
+// Dense tail of the multi-view CNN (dnn.py:78-88: Flatten -> Dense 64 relu -> Dense 64 relu -> Dense n softmax; Dropout is inactive at
+// inference) on the 38 400-long bf16 feature rows the conv trunk (dnn.hip) writes.
+//
+// The first layer is the only one with bytes in it: 8 192 rows x 76.8 KB = 629 MB read once against 4.9 MFLOP per row -- HBM-bound
+// (64 FLOP per byte at bf16 on the matrix cores is far below the machine's balance).  hipBLASLt's pick for this shape
+// (MT64x64x256, one 135 KB workgroup per CU) streams it at 3.4 TB/s (186 us, profiles/r04_stats_dnn.txt); behind it PyTorch launches
+// two GEMMs, two clamps, a cast and a softmax of ~5 us each.  Here:
+//
+//  * k_fc1_splitk: 128 rows x 64 outputs per workgroup and K-step of 64 elements (128 B per row), split-K so that the grid is one
+//    round of three workgroups per CU; the tiles of a step are loaded lane-contiguously into registers three K-steps ahead and go
+//    through two XOR-swizzled [rows][128 B] LDS stages, one LDS-only barrier per step; v_mfma_f32_32x32x16_bf16 with the weights as the A (row) operand and the samples as B, so a lane ends
+//    up with 4 consecutive outputs of ONE sample per accumulator quad: float4 stores of the float32 partial sums.
+//  * k_dense_finish: one wave per sample sums the partials in split order (deterministic), adds the bias, relu; the two small
+//    layers run in float32 in the wave (lane = output unit, the previous layer's activations broadcast with v_readlane), softmax in
+//    lane order.  Activations between the layers stay float32 (the autocast chain this replaces rounded them to bf16).
+#include "rml_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kStepBytes = 128;                 // K-step: 64 bf16 per row
+constexpr int kXRows = 128, kWRows = 64;        // rows of a tile (samples), hidden units
+constexpr int kXBytes = kXRows * kStepBytes, kWBytes = kWRows * kStepBytes, kStageBytes = kXBytes + kWBytes;
+constexpr int kHidden = 64;
+
+struct Fc1Args {
+    const uint8_t* x; int64_t ldx;      // bf16 rows, ldx BYTES apart
+    int64_t kstride;                    // bytes from one K-step of a row to the next: 128 (rows), N * 128 (K-block layout, ldx = 128)
+    int64_t N;
+    const uint8_t* w; int64_t ldw;      // [64][K] bf16, ldw bytes apart ...
+    int64_t wstride;                    // ... and 128 bytes per K-step; K-block layout: [K/64][64][64], ldw = 128, wstride = 8192
+    int KT, S, steps;                   // K-steps in all, splits, K-steps per split
+    float* partial;                     // [S][N][64]
+};
+
+// K-steps in flight per thread: the workgroup's sample tile and weight tile of a step wait in registers (six 16-byte chunks per thread)
+constexpr int kDepth = 3;
+
+// LDS-only barrier: __syncthreads() carries a fence that drains the vector-memory queue (the prefetched steps)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// How this kernel got here (each version measured on 8 192 x 38 400, the time to beat: hipBLASLt 186 us = 3.4 TB/s):
+//  1. rows and weights by LDS-DMA (global_load_lds) into two stages, one in flight per workgroup: 174 us -- every step waits out
+//     a full memory latency;
+//  2. the same with a deeper DMA ring: hipcc treats a global_load_lds as a FLAT access that may return out of order and turns
+//     EVERY later vmcnt wait into vmcnt(0) -- the queue drained once per loop trip;
+//  3. no DMA, rows straight into the lanes that feed the matrix core (lane (n, h): 16 bytes of row n), three steps ahead: 190 us --
+//     neighbouring lanes read rows 76.8 KB (K-block layout: 128 B) apart, so a wave instruction is 64 separate 16-byte requests;
+//     the K-block layout alone: 159 us;
+//  4. (this one) every global load instruction is lane-contiguous -- 8 lanes per 128-byte row piece, in the K-block layout the
+//     whole instruction one 1 KiB run --, three steps ahead in registers, through two XOR-swizzled LDS stages into fragments.
+__global__ __launch_bounds__(256, 3) void k_fc1_splitk(Fc1Args a) {
+    __shared__ __align__(16) unsigned char smem[2 * kStageBytes];      // two stages of [128 sample rows | 64 weight rows] x 128 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x / a.S, split = blockIdx.x - tile * a.S;
+    const int64_t n0 = (int64_t)tile * kXRows;
+    const int k0 = split * a.steps;
+    int cnt = a.KT - k0;
+    cnt = cnt < a.steps ? cnt : a.steps;
+    const int chalf = lane >> 5;
+
+    // chunk s = q * 256 + tid of a tile: row s >> 3, 16-byte chunk s & 7 (a wave instruction: 8 whole 128-byte row pieces); LDS
+    // image [row][128 B] with the chunk index XOR-swizzled by (row >> 1) & 7: conflict-free ds_read_b128 fragments
+    const uint8_t* gx[4];
+    const uint8_t* gw[2];
+    int xdst[4], wdst[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = q * 256 + tid;
+        const int r = s >> 3, c = s & 7;
+        int64_t xr = n0 + r;
+        xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ldx + c * 16 + (int64_t)k0 * a.kstride;
+        xdst[q] = r * kStepBytes + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = q * 256 + tid;
+        const int r = s >> 3, c = s & 7;
+        gw[q] = a.w + (int64_t)r * a.ldw + c * 16 + (int64_t)k0 * a.wstride;
+        wdst[q] = kXBytes + r * kStepBytes + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    const int last = cnt > 0 ? cnt - 1 : 0;
+    v4i xs[kDepth][4], ws[kDepth][2];                   // step j lives in set j % kDepth
+    auto issue = [&](int kt, v4i (&dx)[4], v4i (&dw)[2]) {      // step kt (clamped: the tail re-reads the last step, harmlessly)
+        const int k = kt < last ? kt : last;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dw[q] = *reinterpret_cast<const v4i*>(gw[q] + (int64_t)k * a.wstride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx[q] = *reinterpret_cast<const v4i*>(gx[q] + (int64_t)k * a.kstride);
+        // keep the steps in issue order: hipcc moves loads of one step behind the next one's, and the wait for them at the loop
+        // head -- one static instruction for the prologue and the back edge -- then drains the queue every kDepth steps
+        asm volatile("" ::: "memory");
+    };
+    auto put = [&](int stage, const v4i (&dx)[4], const v4i (&dw)[2]) {
+        unsigned char* base = smem + stage * kStageBytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<v4i*>(base + xdst[q]) = dx[q];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<v4i*>(base + wdst[q]) = dw[q];
+    };
+
+    // fragments: the wave's 32 samples are the B (column) operand, the 64 hidden units two A (row) tiles
+    const int rb = wave * 32 + (lane & 31);
+    const int boff = rb * kStepBytes, bsw = (rb >> 1) & 7;
+    int aoff[2], asw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = i * 32 + (lane & 31);
+        aoff[i] = kXBytes + ra * kStepBytes; asw[i] = (ra >> 1) & 7;
+    }
+    v16f acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    if (cnt > 0) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) issue(d, xs[d], ws[d]);
+        put(0, xs[0], ws[0]);                           // step 0 goes to LDS; its set takes step kDepth
+        issue(kDepth, xs[0], ws[0]);
+        for (int t0 = 0; t0 < cnt; t0 += kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                const int kt = t0 + d;
+                // step kt's stage (written during step kt - 1) is complete and visible; the other stage (read during step kt - 1)
+                // is free for step kt + 1's tiles
+                lds_barrier();
+                put((kt + 1) & 1, xs[(d + 1) % kDepth], ws[(d + 1) % kDepth]);
+                if (kt < cnt) {
+                    const unsigned char* st = smem + (kt & 1) * kStageBytes;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int ch = 2 * kk + chalf;
+                        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(st + boff + ((ch ^ bsw) << 4));
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + aoff[i] + ((ch ^ asw[i]) << 4));
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                issue(kt + kDepth + 1, xs[(d + 1) % kDepth], ws[(d + 1) % kDepth]);     // the set that has just gone to LDS
+            }
+        }
+    }
+
+    // acc[i][4 j + t] = hidden unit 32 i + 8 j + 4 (lane >> 5) + t of sample n0 + wave * 32 + (lane & 31)
+    const int64_t n = n0 + rb;
+    if (n < a.N) {
+        float* dst = a.partial + ((int64_t)split * a.N + n) * kHidden + 4 * chalf;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(dst + 32 * i + 8 * j) = make_float4(acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]);
+    }
+}
+
+struct FinishArgs {
+    const float* partial; int S; int64_t N;
+    const float* b1;            // [64]
+    const float* w2t;           // [64 in][64 out] float32 (transposed: unit-contiguous)
+    const float* b2;            // [64]
+    const float* w3;            // [C][64]
+    const float* b3;            // [C]
+    int C;
+    float* out;                 // [N][C] probabilities
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_dense_finish(FinishArgs a) {
+    __shared__ float w2s[kHidden * kHidden];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kHidden * kHidden; i += 256) w2s[i] = a.w2t[i];
+    __syncthreads();
+    const float b1 = a.b1[lane], b2 = a.b2[lane];
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + (tid >> 6); n < a.N; n += nw) {
+        float h = b1;
+        for (int s = 0; s < a.S; ++s) h += a.partial[((int64_t)s * a.N + n) * kHidden + lane];
+        h = fmaxf(h, 0.0f);
+        float g = b2;
+#pragma unroll
+        for (int k = 0; k < kHidden; ++k)
+            g = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k)), w2s[k * kHidden + lane], g);
+        g = fmaxf(g, 0.0f);
+        // logits in every lane (C <= 16), softmax in float32 like torch.softmax(lg.float())
+        float lg[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < a.C) {
+                lg[c] = wave_sum(g * a.w3[c * kHidden + lane]) + a.b3[c];
+                mx = fmaxf(mx, lg[c]);
+            }
+        }
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.C) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.C && lane == c) a.out[n * a.C + c] = lg[c] / den;
+    }
+}
+
+int pick_splits(int64_t tiles, int KT, int num_cu) {
+    // one round of three workgroups per CU where the K extent allows it; K-steps per split as even as possible
+    int64_t s = ((int64_t)3 * num_cu + tiles - 1) / tiles;
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    if (s > KT) s = KT;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t rml_dnn_dense_workspace_bytes(rml_ctx* ctx, int64_t N, int64_t K) {
+    if (!ctx || N <= 0 || K <= 0) return 0;
+    const int64_t tiles = (N + kXRows - 1) / kXRows;
+    const int S = pick_splits(tiles, (int)(K / 64), ctx->num_cu);
+    return (int64_t)S * N * kHidden * (int64_t)sizeof(float);
+}
+
+extern "C" int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld_feat, int kblock, int64_t N, int64_t K, const uint16_t* w1, const float* b1,
+                                  const float* w2t, const float* b2, const float* w3, const float* b3, int n_classes, float* workspace,
+                                  int64_t workspace_bytes, float* proba, void* stream) {
+    RML_REQUIRE(ctx && N >= 0 && K > 0, RML_ERR_INVALID, "rml_dnn_dense_tail: bad arguments");
+    RML_REQUIRE(K % 64 == 0 && (kblock || (ld_feat >= K && ld_feat % 8 == 0)), RML_ERR_UNSUPPORTED,
+                "rml_dnn_dense_tail: K = %lld must be a multiple of 64 (ld_feat of 8)", (long long)K);
+    RML_REQUIRE(n_classes >= 1 && n_classes <= 16, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail: 1..16 classes");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(feat && w1 && b1 && w2t && b2 && w3 && b3 && workspace && proba, RML_ERR_INVALID, "rml_dnn_dense_tail: NULL argument");
+    RML_REQUIRE(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+                RML_ERR_INVALID, "rml_dnn_dense_tail: feat, w1 and the workspace need 16-byte alignment");
+    RML_REQUIRE(N < (int64_t)1 << 31 && K < (int64_t)1 << 30, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail: too large");
+    RML_REQUIRE(workspace_bytes >= rml_dnn_dense_workspace_bytes(ctx, N, K), RML_ERR_INVALID, "rml_dnn_dense_tail: workspace too small");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t tiles = (N + kXRows - 1) / kXRows;
+    Fc1Args fa{};
+    fa.x = reinterpret_cast<const uint8_t*>(feat); fa.N = N;
+    fa.ldx = kblock ? kStepBytes : ld_feat * 2;
+    fa.kstride = kblock ? N * kStepBytes : kStepBytes;
+    fa.w = reinterpret_cast<const uint8_t*>(w1);
+    fa.ldw = kblock ? kStepBytes : K * 2;
+    fa.wstride = kblock ? kWBytes : kStepBytes;
+    fa.KT = (int)(K / 64);
+    fa.S = pick_splits(tiles, fa.KT, ctx->num_cu);
+    fa.steps = (fa.KT + fa.S - 1) / fa.S;
+    fa.partial = workspace;
+    hipLaunchKernelGGL(k_fc1_splitk, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
+    FinishArgs fi{};
+    fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
+    const int64_t blocks = (N + 3) / 4;
+    hipLaunchKernelGGL(k_dense_finish, dim3((unsigned)(blocks < 8 * ctx->num_cu ? blocks : 8 * ctx->num_cu)), dim3(256), 0, st, fi);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}

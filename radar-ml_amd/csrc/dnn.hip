@@ -53,6 +53,7 @@ struct TrunkArgs {
     const uint16_t* w2t;    // [3][32][576] bf16, k = (ky*3+kx)*64 + cin
     const float* b2;        // [3][32]
     uint16_t* feat;         // [B][OH2*OW2*96] bf16
+    int kblock;             // k_dnn_trunk_rf: feat is [K/64][B][64] with K ordered (branch, pixel, channel) -- see rml_dnn_trunk_kblock
 };
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -481,7 +482,11 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
             }
             int pr = pr0, pc = pc0;
             // the lane's 32 bytes of a pixel's feature row: channels 16 h .. 16 h + 15 of this branch
-            uint16_t* dst = a.feat + (b * (int64_t)P + n) * 96 + br * 32 + 16 * h;
+            // (K-block layout: element (branch, pixel, channel) of sample b at block (branch * P + pixel) / 2 -- two pixels of 32
+            // channels -- , i.e. the lanes (n, n + 1) x (h = 0, 1) fill one 128-byte line and a tile advances 16 blocks)
+            uint16_t* dst = a.kblock ? a.feat + ((int64_t)((br * P + n) >> 1) * a.B + b) * 64 + (n & 1) * 32 + 16 * h
+                                     : a.feat + (b * (int64_t)P + n) * 96 + br * 32 + 16 * h;
+            const int64_t dstep = a.kblock ? 16 * a.B * 64 : 32 * 96;
             for (int tile = 0; tile < NT; ++tile) {
                 // ---- addresses of this tile's windows
                 const bool live = tile * 32 + n < P;
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
                     *reinterpret_cast<uint4*>(dst) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
                     *reinterpret_cast<uint4*>(dst + 8) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
                 }
-                dst += 32 * 96;
+                dst += dstep;
                 pr += incr; pc += incc;
                 if (pc >= OW2) { pc -= OW2; pr += 1; }
             }
@@ -639,8 +644,8 @@ template <bool INBF>
 int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
     int rc = RML_ERR_UNSUPPORTED;
     static const int which = [] { const char* e = getenv("RML_DNN_TRUNK"); return e ? atoi(e) : 1; }();      // 0: LDS-image kernel only
-    if (which) rc = launch_trunk_rf<INBF>(a, num_cu, st);
-    if (rc != RML_ERR_UNSUPPORTED) return rc;
+    if (which || a.kblock) rc = launch_trunk_rf<INBF>(a, num_cu, st);
+    if (rc != RML_ERR_UNSUPPORTED || a.kblock) return rc;          // the K-block layout exists in the register-resident kernel only
     // (measured and dropped: a wave-specialised variant -- one 8-wave workgroup per CU, 4 producer waves doing conv1 and 4
     // consumer waves doing conv2 on a double-buffered conv1 image, one producer and one consumer per SIMD: 0.72 ms against
     // 0.675, archived as tools/exp/dnn_trunk_wave_specialised_kernel.hip.txt; and 2-row strips at three workgroups per CU -- 148 VGPRs, 49 KB LDS -- 0.78 ms against 0.69:
@@ -653,9 +658,9 @@ int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H,
-                             int W, const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
-                             uint16_t* feat, void* stream) {
+static int trunk_entry(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H,
+                       int W, const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                       uint16_t* feat, int kblock, void* stream) {
     RML_REQUIRE(ctx && B >= 0 && H > 0 && W > 0, RML_ERR_INVALID, "rml_dnn_trunk: bad arguments");
     if (B == 0) return RML_OK;
     RML_REQUIRE(xz && yz && xy && w1 && b1 && w2t && b2 && feat, RML_ERR_INVALID, "rml_dnn_trunk: NULL argument");
@@ -669,10 +674,23 @@ extern "C" int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const
     RML_HIP(hipSetDevice(ctx->device));
     TrunkArgs a{};
     a.in[0] = xz; a.in[1] = yz; a.in[2] = xy; a.B = B; a.H = H; a.W = W;
-    a.w1 = w1; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.feat = feat;
+    a.w1 = w1; a.b1 = b1; a.w2t = w2t; a.b2 = b2; a.feat = feat; a.kblock = kblock;
+    RML_REQUIRE(!kblock || ((H / 4) * (W / 4)) % 2 == 0, RML_ERR_UNSUPPORTED, "rml_dnn_trunk_kblock: an even number of output pixels expected");
     const int rc = in_bf16 ? dispatch_trunk<true>(a, ctx->num_cu, static_cast<hipStream_t>(stream))
                            : dispatch_trunk<false>(a, ctx->num_cu, static_cast<hipStream_t>(stream));
     RML_REQUIRE(rc != RML_ERR_UNSUPPORTED, RML_ERR_UNSUPPORTED, "rml_dnn_trunk: plane %dx%d does not fit the LDS-resident trunk", H, W);
     RML_HIP(hipGetLastError());
     return RML_OK;
+}
+
+extern "C" int rml_dnn_trunk(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H,
+                             int W, const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                             uint16_t* feat, void* stream) {
+    return trunk_entry(ctx, xz, yz, xy, in_bf16, B, H, W, w1, b1, w2t, b2, feat, 0, stream);
+}
+
+extern "C" int rml_dnn_trunk_kblock(rml_ctx* ctx, const void* xz, const void* yz, const void* xy, int in_bf16, int64_t B, int H,
+                                    int W, const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
+                                    uint16_t* feat, void* stream) {
+    return trunk_entry(ctx, xz, yz, xy, in_bf16, B, H, W, w1, b1, w2t, b2, feat, 1, stream);
 }

@@ -15,6 +15,13 @@ struct rml_resize_tab {
     const double* kk;       // [out][ksize]
 };
 
+// device tables of the CNN preprocessing kernel for one (grid, output size) pair (preprocess.hip)
+struct rml_pre_tab {
+    int X, Y, Z, OH, OW;
+    void* dev;              // one allocation; the six tables start at off[]
+    size_t off[6];
+};
+
 struct rml_ctx {
     int device = 0;
     int num_cu = 256;
@@ -41,6 +48,7 @@ struct rml_ctx {
     size_t prof_used_g = 0;
     double prof_ops_g = 0.0;
     std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
+    std::vector<rml_pre_tab> pre_tabs;          // owned; freed with the context
     // RML_OPT_PROJECT_SHARE_CU: stand-alone projection launches (rml_project*) use the configuration the fused pipeline uses
     // beside a GEMM -- one persistent workgroup per CU, LDS request padded -- so that another kernel of the caller's (on another
     // stream) finds room on every CU

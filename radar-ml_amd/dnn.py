@@ -168,9 +168,11 @@ class Classifier(_module_base()):
             pk = self._trunk_pack = (w1, b1, w2t, b2)
         return pk
 
-    def features_fused(self, xz, yz, xy):
-        """The 38 400-long NHWC feature rows (bf16) of the three conv branches from the fused HIP kernel
-        (csrc/dnn.hip); inputs (N,H,W) or (N,1,H,W) CUDA tensors, float32 or bfloat16 (same results)."""
+    def features_fused(self, xz, yz, xy, layout="nhwc"):
+        """The conv features (bf16) of the three branches from the fused HIP kernel (csrc/dnn.hip); inputs (N,H,W) or
+        (N,1,H,W) CUDA tensors, float32 or bfloat16 (same results).  ``layout="nhwc"``: (N, 38 400) rows in Keras' Flatten
+        order; ``layout="kblock"``: the same values as (K/64, N, 64) with the K axis ordered (branch, pixel, channel) -- what
+        ``dense_tail(..., kblock=True)`` streams (rml_dnn_trunk_kblock)."""
         import torch
         from . import _lib
         lib = _lib.load()
@@ -180,43 +182,104 @@ class Classifier(_module_base()):
         n, H, W = xs[0].shape
         dev = xs[0].device
         w1, b1, w2t, b2 = self._packed_trunk_weights()
-        feat = torch.empty((n, (H // 4) * (W // 4) * 96), dtype=torch.bfloat16, device=dev)
+        K = (H // 4) * (W // 4) * 96
+        kb = layout == "kblock"
+        if not kb and layout != "nhwc":
+            raise ValueError("layout must be 'nhwc' or 'kblock'")
+        feat = torch.empty((K // 64, n, 64) if kb else (n, K), dtype=torch.bfloat16, device=dev)
+        fn = lib.rml_dnn_trunk_kblock if kb else lib.rml_dnn_trunk
         with torch.cuda.device(dev):
-            _lib.check(lib.rml_dnn_trunk(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), 1 if bf else 0,
-                                         n, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(feat),
-                                         _lib.stream_ptr(dev)), "rml_dnn_trunk")
+            _lib.check(fn(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), 1 if bf else 0,
+                          n, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(feat),
+                          _lib.stream_ptr(dev)), "rml_dnn_trunk")
         return feat
 
+    def kblock_supported(self, H, W):
+        """True when trunk and dense tail can hand the features over in the K-block layout: planes the register-resident trunk
+        kernel takes (the 80 x 80 of dnn.py does), an even number of output pixels, the reference's 64 / 64 / n dense layers."""
+        P = (H // 4) * (W // 4)
+        return (H % 4 == 0 and W % 8 == 0 and P % 2 == 0 and H <= 96 and W <= 96 and len(self.branches) == 3
+                and tuple(self.fc2.weight.shape) == (64, 64) and self.fc1.weight.shape[0] == 64 and self.n_classes <= 16
+                and self.fc1.weight.shape[1] == P * 96)
+
     def forward_fused(self, xz, yz, xy):
-        """Class probabilities with the fused HIP trunk + bf16 dense tail (hipBLASLt through PyTorch)."""
+        """Class probabilities with the fused HIP trunk + the fused dense tail (csrc/dense.hip)."""
+        H, W = int(xz.shape[-2]), int(xz.shape[-1])
+        if self.kblock_supported(H, W):
+            return self.dense_tail(self.features_fused(xz, yz, xy, layout="kblock"), kblock=True)
         return self.dense_tail(self.features_fused(xz, yz, xy))
 
     def _tail_weights(self):
-        """bf16 copies of the dense kernels (float32 biases), cached until a parameter is written: autocast re-casts the three
-        weight matrices on every call (six element-wise launches of ~6 us per batch in the round-3 profile)."""
+        """The dense kernels in the layouts the tail uses, cached until a parameter is written: bf16 copies for the matrix cores
+        (autocast re-casts the three weight matrices on every call: six element-wise launches of ~6 us per batch in the round-3
+        profile) and the float32 operands of rml_dnn_dense_tail (second kernel transposed to (in, out), biases)."""
         import torch
         key = tuple((p._version, p.data_ptr()) for fc in (self.fc1, self.fc2, self.fc3) for p in (fc.weight, fc.bias))
         if getattr(self, "_tail_pack_key", None) != key:
             self._tail_pack_key = key
             self._tail_pack = [(fc.weight.detach().to(torch.bfloat16).contiguous(), fc.bias.detach().to(torch.bfloat16).contiguous())
                                for fc in (self.fc1, self.fc2, self.fc3)]
+            self._tail_f32 = (self.fc1.bias.detach().float().contiguous(), self.fc2.weight.detach().float().t().contiguous(),
+                              self.fc2.bias.detach().float().contiguous(), self.fc3.weight.detach().float().contiguous(),
+                              self.fc3.bias.detach().float().contiguous())
+            # the first kernel with its K axis in the K-block order (branch, pixel, channel) instead of Keras' (pixel, branch, channel)
+            w1 = self._tail_pack[0][0]
+            K = int(w1.shape[1])
+            # ... and blocked like the features: [K/64][out][64]
+            self._w1_kblock = (w1.view(w1.shape[0], K // 96, 3, 32).permute(0, 2, 1, 3).reshape(w1.shape[0], K // 64, 64)
+                               .permute(1, 0, 2).contiguous() if K % 192 == 0 else None)
         return self._tail_pack
 
-    def dense_tail(self, fv):
-        """Dense 64 relu, Dense 64 relu, Dense n softmax (dnn.py:78-88) on bf16 feature rows: the arithmetic of the autocast
-        region it replaces (bf16 operands, float32 accumulation, bf16 activations), without its per-call casts."""
+    def dense_tail(self, fv, fused=True, kblock=False):
+        """Dense 64 relu, Dense 64 relu, Dense n softmax (dnn.py:78-88) on bf16 feature rows.  ``fused`` (default, CUDA bf16 rows
+        with K % 64 == 0, two hidden layers of 64 units, <= 16 classes): csrc/dense.hip -- the first layer as a split-K bf16 GEMM
+        that streams the rows once, the small layers and the softmax in float32 in one finishing kernel.  Otherwise the
+        arithmetic of the autocast region (hipBLASLt through PyTorch: bf16 operands, float32 accumulation, bf16 activations)
+        without its per-call casts.  ``kblock=True``: ``fv`` is the (K/64, N, 64) tensor of ``features_fused(layout="kblock")`` --
+        a 128-sample tile of a K-step is then 16 KB of contiguous memory instead of 128 pieces 76.8 KB apart."""
         import torch
         import torch.nn.functional as F
         (w1, b1), (w2, b2), (w3, b3) = self._tail_weights()
+        if kblock:
+            # (K/64, N, 64) features of features_fused(layout="kblock")
+            if not (fused and fv.is_cuda and fv.dtype == torch.bfloat16 and fv.ndim == 3 and fv.shape[2] == 64 and fv.is_contiguous()
+                    and self._w1_kblock is not None and int(fv.shape[0]) == int(self._w1_kblock.shape[0])):
+                raise ValueError("dense_tail(kblock=True): contiguous CUDA bfloat16 (K/64, N, 64) features expected")
+            K, n, ld = int(fv.shape[0]) * 64, int(fv.shape[1]), 0
+            w1 = self._w1_kblock
+        else:
+            K, n, ld = (int(fv.shape[1]), int(fv.shape[0]), int(fv.stride(0))) if fv.ndim == 2 else (0, 0, 0)
+        if kblock or (fused and fv.is_cuda and fv.dtype == torch.bfloat16 and fv.ndim == 2 and K % 64 == 0 and fv.stride(1) == 1
+                      and fv.stride(0) % 8 == 0 and fv.data_ptr() % 16 == 0
+                      and tuple(self.fc2.weight.shape) == (64, 64) and self.fc1.weight.shape[0] == 64 and self.n_classes <= 16):
+            from . import _lib
+            lib = _lib.load()
+            dev = fv.device
+            out = torch.empty((n, self.n_classes), dtype=torch.float32, device=dev)
+            if n == 0:
+                return out
+            bb1, w2t, bb2, w3f, bb3 = self._tail_f32
+            ctx = _lib.context(dev)
+            nbytes = int(lib.rml_dnn_dense_workspace_bytes(ctx, n, K))
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rml_dnn_dense_tail(ctx, _lib.ptr(fv), ld, 1 if kblock else 0, n, K, _lib.ptr(w1), _lib.ptr(bb1), _lib.ptr(w2t),
+                                                  _lib.ptr(bb2), _lib.ptr(w3f), _lib.ptr(bb3), self.n_classes, _lib.ptr(ws), nbytes,
+                                                  _lib.ptr(out), _lib.stream_ptr(dev)), "rml_dnn_dense_tail")
+            return out
         h = F.relu(F.linear(fv, w1, b1))
         h = F.relu(F.linear(h, w2, b2))
         lg = F.linear(h, w3, b3)
         return torch.softmax(lg.float(), dim=-1)
 
-    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=False, trunk_events=None):
+    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=False, trunk_events=None,
+                        exact_resize=False):
         """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
-        projections (csrc/project.hip) -> [-1,1] scaling + Pillow bicubic resize (csrc/resize.hip, bf16 out) -> fused
-        conv trunk (csrc/dnn.hip) -> dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor.
+        projections as uint8 code rows (csrc/project*.hip) -> [-1,1] scaling + bicubic resize of the three projections in one
+        launch, bf16 out (csrc/preprocess.hip: Pillow's windows and weights in float32) -> fused conv trunk (csrc/dnn.hip) ->
+        dense tail: class probabilities (N, n_classes) as a float32 CUDA tensor.  ``exact_resize=True`` (and shapes the fused
+        preprocessing does not take) runs the round-1..3 chain instead: float32 feature rows and the Pillow-bit-identical
+        float64 resize (csrc/resize.hip), one launch per projection -- the same values before the bf16 rounding to ~1e-6.
 
         ``overlap`` (off): the projection of batch b+2 on a second stream beside the resize of batch b+1, the trunk (a whole CU's
         LDS) and the dense tail (hipBLASLt: 135 KB of LDS) alone between two projection launches.  Measured in round 4 (three
@@ -244,10 +307,14 @@ class Classifier(_module_base()):
         with torch.no_grad(), torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if not overlap:
+                fused = not exact_resize and nn_common.preprocess_supported((X, Y, Z), rescale)
                 for b in range(nb):
                     s0, s1 = b * bs, min(n, (b + 1) * bs)
-                    feat = common.process_volumes(volumes[s0:s1], mode=mode, scale=False)
-                    xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
+                    if fused:
+                        xs = nn_common.preprocess_volumes(volumes[s0:s1], rescale, mode=mode)
+                    else:
+                        feat = common.process_volumes(volumes[s0:s1], mode=mode, scale=False)
+                        xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
                     out[s0:s1] = self._forward_timed(xs, trunk_events)
                 return out
             lib = _lib.load()
@@ -299,19 +366,20 @@ class Classifier(_module_base()):
             cur.wait_stream(sp)
         return out
 
-    def _features_timed(self, xs, trunk_events):
+    def _features_timed(self, xs, trunk_events, layout="nhwc"):
         import torch
         if trunk_events is None:
-            return self.features_fused(*xs)
+            return self.features_fused(*xs, layout=layout)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fv = self.features_fused(*xs)
+        fv = self.features_fused(*xs, layout=layout)
         e1.record()
-        trunk_events.append((e0, e1, int(fv.shape[0])))
+        trunk_events.append((e0, e1, int(xs[0].shape[0])))
         return fv
 
     def _forward_timed(self, xs, trunk_events):
-        return self.dense_tail(self._features_timed(xs, trunk_events))
+        kb = self.kblock_supported(int(xs[0].shape[-2]), int(xs[0].shape[-1]))
+        return self.dense_tail(self._features_timed(xs, trunk_events, "kblock" if kb else "nhwc"), kblock=kb)
 
     def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""

@@ -115,6 +115,68 @@ def preprocess_features(feat, grid, rescale, out_dtype="bfloat16"):
     return outs
 
 
+def preprocess_supported(grid, rescale):
+    """True when the fused preprocessing kernel (csrc/preprocess.hip) takes this (X, Y, Z) grid and (width, height) target."""
+    from . import _lib
+    X, Y, Z = (int(v) for v in grid)
+    return bool(_lib.load().rml_dnn_preprocess_supported(X, Y, Z, int(rescale[1]), int(rescale[0])))
+
+
+def preprocess_rows(grid, rescale, feat=None, codes=None, flags=None):
+    """The CNN preprocessing of dnn.py:200-254 for the bf16 conv trunk in ONE launch (csrc/preprocess.hip): float32 feature rows
+    [xz | yz | xy] (``feat``) and / or the biased uint8 code rows of ``process_volumes(codes=...)`` (``codes``; with both,
+    ``flags[b] != 0`` selects the code row) -> (xz, yz, xy) as (N, H, W) bfloat16.  Pillow's windows and weights applied in
+    float32: within one bf16 ulp of ``resize_bicubic(..., out_dtype='bfloat16')`` (the Pillow-exact kernel), not bit-identical."""
+    torch = _torch()
+    from . import _lib
+    lib = _lib.load()
+    X, Y, Z = (int(v) for v in grid)
+    src = feat if feat is not None else codes
+    if src is None:
+        raise ValueError("preprocess_rows: feat and / or codes expected")
+    n, dev = int(src.shape[0]), src.device
+    oh, ow = int(rescale[1]), int(rescale[0])
+    outs = [torch.empty((n, oh, ow), dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_dnn_preprocess_rows(_lib.context(dev), _lib.ptr(feat), int(feat.stride(0)) if feat is not None else 0,
+                                               _lib.ptr(codes), int(codes.stride(0)) if codes is not None else 0, _lib.ptr(flags),
+                                               n, X, Y, Z, oh, ow, _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
+                                               _lib.stream_ptr(dev)), "rml_dnn_preprocess_rows")
+    return outs
+
+
+def preprocess_volumes(volumes, rescale, mode="max", ijk=None):
+    """(N, X, Y, Z) volumes (float32 or uint8, CUDA) -> the trunk's three bf16 inputs (N, H, W): projection into uint8 code rows
+    (no float rows through HBM when the projections are integers 0..255 -- radar magnitudes, common.py:30-31; rows that are not
+    take a device-predicated float pass), then the fused scaling + bicubic resize (``rml_dnn_preprocess_volumes``)."""
+    torch = _torch()
+    from . import _lib, common
+    lib = _lib.load()
+    v, vdt = common._as_device_volumes(volumes)
+    n, X, Y, Z = (int(t) for t in v.shape)
+    dev = v.device
+    m = _lib.MODES[mode]
+    ijk_t = None
+    if m == _lib.MODE_SLICE:
+        if ijk is None:
+            raise ValueError("preprocess_volumes: mode='slice' needs ijk")
+        ijk_t, T = common._slice_indices(ijk, n, X, Y, Z, dev)
+        if T != 1:
+            raise ValueError("preprocess_volumes: one (i,j,k) per frame")
+    D = common.feature_len(X, Y, Z)
+    ldq = (D + 127) // 128 * 128
+    oh, ow = int(rescale[1]), int(rescale[0])
+    codes = torch.empty((n, ldq), dtype=torch.uint8, device=dev)
+    flags = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+    rows = torch.empty((n, D), dtype=torch.float32, device=dev) if vdt == _lib.VOL_F32 else None
+    outs = [torch.empty((n, oh, ow), dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    with torch.cuda.device(dev):
+        _lib.check(lib.rml_dnn_preprocess_volumes(_lib.context(dev), _lib.ptr(v), vdt, n, X, Y, Z, m, _lib.ptr(ijk_t), _lib.ptr(codes), ldq,
+                                                  _lib.ptr(flags), _lib.ptr(rows), D, oh, ow, _lib.ptr(outs[0]), _lib.ptr(outs[1]),
+                                                  _lib.ptr(outs[2]), _lib.stream_ptr(dev)), "rml_dnn_preprocess_volumes")
+    return outs
+
+
 def _bn_lrelu_pad_function():
     """torch.autograd.Function around csrc/bnact.hip (built lazily: torch is imported on first use)."""
     torch = _torch()

@@ -312,6 +312,164 @@ def test_resize_random_shapes_property(rml):
     check()
 
 
+@pytest.mark.parametrize("n", [1, 127, 129, 1000, 2500])
+def test_fused_dense_tail_vs_float64(rml, n):
+    """csrc/dense.hip (split-K bf16 GEMM for Dense 64 + the two small layers and the softmax in float32, dnn.py:78-88) against the
+    same layers in float64 on the very bf16 operands (feature rows and first kernel as the matrix cores see them): what is left is
+    float32 accumulation order, far below the 1e-3 the bf16 chain is held to; the hipBLASLt tail it replaces (bf16 activations
+    between the layers) sits further away from the float64 result than the fused one."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    torch.manual_seed(n)
+    for n_classes in (3, 5):
+        model = dnn.define_classifier(n_classes=n_classes, device="cuda").eval()
+        with torch.no_grad():
+            model.fc1.bias.uniform_(-0.1, 0.1); model.fc2.bias.uniform_(-0.1, 0.1); model.fc3.bias.uniform_(-0.1, 0.1)
+            fv = torch.relu(torch.randn((n, 38400), device="cuda")).to(torch.bfloat16)      # conv features are relu outputs
+            got = model.dense_tail(fv)
+            old = model.dense_tail(fv, fused=False)
+            w1 = model.fc1.weight.to(torch.bfloat16).double()
+            h = torch.relu(fv.double() @ w1.t() + model.fc1.bias.double())
+            h = torch.relu(h @ model.fc2.weight.double().t() + model.fc2.bias.double())
+            want = torch.softmax(h @ model.fc3.weight.double().t() + model.fc3.bias.double(), dim=-1)
+        assert got.shape == (n, n_classes) and got.dtype == torch.float32
+        e_new, e_old = float((got.double() - want).abs().max()), float((old.double() - want).abs().max())
+        print("dense tail n=%d C=%d: fused |dp| = %.2e, hipBLASLt bf16 chain |dp| = %.2e" % (n, n_classes, e_new, e_old))
+        assert e_new < 2e-5
+        assert torch.allclose(got.sum(1), torch.ones(n, device="cuda"), atol=1e-5)
+        assert torch.equal(got, model.dense_tail(fv))                       # deterministic (fixed split order)
+
+
+def test_kblock_feature_layout_and_tail(rml):
+    """features_fused(layout="kblock") holds the very values of the Keras-order rows at [(branch * P + pixel) // 2][sample]
+    [(pixel & 1) * 32 + channel]; dense_tail on either layout gives the same probabilities (other summation order: 1e-6)."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    torch.manual_seed(5)
+    model = dnn.define_classifier(device="cuda").eval()
+    for n in (1, 130, 777):
+        xs = [torch.rand((n, 80, 80), device="cuda").mul(2).sub(1).to(torch.bfloat16) for _ in range(3)]
+        with torch.no_grad():
+            rows = model.features_fused(*xs)
+            kb = model.features_fused(*xs, layout="kblock")
+            assert kb.shape == (600, n, 64)
+            want = rows.view(n, 400, 3, 32).permute(2, 1, 0, 3).reshape(3 * 400 // 2, 2, n, 32).permute(0, 2, 1, 3).reshape(600, n, 64)
+            assert torch.equal(kb, want)
+            pa, pb = model.dense_tail(rows), model.dense_tail(kb, kblock=True)
+            assert float((pa - pb).abs().max()) < 1e-5
+            assert torch.equal(pb, model.forward_fused(*xs))
+
+
+def _bf16_ulps(a, b, floor=2e-6):
+    """distance of two bf16 tensors in units of the last place (bf16 is sign-magnitude: map the bit patterns to a monotone scale);
+    values that differ by less than ``floor`` in absolute terms count as equal -- next to zero a float32 rounding error of 1e-6 is
+    many bf16 'ulps' of a number that small and says nothing"""
+    def key(t):
+        i = t.view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7FFF), i)
+    d = (key(a) - key(b)).abs()
+    return torch.where((a.float() - b.float()).abs() <= floor, torch.zeros_like(d), d)
+
+
+@pytest.mark.parametrize("grid,rescale", [((22, 31, 176), (80, 80)), ((64, 64, 128), (80, 80)), ((16, 24, 48), (64, 32)),
+                                          ((5, 7, 16), (16, 12)), ((40, 40, 80), (80, 80)), ((30, 12, 256), (128, 128))])
+def test_fused_preprocessing_tracks_the_pillow_exact_resize(rml, grid, rescale):
+    """csrc/preprocess.hip (one launch: [-1,1] scaling + bicubic resize of the three projections, float32 arithmetic, bf16 out)
+    against the Pillow-bit-identical kernel rounded to bf16: the float32 value is within ~1e-6 of the exact one, so the bf16 results
+    may differ by ONE ulp where the exact value sits at a rounding boundary -- never more, and on well under 1 % of the pixels.
+    Code rows, float rows and the mixed call (flags) give the same bits on integer data; rows off the code grid take the float path."""
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    X, Y, Z = grid
+    assert nc.preprocess_supported(grid, rescale)
+    rng = np.random.default_rng(X * 1000 + Z)
+    B = 37
+    D = X * Z + Y * Z + X * Y
+    feat = torch.from_numpy(rng.integers(0, 256, (B, D)).astype(np.float32)).cuda()
+    feat[3] = 0.0
+    feat[4] = 255.0
+    want = nc.preprocess_features(feat, grid, rescale, out_dtype="bfloat16")
+    want32 = nc.preprocess_features(feat, grid, rescale, out_dtype="float32")
+    ldq = (D + 127) // 128 * 128
+    codes = torch.full((B, ldq), 0x55, dtype=torch.uint8, device="cuda")          # pad columns: anything
+    codes[:, :D] = feat.to(torch.uint8) ^ 0x80
+    got_c = nc.preprocess_rows(grid, rescale, codes=codes)
+    got_f = nc.preprocess_rows(grid, rescale, feat=feat)
+    flags = torch.from_numpy((rng.random(B) < 0.5).astype(np.int32)).cuda()
+    got_m = nc.preprocess_rows(grid, rescale, feat=feat, codes=codes, flags=flags)
+    worst, frac = 0, 0.0
+    for pl in range(3):
+        assert got_c[pl].shape == want[pl].shape and got_c[pl].dtype == torch.bfloat16
+        assert torch.equal(got_c[pl], got_f[pl]), "code rows and float rows of the same integers: same bits"
+        assert torch.equal(got_c[pl], got_m[pl])
+        d = _bf16_ulps(got_c[pl], want[pl])
+        worst = max(worst, int(d.max()))
+        frac = max(frac, float((d != 0).float().mean()))
+        assert float((got_c[pl].float() - want32[pl]).abs().max()) <= 2.0 ** -8     # half a bf16 ulp at |v| <= 1, plus the 1e-6
+    print("fused preprocessing %s -> %s: worst %d bf16 ulp, %.4f %% of the pixels differ from the Pillow-exact kernel" % (grid, rescale, worst, 100 * frac))
+    assert worst <= 1 and frac < 0.01
+    # rows off the code grid: flag 0 -> the float row is used (the code row of such a row is not its value)
+    feat2 = feat.clone()
+    feat2[::2] += torch.from_numpy(rng.uniform(0.1, 0.9, (feat2[::2].shape[0], D)).astype(np.float32)).cuda()
+    flags2 = torch.ones(B, dtype=torch.int32, device="cuda")
+    flags2[::2] = 0
+    want2 = nc.preprocess_features(feat2, grid, rescale, out_dtype="bfloat16")
+    got2 = nc.preprocess_rows(grid, rescale, feat=feat2, codes=codes, flags=flags2)
+    for pl in range(3):
+        d = _bf16_ulps(got2[pl], want2[pl])
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.01
+
+
+def test_fused_preprocessing_from_volumes(rml):
+    """rml_dnn_preprocess_volumes: volumes -> code rows (+ device-predicated float pass) -> the trunk's inputs.  uint8 and float32
+    ingest of the same integers: same bits; volumes with non-integer returns: every row through the float pass, still within one
+    bf16 ulp of the Pillow-exact chain; the batch with ONE such frame: that frame through the float pass, the others through codes."""
+    import oracle_np as O
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    import radar_ml_amd as rml_
+    grid, rescale = (22, 31, 176), (80, 80)
+    vol, _ = O.synth_volumes(5, 300, *grid)
+    v = torch.from_numpy(vol).cuda()
+    feat = rml_.process_volumes(v, mode="max", scale=False)
+    want = nc.preprocess_features(feat, grid, rescale, out_dtype="bfloat16")
+    got = nc.preprocess_volumes(v, rescale)
+    got8 = nc.preprocess_volumes(v.to(torch.uint8), rescale)
+    for pl in range(3):
+        assert torch.equal(got[pl], got8[pl])
+        d = _bf16_ulps(got[pl], want[pl])
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.01
+    for frames in (slice(0, 300), slice(17, 18)):
+        v2 = v.clone()
+        v2[frames] *= 0.731                                     # returns that are no integers: off the code grid
+        feat2 = rml_.process_volumes(v2, mode="max", scale=False)
+        want2 = nc.preprocess_features(feat2, grid, rescale, out_dtype="bfloat16")
+        got2 = nc.preprocess_volumes(v2, rescale)
+        for pl in range(3):
+            d = _bf16_ulps(got2[pl], want2[pl])
+            assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.01
+    # slices at given voxels take the same route
+    ijk = np.stack([np.arange(300) % 22, np.arange(300) % 31, np.arange(300) % 176], axis=1).astype(np.int32)
+    feat3 = rml_.process_volumes(v, mode="slice", ijk=ijk, scale=False)
+    want3 = nc.preprocess_features(feat3, grid, rescale, out_dtype="bfloat16")
+    got3 = nc.preprocess_volumes(v, rescale, mode="slice", ijk=ijk)
+    for pl in range(3):
+        assert int(_bf16_ulps(got3[pl], want3[pl]).max()) <= 1
+
+
+def test_predict_volumes_fused_and_exact_preprocessing_agree(rml):
+    """Classifier.predict_volumes with the fused float32 preprocessing (default) against exact_resize=True (float rows, the
+    Pillow-bit-identical float64 resize): the probabilities move by far less than the bf16 tolerance of the chain."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    import oracle_np as O
+    torch.manual_seed(3)
+    model = dnn.define_classifier(device="cuda").eval()
+    vol, _ = O.synth_volumes(12, 700, 22, 31, 176)
+    v = torch.from_numpy(vol).cuda()
+    a = model.predict_volumes(v, batch_size=256)
+    b = model.predict_volumes(v, batch_size=256, exact_resize=True)
+    c = model.predict_volumes(v.to(torch.uint8), batch_size=512)
+    print("predict_volumes fused vs exact preprocessing: max |dp| = %.2e" % float((a - b).abs().max()))
+    assert float((a - b).abs().max()) < 2e-4
+    assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape,pad", [((6, 128, 64, 64), 1), ((5, 64, 32, 32), 1), ((7, 32, 16, 16), 0), ((3, 8, 6, 10), 1)])
 def test_fused_bn_lrelu_pad_matches_torch(rml, dtype, shape, pad):
