@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
     };
     constexpr int PPT = NG == 1 ? 2 : 1;                // planes per trip; whole-plane buffers need an even X
     Emitter em(a, cf);
+    extern __shared__ __align__(16) unsigned char wave_dyn[];      // codes-only launches: the wave's code stage (see Emitter::stage)
+    if (a.stage_bytes) em.set_stage(wave_dyn + wave * a.stage_bytes, (X * Zr + 15) & ~15);
     fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
     for (; cf < a.B; cf += stride) {
         em.reset(cf);
@@ -383,25 +385,28 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
             constexpr int j = decltype(jc)::value;
             if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j]);
         });
+        em.flush_wave(lane_f);
         em.finish_wave(lane_f);
     }
 }
 
 template <typename VT, int MODE, int NY, int G>
-void launch_wave(const ProjParams& pp, int num_cu, hipStream_t st) {
+void launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
+    ProjParams pp = pp_in;
     constexpr int per_cu_max = (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2;
+    const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
+    pp.stage_bytes = code_stage_bytes(pp, sizeof(VT));
+    const size_t stage = (size_t)4 * pp.stage_bytes;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
-    const int per_cu = env && atoi(env) >= 1 && atoi(env) <= per_cu_max ? atoi(env) : (pp.o.share_cu ? 1 : per_cu_max);
+    int per_cu = env && atoi(env) >= 1 && atoi(env) <= per_cu_max ? atoi(env) : (pp.o.share_cu ? 1 : per_cu_max);
+    if (per_cu * (mine + stage) > 160 * 1024) per_cu = 1;      // (measured: one or two of these workgroups per CU stream equally fast)
     const int64_t want = (pp.B + 3) / 4;
     const int64_t cap = (int64_t)num_cu * per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
     // beside a GEMM: the request is padded past half of the CU's LDS, so that the dispatcher cannot put two of these
     // persistent workgroups on one CU (and none on another) while GEMM workgroups (69.6 KB) still fit next to one
-    size_t pad = 0;
-    if (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad) {
-        const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
-        pad = mine < 81 * 1024 ? 81 * 1024 - mine : 0;
-    }
+    size_t pad = stage;
+    if (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine + stage < 81 * 1024) pad = 81 * 1024 - mine;
     if (pp.o.skip_if_set) {
         RML_MAX_DYN_LDS(96 * 1024, &k_project_wave<VT, MODE, NY, G, true>);
         hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, pad, st, pp);
@@ -678,7 +683,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
 
 void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
     pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.rpl = 1; pp.o = o;
-    pp.ntgt = 1; pp.ijk_out = nullptr; pp.profiles = nullptr; pp.wave_lds = 0;
+    pp.ntgt = 1; pp.ijk_out = nullptr; pp.profiles = nullptr; pp.wave_lds = 0; pp.stage_bytes = 0;
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
 }

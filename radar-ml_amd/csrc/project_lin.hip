@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
         });
     };
     Emitter em(a, cf);
+    if (a.stage_bytes) {                                // codes-only launches: the wave's code stage behind the images (Emitter::stage)
+        em.set_stage(lin_smem + (size_t)4 * (NI * 64 * sizeof(float4) + NT * 64 * sizeof(float)) + wave * a.stage_bytes, (X * Z + 15) & ~15);
+    }
     fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
     for (; cf < a.B; cf += stride) {
         em.reset(cf);
@@ -150,27 +153,31 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
             const int q = t * 64 + lane_f;
             if (q < pq_f) em.put4(1, (int64_t)q * 4, yz[t]);
         });
+        em.flush_wave(lane_f);
         em.finish_wave(lane_f);
     }
 }
 
 template <int MODE, int ZQ4, int NI, int RG, int NGRP, int NMASK>
-void launch_lin(const ProjParams& pp, int num_cu, hipStream_t st) {
+void launch_lin(const ProjParams& pp_in, int num_cu, hipStream_t st) {
+    ProjParams pp = pp_in;
+    pp.stage_bytes = code_stage_bytes(pp, 4);
+    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) (44 quads: 66 KB) + the code stage of a codes-only launch (4 x 4.6 KB
+    // at the Walabot grid).  Beside a GEMM (share_cu = 1) the request is padded past half of the CU's LDS so that the dispatcher cannot
+    // put two of these persistent workgroups on one CU (see launch_wave)
+    const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4) + (size_t)4 * pp.stage_bytes;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
-    const int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
+    int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
+    if (per_cu * mine > 160 * 1024) per_cu = 1;         // (measured: one or two of these workgroups per CU stream equally fast)
     const int64_t want = (pp.B + 3) / 4;
     const int64_t cap = (int64_t)num_cu * per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
-    // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) (44 quads: 66 KB).  Beside a GEMM (share_cu = 1) the request is
-    // padded past half of the CU's LDS so that the dispatcher cannot put two of these persistent workgroups on one CU (see
-    // launch_wave)
-    const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
     const size_t lds = (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 81 * 1024) ? 81 * 1024 : mine;
     if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>);
+        RML_MAX_DYN_LDS(112 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>);
         hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>), grid, block, lds, st, pp);
     } else {
-        RML_MAX_DYN_LDS(96 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>);
+        RML_MAX_DYN_LDS(112 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>);
         hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>), grid, block, lds, st, pp);
     }
 }

@@ -24,6 +24,9 @@ struct ProjParams {
     int32_t* ijk_out;
     float* profiles;
     int wave_lds;
+    // wave-per-frame kernels, codes-only launches: bytes of wave-private LDS in which the codes of the per-plane outputs (xz, xy) wait
+    // for the frame's end (Emitter::stage); 0 = every plane's codes go to memory as they are finished
+    int stage_bytes;
 };
 
 template <int MODE> struct Op;
@@ -66,6 +69,20 @@ struct Emitter {
     int ok = 1;
     double nsq = 0.0;
     bool want_stats;
+    // Codes-only launches of the wave-per-frame kernels: a frame's xz and xy codes are finished plane by plane -- a 176-byte and a
+    // 31-byte store per 21.8 KB plane at the Walabot grid, from each of 2 048 waves -- and those small writes, scattered in time
+    // between the reads, cost the streaming kernels far more than their bytes (stand-alone, Walabot grid: 0.70 of 8 TB/s with them,
+    // 0.73 without, 0.81 with no output at all; the LDS work, the VALU work and the number of resident waves change nothing:
+    // tools/exp/README.md, round 4).  With `stage` set they wait in a wave-private LDS row [xz | xy] and leave as one burst of
+    // 16-byte stores at the frame's end (flush_wave).
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 lds_u128;
+    lds_u8* stage = nullptr;    // an LDS pointer, and a separate flag: a null test on a generic pointer into LDS does not compile here
+    int staged = 0;
+    int stage_xy = 0;           // byte offset of the xy codes in the stage
+    __device__ __forceinline__ void set_stage(unsigned char* p, int xy_off) { stage = (lds_u8*)p; staged = 1; stage_xy = xy_off; }
 
     __device__ Emitter(const ProjParams& a_, int64_t b_) : a(a_), b(b_) {
         want_stats = a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.q[0] || a.o.q[1] || a.o.q[2];
@@ -97,7 +114,10 @@ struct Emitter {
         if (a.o.row_nsq) { double t = (double)scaled(v); nsq += t * t; }
         if (want_stats) {
             uint32_t c = code(v);
-            if (a.o.q[pl]) a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)c;
+            if (a.o.q[pl]) {
+                if (staged && pl != 1) stage[(pl == 2 ? stage_xy : 0) + idx] = (uint8_t)c;
+                else a.o.q[pl][b * a.o.qstride + idx] = (uint8_t)c;
+            }
         }
     }
     // four projection values that ARE bytes (uint8 volumes; idx a multiple of 4): when only codes and their statistics are
@@ -134,12 +154,34 @@ struct Emitter {
             uint32_t c0 = code(v.x), c1 = code(v.y), c2 = code(v.z), c3 = code(v.w);
             if (a.o.q[pl]) {
                 uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-                *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
+                if (staged && pl != 1) *(lds_u32*)(stage + (pl == 2 ? stage_xy : 0) + idx) = packed;
+                else *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
             }
         }
     }
     // next frame of a persistent kernel
     __device__ __forceinline__ void reset(int64_t b_) { b = b_; isum = 0; isq = 0; ok = 1; nsq = 0.0; }
+    // the staged xz / xy codes of frame b -> the code row, 16 bytes per lane and store where the row allows it (one wave: the DS unit
+    // runs its instructions in order; the fences only keep the compiler from moving an access across the hand-over)
+    __device__ void flush_wave(int lane) {
+        if (!staged) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int len[2] = {a.X * a.Z, a.X * a.Y};
+        lds_u8* src[2] = {stage, stage + stage_xy};
+        uint8_t* dst[2] = {a.o.q[0] + b * a.o.qstride, a.o.q[2] + b * a.o.qstride};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int done = 0;
+            if ((reinterpret_cast<uintptr_t>(dst[r]) & 15) == 0) {
+                for (int i = lane; i < (len[r] >> 4); i += 64) reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
+                done = len[r] & ~15;
+            }
+            for (int i = done + 4 * lane; i + 4 <= len[r]; i += 256)       // rows are 4-byte aligned (rml_project's contract)
+                *reinterpret_cast<uint32_t*>(dst[r] + i) = *(lds_u32*)(src[r] + i);
+            for (int i = (len[r] & ~3) + lane; i < len[r]; i += 64) dst[r][i] = src[r][i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     // the same as finish() for kernels in which ONE WAVE owns the frame: no LDS, no barrier
     __device__ void finish_wave(int lane) {
         if (a.o.qrow) {
@@ -282,6 +324,16 @@ template <int MODE> __device__ __forceinline__ float op_raw(float a, float b) {
 }
 template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b) {
     return make_float4(op_raw<MODE>(a.x, b.x), op_raw<MODE>(a.y, b.y), op_raw<MODE>(a.z, b.z), op_raw<MODE>(a.w, b.w));
+}
+
+// bytes of per-wave LDS code stage for a launch of a wave-per-frame kernel (0: not a codes-only launch, or RML_STAGE_CODES=0)
+inline int code_stage_bytes(const ProjParams& pp, size_t voxel_bytes) {
+    const ProjOut& o = pp.o;
+    if (voxel_bytes != 4 || o.p[0] || o.p[1] || o.p[2] || o.row_nsq || !o.q[0] || !o.q[2] || o.skip_if_set) return 0;
+    const char* env = getenv("RML_STAGE_CODES");
+    if (env && atoi(env) == 0) return 0;
+    const int bytes = ((pp.X * pp.Z + 15) & ~15) + ((pp.X * pp.Y + 15) & ~15);
+    return bytes <= 16 * 1024 ? bytes : 0;
 }
 
 // project_lin.hip: the linear-plane wave-per-frame kernel for rows that do not fill a load instruction (32 < Z/4 < 64); returns

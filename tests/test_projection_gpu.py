@@ -416,6 +416,57 @@ def test_uint8_byte_kernel_lane_layouts_and_codes_only_output(rml, shape):
     np.testing.assert_array_equal(isq.cpu().numpy(), (codes * codes).sum(axis=1))
 
 
+@pytest.mark.parametrize("shape,share", [((22, 31, 176), 0), ((22, 31, 176), 1), ((22, 31, 160), 0), ((16, 24, 224), 0), ((64, 64, 128), 1),
+                                         ((22, 31, 180), 0), ((9, 20, 256), 0), ((32, 32, 64), 1)])
+def test_codes_only_pass_with_the_code_stage(rml, shape, share, monkeypatch):
+    """The fused pipelines' first pass on float32 volumes (codes + statistics, no float rows) through the wave-per-frame kernels:
+    the xz / xy codes wait in a wave-private LDS stage and leave in one burst per frame (Emitter::stage / flush_wave).  Bit for bit
+    NumPy's projections as codes, the statistics, the flags (a frame with a non-integer return is flagged, its codes are whatever),
+    and the same bytes as with RML_STAGE_CODES=0; rows that start 4 (not 16) bytes aligned take the dword path of the flush."""
+    import torch
+    from radar_ml_amd import _lib
+    X, Y, Z = shape
+    if share:
+        monkeypatch.setenv("RML_WAVE_SHARE", "1")       # the pipeline's configuration: k_project_wave also for rows of 16 / 32 quads
+    rng = np.random.default_rng(X * 131 + Z)
+    B = 2 * 256 + 77                                    # persistent kernels take batches of >= 2 frames per CU
+    vf = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
+    vf[3][rng.random((X, Y, Z)) < 0.9] = 0.0
+    vf[5] = 255.0
+    vf[7, X // 2, Y // 2, Z // 2] = 254.5               # off the code grid (and a maximum of its lines)
+    vf[7, X // 2, Y // 2] = np.maximum(vf[7, X // 2, Y // 2], 0.0)
+    want = [np.max(vf, axis=2), np.max(vf, axis=1), np.max(vf, axis=3)]
+    rows = np.concatenate([w.reshape(B, -1) for w in want], axis=1)
+    D = rows.shape[1]
+    dev = torch.device("cuda", 0)
+    lib = _lib.load(); ctx = _lib.context(dev)
+    V = torch.from_numpy(vf).to(dev)
+    ldq = (D + 127) // 128 * 128
+    st = torch.cuda.current_stream(dev).cuda_stream
+    outs = {}
+    for knob, off in (("1", 0), ("0", 0), ("1", 4)):
+        monkeypatch.setenv("RML_STAGE_CODES", knob)
+        buf = torch.full((B * ldq + 16,), 7, dtype=torch.uint8, device=dev)
+        q = buf[off:off + B * ldq].view(B, ldq)
+        isum = torch.empty(B, dtype=torch.int32, device=dev); isq = torch.empty(B, dtype=torch.int64, device=dev)
+        flags = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.rml_project(ctx, V.data_ptr(), 0, B, X, Y, Z, 0, None, 255.0, 7, None, 0, q.data_ptr(), ldq,
+                                   isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st), "rml_project")
+        torch.cuda.synchronize()
+        outs[(knob, off)] = (q.clone(), isum.clone(), isq.clone(), flags.clone())
+    q, isum, isq, flags = outs[("1", 0)]
+    good = np.ones(B, bool); good[7] = False
+    assert flags.cpu().numpy().tolist() == good.astype(np.int32).tolist()
+    codes = (q[:, :D].cpu().numpy() ^ 0x80).astype(np.int64)
+    np.testing.assert_array_equal(codes[good], rows[good].astype(np.int64))
+    np.testing.assert_array_equal(isum.cpu().numpy()[good], codes[good].sum(axis=1))
+    np.testing.assert_array_equal(isq.cpu().numpy()[good], (codes[good] * codes[good]).sum(axis=1))
+    assert int(q[:, D:].to(torch.int32).sum()) == 0
+    for key in (("0", 0), ("1", 4)):
+        for a_, b_ in zip(outs[("1", 0)], outs[key]):
+            assert torch.equal(a_, b_), key
+
+
 def test_uint8_random_shapes_property(rml):
     """Property test for the uint8 ingest over random grids (byte-native kernel when Z % 16 == 0, widening kernels
     otherwise; 1..8 rows per lane): max / sum / slice projections and the code rows equal NumPy's on the same values."""
