@@ -630,9 +630,11 @@ def _top2_margin(p):
 
 
 def run_dnn(a, env):
-    """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection (csrc/project.hip) ->
-    [-1,1] scaling + Pillow-exact bicubic resize to 80x80 (csrc/resize.hip) -> fused conv trunk (csrc/dnn.hip) -> dense
-    tail (hipBLASLt through PyTorch), bf16, random-init weights of the reference's architecture (dnn.py:45-91).
+    """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection into uint8 code rows (csrc/project_lin.hip;
+    a device-predicated float pass for frames off the code grid) -> [-1,1] scaling + bicubic resize to 80x80 of the three projections
+    in one launch (csrc/preprocess.hip: Pillow's windows and weights in float32, bf16 out) -> fused conv trunk (csrc/dnn.hip) ->
+    fused dense tail (csrc/dense.hip), bf16 operands, random-init weights of the reference's architecture (dnn.py:45-91).  The
+    parity leg compares with the float64 NumPy restatement of the reference's chain (Pillow-exact resize included).
     Frames are sharded over the ranks; the predicted labels are all-gathered (RCCL) when N > 1.  Returns the result dict
     on rank 0."""
     import importlib
@@ -674,6 +676,17 @@ def run_dnn(a, env):
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         res[tag] = (float(dt.item()), p)
+    # the same frames through the round-1..3 front of the chain (float rows, Pillow-bit-identical float64 resize, one launch per
+    # projection): what the float32 preprocessing kernel is allowed to change is the bf16 rounding of ~3e-4 of the pixels
+    for _ in range(2):
+        pe = model.predict_volumes(V, exact_resize=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pe = model.predict_volumes(V, exact_resize=True)
+    torch.cuda.synchronize(dev)
+    exact_dt = time.perf_counter() - t0
+    exact_dp = float((pe - res["f32"][1]).abs().max())
     if rank != 0:
         return None
     # parity on a few frames: NumPy restatement of the whole chain (oracle projections, Pillow restatement, Keras layers)
@@ -701,6 +714,7 @@ def run_dnn(a, env):
     out = {"metric": "radar frames/s (3D-proj->resize->CNN forward)", "unit": "frames/s", "dtype": "bf16 operands, f32 accumulate",
            "value": round(world * B * a.steps / res["f32"][0], 1), "ms_per_step": round(res["f32"][0] / a.steps * 1e3, 3),
            "value_uint8_volumes": round(world * B * a.steps / res["u8"][0], 1),
+           "pillow_exact_resize_chain": {"value_this_rank": round(B * a.steps / exact_dt, 1), "proba_max_abs_diff_vs_fused_preprocessing": exact_dp},
            "uint8_identical_labels": bool(torch.equal(res["u8"][1].argmax(1), res["f32"][1].argmax(1))),
            "config": {"workload": "configs[3]: %d frames/GPU of %dx%dx%d -> 3 x 80x80 -> multi-view CNN (2.52 M parameters, "
                                   "54.7 MFLOP/frame), random-init weights" % (B, X, Y, Z), "frames_per_gpu": B},

@@ -182,25 +182,48 @@ __global__ __launch_bounds__(256) void k_dense_finish(FinishArgs a) {
     __shared__ float w2s[kHidden * kHidden];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < kHidden * kHidden; i += 256) w2s[i] = a.w2t[i];
-    __syncthreads();
     const float b1 = a.b1[lane], b2 = a.b2[lane];
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t n = (int64_t)blockIdx.x * 4 + (tid >> 6); n < a.N; n += nw) {
-        float h = b1;
-        for (int s = 0; s < a.S; ++s) h += a.partial[((int64_t)s * a.N + n) * kHidden + lane];
-        h = fmaxf(h, 0.0f);
-        float g = b2;
+    float w3l[16], b3l[16];                         // the last layer's kernel column of this lane, the biases
 #pragma unroll
-        for (int k = 0; k < kHidden; ++k)
-            g = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k)), w2s[k * kHidden + lane], g);
-        g = fmaxf(g, 0.0f);
+    for (int c = 0; c < 16; ++c) { w3l[c] = c < a.C ? a.w3[c * kHidden + lane] : 0.0f; b3l[c] = c < a.C ? a.b3[c] : 0.0f; }
+    __syncthreads();
+    // persistent: wave w of the grid takes samples w, w + #waves, ...; the partial sums of the next sample are in flight (16 splits
+    // at most per batch of loads) while this one runs its 64-step layer
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    constexpr int SB = 16;
+    auto gather = [&](int64_t n) -> float {
+        float h = 0.0f;
+        for (int s0 = 0; s0 < a.S; s0 += SB) {
+            float p[SB];
+#pragma unroll
+            for (int s = 0; s < SB; ++s) p[s] = (s0 + s < a.S && n < a.N) ? a.partial[((int64_t)(s0 + s) * a.N + n) * kHidden + lane] : 0.0f;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) h += p[s];     // split order: deterministic
+        }
+        return h;
+    };
+    int64_t n = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    float hn = gather(n);
+    for (; n < a.N; n += nw) {
+        const float h = fmaxf(hn + b1, 0.0f);
+        hn = gather(n + nw);
+        // second layer: lane = output unit; four independent chains over the 64 inputs (each input broadcast with v_readlane)
+        float g0 = b2, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kHidden; k += 4) {
+            g0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k)), w2s[k * kHidden + lane], g0);
+            g1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k + 1)), w2s[(k + 1) * kHidden + lane], g1);
+            g2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k + 2)), w2s[(k + 2) * kHidden + lane], g2);
+            g3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k + 3)), w2s[(k + 3) * kHidden + lane], g3);
+        }
+        const float g = fmaxf((g0 + g1) + (g2 + g3), 0.0f);
         // logits in every lane (C <= 16), softmax in float32 like torch.softmax(lg.float())
         float lg[16];
         float mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             if (c < a.C) {
-                lg[c] = wave_sum(g * a.w3[c * kHidden + lane]) + a.b3[c];
+                lg[c] = wave_sum(g * w3l[c]) + b3l[c];
                 mx = fmaxf(mx, lg[c]);
             }
         }
@@ -263,7 +286,7 @@ extern "C" int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld
     FinishArgs fi{};
     fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
     const int64_t blocks = (N + 3) / 4;
-    hipLaunchKernelGGL(k_dense_finish, dim3((unsigned)(blocks < 8 * ctx->num_cu ? blocks : 8 * ctx->num_cu)), dim3(256), 0, st, fi);
+    hipLaunchKernelGGL(k_dense_finish, dim3((unsigned)(blocks < 2 * ctx->num_cu ? blocks : 2 * ctx->num_cu)), dim3(256), 0, st, fi);
     RML_HIP(hipGetLastError());
     return RML_OK;
 }

@@ -61,9 +61,13 @@ __device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
 
 // Per-thread sink for finished projection values: scaled float store, uint8 code store and
 // the row statistics of the exact-integer SVM path.
+#ifndef RML_EMIT_ABL
+#define RML_EMIT_ABL 0      // experiment builds (timing only): 1 = no code stores, 2 = code rows of all frames land on 64 rows (L2-resident)
+#endif
 struct Emitter {
     const ProjParams& a;
     int64_t b;
+    __device__ __forceinline__ int64_t qb() const { return RML_EMIT_ABL == 2 ? (b & 63) : b; }
     int32_t isum = 0;
     uint32_t isq = 0;       // per THREAD: < 66 000 codes of <= 255^2 each (the launchers keep a thread's share far below that)
     int ok = 1;
@@ -128,7 +132,11 @@ struct Emitter {
         if (want_stats) {
             isum += (int32_t)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
             isq = __builtin_amdgcn_udot4(w, w, isq, false);
-            if (a.o.q[pl]) *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = w ^ 0x80808080u;
+#if RML_EMIT_ABL == 1
+            asm volatile("" :: "v"(w));
+#else
+            if (a.o.q[pl]) *reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx) = w ^ 0x80808080u;
+#endif
         }
     }
     // idx is a multiple of 4
@@ -155,7 +163,11 @@ struct Emitter {
             if (a.o.q[pl]) {
                 uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
                 if (staged && pl != 1) *(lds_u32*)(stage + (pl == 2 ? stage_xy : 0) + idx) = packed;
-                else *reinterpret_cast<uint32_t*>(a.o.q[pl] + b * a.o.qstride + idx) = packed;
+#if RML_EMIT_ABL == 1
+                else asm volatile("" :: "v"(packed));
+#else
+                else *reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx) = packed;
+#endif
             }
         }
     }
@@ -168,7 +180,10 @@ struct Emitter {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int len[2] = {a.X * a.Z, a.X * a.Y};
         lds_u8* src[2] = {stage, stage + stage_xy};
-        uint8_t* dst[2] = {a.o.q[0] + b * a.o.qstride, a.o.q[2] + b * a.o.qstride};
+        uint8_t* dst[2] = {a.o.q[0] + qb() * a.o.qstride, a.o.q[2] + qb() * a.o.qstride};
+#if RML_EMIT_ABL == 1
+        return;
+#endif
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int done = 0;

@@ -974,10 +974,24 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t
 }
 
 // tile_exact[ft] = policy(flags of the 128 rows of tile ft); *all_exact = AND over tiles.
-// One 128-thread block per tile, one row flag per thread.
+// One 128-thread block per tile, one row flag per thread; with all_exact, ONE MORE block that scans every row flag and writes the AND
+// (round 3 pre-set the word with a one-thread kernel and cleared it with atomics: a launch and its gap per chunk on the stream whose
+// chain is the period of the Walabot pipeline).
 // group = sample tiles decided together (2 when the 256-sample GEMM kernel takes the exact tiles): blockDim = group * 128.
 __global__ __launch_bounds__(256) void k_tile_flags(const int32_t* flags, int64_t N, int FT, int policy /*0 auto,1 force general,2 force i8*/,
                                                     int model_exact, int32_t* tile_exact, int32_t* all_exact, int group) {
+    const int tile_blocks = (FT + group - 1) / group;
+    if ((int)blockIdx.x >= tile_blocks) {
+        int mine = 1;
+        if (policy == 1) mine = 0;
+        else if (policy != 2) {
+            if (!(model_exact && flags != nullptr)) mine = 0;
+            else for (int64_t r = threadIdx.x; r < N; r += blockDim.x) mine &= flags[r] != 0;
+        }
+        const int e = __syncthreads_and(mine);
+        if (threadIdx.x == 0) *all_exact = e;
+        return;
+    }
     const int ft0 = blockIdx.x * group;
     int e;
     if (policy == 1) e = 0;
@@ -987,10 +1001,8 @@ __global__ __launch_bounds__(256) void k_tile_flags(const int32_t* flags, int64_
         int mine = (model_exact && flags != nullptr) ? ((r < N) ? (flags[r] != 0) : 1) : 0;
         e = __syncthreads_and(mine);
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         for (int g = 0; g < group; ++g) if (ft0 + g < FT) tile_exact[ft0 + g] = e;
-        if (!e && all_exact) atomicAnd(all_exact, 0);
-    }
 }
 
 // second decision, once the digit planes of a chunk exist: a tile group that is not on the code grid (tile_exact == 0) goes
@@ -1036,7 +1048,6 @@ inline bool use_big_gemm(const rml_svm* m, int64_t n, int num_cu) {
     return wgs * 4 >= (int64_t)num_cu * 3 && wgs * 4 >= rounds * num_cu * 3;
 }
 
-__global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
 
 // ---- finishing kernel: fixed-order sum of the SV-tile partials + libsvm/sklearn tail ------
 struct FinishArgs {
@@ -1878,9 +1889,8 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
             if (rc) return rc;
             RML_HIP(hipEventRecord(ev_proj[c % NBUF], sp));
             RML_HIP(hipStreamWaitEvent(side, ev_proj[c % NBUF], 0));
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, side, w.all_exact, 1);
             const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
-            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group), dim3(128 * group), 0, side, w.flags, n, FT, 0, 1, w.tile_exact,
+            hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group + 1), dim3(128 * group), 0, side, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }
         // pass 2: float rows + norms for the f32 path; a no-op when every tile is exact
