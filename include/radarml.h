@@ -325,8 +325,9 @@ int rml_resize_bicubic(rml_ctx* ctx, const float* in, int64_t in_stride, int64_t
  * before the bf16 rounding (the bf16 value differs from the rounded exact one by at most one bf16 ulp on a small fraction of
  * the pixels); rml_resize_bicubic stays the Pillow-exact surface.  Input per row: the float32 feature row [xz | yz | xy]
  * (rows, ld floats apart) and / or the biased uint8 code row rml_project writes (codes, ldq bytes apart, 16-byte aligned);
- * with both given, flags[b] != 0 selects the code row of row b (the per-row "every value is an integer in [0, 255]" flag of
- * rml_project); codes alone: always the code row.  Outputs: (B, out_h, out_w) bf16, 8-byte aligned.
+ * flags[b] != 0 selects the code row of row b (the per-row "every value is an integer in [0, 255]" flag of rml_project), 0 its
+ * float row; a row whose kind was not passed is left untouched (flags with ONE kind of row: only the rows of that kind are
+ * written); flags = NULL: every row, from the one kind given.  Outputs: (B, out_h, out_w) bf16, 8-byte aligned.
  * Shapes: Z % 16 == 0, out_w % 4 == 0, out_w <= 256, out_h >= X and >= Y (no vertical shrink), (X + Y) * Z <= 16 384,
  * X * Y <= 4 096 -- rml_dnn_preprocess_supported says; others: RML_ERR_UNSUPPORTED (rml_resize_bicubic per projection). */
 int rml_dnn_preprocess_supported(int X, int Y, int Z, int out_h, int out_w);
@@ -335,7 +336,8 @@ int rml_dnn_preprocess_rows(rml_ctx* ctx, const float* rows, int64_t ld, const u
                             void* stream);
 /* Volumes -> trunk inputs (the front of BASELINE configs[3]): projection (mode as rml_project; ijk for RML_MODE_SLICE) into code rows
  * + row flags (no float rows through HBM), for float32 volumes a float-row pass predicated ON THE DEVICE on "some row left the
- * code grid" (it exits at once for radar data, integers 0..255: common.py:30-31), then rml_dnn_preprocess_rows.  Scratch is the
+ * code grid" (it exits at once for radar data, integers 0..255: common.py:30-31) -- queued on the context's second stream beside
+ * the code rows' preprocessing, joined before the call returns its stream --, then rml_dnn_preprocess_rows.  Scratch is the
  * caller's: codes B x ldq bytes (ldq >= D, % 16 == 0), flags B + 1 int32 (flags[B]: every row on the grid), rows B x ld float32
  * (float32 volumes only; NULL for uint8 volumes, which cannot leave the grid). */
 int rml_dnn_preprocess_volumes(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode, const int32_t* ijk,

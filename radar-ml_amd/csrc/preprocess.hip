@@ -412,6 +412,8 @@ static int preprocess_rows(rml_ctx* ctx, const float* rows, int64_t ld, const ui
     RML_REQUIRE(B < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_dnn_preprocess_rows: B too large");
     RML_REQUIRE((rows || codes) && xz && yz && xy, RML_ERR_INVALID, "rml_dnn_preprocess_rows: NULL argument");
     RML_REQUIRE(!(rows && codes) || flags, RML_ERR_INVALID, "rml_dnn_preprocess_rows: float rows AND code rows need the row flags");
+    // (one kind of row WITH flags: only the rows whose flag selects that kind are written -- the two launches of
+    // rml_dnn_preprocess_volumes on its two streams)
     const int64_t D = (int64_t)X * Z + (int64_t)Y * Z + (int64_t)X * Y;
     RML_REQUIRE(!rows || ld >= D, RML_ERR_INVALID, "rml_dnn_preprocess_rows: ld < D");
     RML_REQUIRE(!codes || (ldq >= D && ldq % 16 == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0), RML_ERR_INVALID,
@@ -427,14 +429,13 @@ static int preprocess_rows(rml_ctx* ctx, const float* rows, int64_t ld, const ui
     int rc = pre_tables(ctx, X, Y, Z, out_h, out_w, p, a);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    a.flags = flags;                                // nullptr: every row
     if (codes) {
-        a.flags = rows ? flags : nullptr;           // codes alone: every row
         a.SZ = p.SZ[1];
         launch_pre3_w<true>(p, a, ctx->num_cu, st);
     }
     if (rows) {
-        a.flags = codes ? flags : nullptr;          // rows alone: every row
-        a.skip_if_set = codes ? skip_rows : nullptr;
+        a.skip_if_set = skip_rows;
         a.SZ = p.SZ[0];
         launch_pre3_w<false>(p, a, ctx->num_cu, st);
     }
@@ -490,21 +491,31 @@ extern "C" int rml_dnn_preprocess_volumes(rml_ctx* ctx, const void* V, int vdtyp
     o.scale_div = 0.0f;
     int rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, st);
     if (rc) return rc;
-    const bool general = vdtype != RML_VOL_U8;
-    if (general) {
-        // rows that left the code grid need their float32 projections: a second projection pass, predicated on the device (it
-        // exits at once when every row of the batch is on the grid -- radar returns are integers 0..255, common.py:30-31)
-        hipLaunchKernelGGL(k_all_set, dim3(1), dim3(256), 0, st, flags, B);
-        ProjOut of{};
-        off = 0;
-        for (int pl = 0; pl < 3; ++pl) { of.p[pl] = rows + off; of.stride[pl] = ld; off += plen[pl]; }
-        of.sel = RML_MASK_ALL;
-        of.scale_div = 0.0f;
-        of.skip_if_set = flags + B;
-        of.no_pad = 1;
-        rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, of, st);
-        if (rc) return rc;
-    }
-    return preprocess_rows(ctx, general ? rows : nullptr, ld, codes, ldq, general ? flags : nullptr, general ? flags + B : nullptr, B, X, Y, Z,
-                           out_h, out_w, xz, yz, xy, stream);
+    if (vdtype == RML_VOL_U8)           // bytes cannot leave the code grid
+        return preprocess_rows(ctx, nullptr, 0, codes, ldq, nullptr, nullptr, B, X, Y, Z, out_h, out_w, xz, yz, xy, stream);
+    // float32 volumes: rows that left the code grid need their float32 projections -- a second projection pass and the float-row
+    // preprocessing launch, both predicated on the device (they exit at once when every row of the batch is on the grid: radar
+    // returns are integers 0..255, common.py:30-31).  The three small launches of that fallback run on the context's second stream
+    // BESIDE the code-row preprocessing of the batch (disjoint output rows), not in front of it.
+    rml_ctx_guard guard(ctx, st);
+    hipStream_t aux = ctx->aux_stream;
+    RML_HIP(hipEventRecord(ctx->ev_fork, st));
+    RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_all_set, dim3(1), dim3(256), 0, aux, flags, B);
+    ProjOut of{};
+    off = 0;
+    for (int pl = 0; pl < 3; ++pl) { of.p[pl] = rows + off; of.stride[pl] = ld; off += plen[pl]; }
+    of.sel = RML_MASK_ALL;
+    of.scale_div = 0.0f;
+    of.skip_if_set = flags + B;
+    of.no_pad = 1;
+    rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, of, aux);
+    if (rc) return rc;
+    rc = preprocess_rows(ctx, rows, ld, nullptr, 0, flags, flags + B, B, X, Y, Z, out_h, out_w, xz, yz, xy, aux);
+    if (rc) return rc;
+    RML_HIP(hipEventRecord(ctx->ev_join, aux));
+    rc = preprocess_rows(ctx, nullptr, 0, codes, ldq, flags, nullptr, B, X, Y, Z, out_h, out_w, xz, yz, xy, stream);
+    if (rc) return rc;
+    RML_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    return RML_OK;
 }
