@@ -61,6 +61,9 @@ __device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
 
 // Per-thread sink for finished projection values: scaled float store, uint8 code store and
 // the row statistics of the exact-integer SVM path.
+#ifndef RML_CODE_NT
+#define RML_CODE_NT 0       // experiment builds: 1 = the code rows leave with non-temporal stores
+#endif
 #ifndef RML_EMIT_ABL
 #define RML_EMIT_ABL 0      // experiment builds (timing only): 1 = no code stores, 2 = code rows of all frames land on 64 rows (L2-resident)
 #endif
@@ -165,6 +168,8 @@ struct Emitter {
                 if (staged && pl != 1) *(lds_u32*)(stage + (pl == 2 ? stage_xy : 0) + idx) = packed;
 #if RML_EMIT_ABL == 1
                 else asm volatile("" :: "v"(packed));
+#elif RML_CODE_NT
+                else __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx));
 #else
                 else *reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx) = packed;
 #endif
@@ -188,7 +193,13 @@ struct Emitter {
         for (int r = 0; r < 2; ++r) {
             int done = 0;
             if ((reinterpret_cast<uintptr_t>(dst[r]) & 15) == 0) {
-                for (int i = lane; i < (len[r] >> 4); i += 64) reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
+                for (int i = lane; i < (len[r] >> 4); i += 64) {
+#if RML_CODE_NT
+                    __builtin_nontemporal_store(((lds_u128*)src[r])[i], reinterpret_cast<u32x4*>(dst[r]) + i);
+#else
+                    reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
+#endif
+                }
                 done = len[r] & ~15;
             }
             for (int i = done + 4 * lane; i + 4 <= len[r]; i += 256)       // rows are 4-byte aligned (rml_project's contract)

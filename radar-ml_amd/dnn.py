@@ -272,7 +272,7 @@ class Classifier(_module_base()):
         lg = F.linear(h, w3, b3)
         return torch.softmax(lg.float(), dim=-1)
 
-    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=8192, overlap=False, trunk_events=None,
+    def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=16384, overlap=False, trunk_events=None,
                         exact_resize=False):
         """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
         projections as uint8 code rows (csrc/project*.hip) -> [-1,1] scaling + bicubic resize of the three projections in one
@@ -281,6 +281,8 @@ class Classifier(_module_base()):
         preprocessing does not take) runs the round-1..3 chain instead: float32 feature rows and the Pillow-bit-identical
         float64 resize (csrc/resize.hip), one launch per projection -- the same values before the bf16 rounding to ~1e-6.
 
+        ``batch_size``: frames per pass of the chain (16 384: 5.96-6.08 M frames/s against 5.83-5.85 M at 8 192 and 6.03-6.04 M at
+        32 768 on one box -- fewer launch gaps and persistent-kernel tails; 2.2 GB of intermediates at the Walabot grid).
         ``overlap`` (off): the projection of batch b+2 on a second stream beside the resize of batch b+1, the trunk (a whole CU's
         LDS) and the dense tail (hipBLASLt: 135 KB of LDS) alone between two projection launches.  Measured in round 4 (three
         schedules, kernel timeline in tools/exp/README.md): no gain -- beside the projection the resize kernels take 3 x as long

@@ -210,3 +210,81 @@ def test_round4_entry_points_reject_bad_arguments_and_options(rml):
     finally:
         assert lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0) == 0
     assert torch.equal(a, b)
+
+
+def test_cnn_chain_entry_points_reject_bad_arguments(rml):
+    """rml_dnn_preprocess_supported / _rows / _volumes, rml_dnn_trunk_kblock, rml_dnn_dense_workspace_bytes / rml_dnn_dense_tail
+    through the C ABI: status codes and messages for bad arguments, the support predicate, the B == 0 cases."""
+    import torch
+    from radar_ml_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.context()
+    st = _lib.stream_ptr()
+    # support predicate: Z % 16 == 0, out_w % 4 == 0 and <= 256, no vertical shrink, rows of at most 20 480 elements
+    assert lib.rml_dnn_preprocess_supported(22, 31, 176, 80, 80) == 1 and lib.rml_dnn_preprocess_supported(64, 64, 128, 80, 80) == 1
+    assert lib.rml_dnn_preprocess_supported(22, 31, 180, 80, 80) == 0           # Z % 16
+    assert lib.rml_dnn_preprocess_supported(22, 31, 176, 80, 82) == 0           # out_w % 4
+    assert lib.rml_dnn_preprocess_supported(22, 31, 176, 16, 80) == 0           # the height would shrink: windows of more than 4 taps
+    assert lib.rml_dnn_preprocess_supported(64, 64, 256, 80, 80) == 0           # row longer than 20 480
+    assert lib.rml_dnn_preprocess_supported(0, 31, 176, 80, 80) == 0
+    X, Y, Z = 5, 7, 16
+    D = X * Z + Y * Z + X * Y
+    B = 3
+    ldq = 256
+    feat = torch.zeros((B, D), device="cuda")
+    codes = torch.zeros((B, ldq), dtype=torch.uint8, device="cuda")
+    flags = torch.ones((B + 1,), dtype=torch.int32, device="cuda")
+    outs = [torch.empty((B, 12, 16), dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    rows = lambda f=feat, ld=D, c=None, lq=0, fl=None, o0=outs[0], ow=16: lib.rml_dnn_preprocess_rows(
+        ctx, _lib.ptr(f), ld, _lib.ptr(c), lq, _lib.ptr(fl), B, X, Y, Z, 12, ow, _lib.ptr(o0), _lib.ptr(outs[1]), _lib.ptr(outs[2]), st)
+    assert rows() == 0
+    assert rows(c=codes, lq=ldq, fl=flags) == 0
+    assert rows(f=None) == -1 and b"NULL" in lib.rml_last_error()
+    assert rows(ld=D - 1) == -1 and b"ld" in lib.rml_last_error()
+    assert rows(c=codes, lq=ldq) == -1 and b"flags" in lib.rml_last_error()     # both kinds of rows, nothing to choose by
+    assert rows(f=None, c=codes, lq=D) == -1 and b"ldq" in lib.rml_last_error()    # ldq % 16
+    assert rows(o0=None) == -1
+    assert rows(ow=18) == -2 and b"rml_resize_bicubic" in lib.rml_last_error()  # unsupported shape names the way out
+    assert lib.rml_dnn_preprocess_rows(ctx, None, 0, None, 0, None, 0, X, Y, Z, 12, 16, None, None, None, st) == 0      # B == 0
+    v = torch.zeros((B, X, Y, Z), device="cuda")
+    scratch = torch.empty((B, D), device="cuda")
+    vols = lambda vol=v, vdt=0, c=codes, sc=scratch, lq=ldq: lib.rml_dnn_preprocess_volumes(
+        ctx, _lib.ptr(vol), vdt, B, X, Y, Z, 0, None, _lib.ptr(c), lq, _lib.ptr(flags), _lib.ptr(sc), D, 12, 16,
+        _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), st)
+    assert vols() == 0
+    assert vols(vol=None) == -1 and vols(c=None) == -1
+    assert vols(vdt=5) == -1 and b"dtype" in lib.rml_last_error()
+    assert vols(sc=None) == -1 and b"scratch" in lib.rml_last_error()           # float32 volumes need the float-row scratch ...
+    assert vols(vol=v.to(torch.uint8), vdt=1, sc=None) == 0                     # ... uint8 volumes do not
+    assert vols(lq=D + 1) == -1
+    torch.cuda.synchronize()
+    # the dense tail
+    K, N = 38400, 5
+    fv = torch.zeros((N, K), dtype=torch.bfloat16, device="cuda")
+    w1 = torch.zeros((64, K), dtype=torch.bfloat16, device="cuda")
+    b64 = torch.zeros(64, device="cuda"); w2t = torch.zeros((64, 64), device="cuda"); w3 = torch.zeros((3, 64), device="cuda"); b3 = torch.zeros(3, device="cuda")
+    nbytes = lib.rml_dnn_dense_workspace_bytes(ctx, N, K)
+    assert nbytes >= N * 64 * 4 and lib.rml_dnn_dense_workspace_bytes(ctx, 0, K) == 0
+    ws = torch.empty((nbytes // 4,), device="cuda")
+    pr = torch.empty((N, 3), device="cuda")
+    tail = lambda k=K, f=fv, nb=nbytes, nc=3, kb=0: lib.rml_dnn_dense_tail(ctx, _lib.ptr(f), K, kb, N, k, _lib.ptr(w1), _lib.ptr(b64), _lib.ptr(w2t),
+                                                                             _lib.ptr(b64), _lib.ptr(w3), _lib.ptr(b3), nc, _lib.ptr(ws), nb, _lib.ptr(pr), st)
+    assert tail() == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(pr, torch.full_like(pr, 1.0 / 3.0))                   # zero weights: uniform probabilities
+    assert tail(k=K - 32) == -2 and b"multiple of 64" in lib.rml_last_error()
+    assert tail(f=None) == -1 and tail(nb=nbytes - 4) == -1 and b"workspace" in lib.rml_last_error()
+    assert tail(nc=17) == -2
+    # the K-block trunk needs an even number of output pixels
+    x = torch.zeros((2, 12, 8), dtype=torch.bfloat16, device="cuda")           # 3 x 2 = 6 output pixels: fine; 12 x 8 planes
+    w1c = torch.zeros((3, 64, 9), device="cuda"); b1c = torch.zeros((3, 64), device="cuda")
+    w2c = torch.zeros((3, 32, 576), dtype=torch.bfloat16, device="cuda"); b2c = torch.zeros((3, 32), device="cuda")
+    fk = torch.empty((6 * 96 // 64, 2, 64), dtype=torch.bfloat16, device="cuda")
+    kb = lambda H, W: lib.rml_dnn_trunk_kblock(ctx, _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 2, H, W, _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(w2c),
+                                               _lib.ptr(b2c), _lib.ptr(fk), st)
+    assert kb(12, 8) == 0
+    torch.cuda.synchronize()
+    # bf16 planes (W % 8 == 0) always have an even number of output pixels; float32 planes need not: 12 x 12 -> 3 x 3
+    xf = torch.zeros((2, 12, 12), device="cuda")
+    assert lib.rml_dnn_trunk_kblock(ctx, _lib.ptr(xf), _lib.ptr(xf), _lib.ptr(xf), 0, 2, 12, 12, _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(w2c),
+                                    _lib.ptr(b2c), _lib.ptr(fk), st) == -2 and b"even" in lib.rml_last_error()

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=16384)
     ap.add_argument("--exact", action="store_true", help="float rows + the Pillow-bit-identical resize (the round-1..3 chain)")
     ap.add_argument("--u8", action="store_true")
     a = ap.parse_args()
