@@ -59,6 +59,15 @@ CFG='[{"tag":"primary_f32","grid":[64,64,128],"frames":8192,"u8":false},{"tag":"
 for c in FETCH_SIZE WRITE_SIZE; do
     RML_WAVE_SHARE=1 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/prof_$c -o k -- python $R/tools/pmc_child.py "$CFG" > /dev/null 2> $R/gpurun_out/prof_$c.err
 done
+# the CNN chain's kernels (configs[3]: code-row projection, k_pre3, trunk, k_fc1_splitk): FETCH_SIZE / WRITE_SIZE per launch
+for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/prof_dnn_$c -o k -- python $R/tools/dnn_chain.py --frames 32768 --steps 2 > /dev/null 2> $R/gpurun_out/prof_dnn_$c.err
+done
+( echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) on tools/dnn_chain.py --frames 32768 --steps 2 (passes of 16 384 Walabot frames):"
+  echo "# per-kernel averages; FETCH_SIZE in KB as reported (x2 = bytes / 1024 on gfx950).  Algorithmic bytes per pass of 16 384 frames: projection 7.87 GB read;"
+  echo "# k_pre3 0.164 GB read + 0.629 GB written; k_dnn_trunk_rf 0.629 GB read + 1.258 GB written; k_fc1_splitk 1.258 GB read"
+  for c in FETCH_SIZE WRITE_SIZE; do echo "# --- $c"; python $R/tools/pmc_query.py $R/gpurun_out/prof_dnn_$c/k_results.db "%k_%"; done ) > $R/gpurun_out/${TAG}_pmc_dnn.txt 2>&1
+rm -rf $R/gpurun_out/prof_dnn_FETCH_SIZE $R/gpurun_out/prof_dnn_WRITE_SIZE
 cd $R
 python tools/prof_summary.py pmc gpurun_out/prof_FETCH_SIZE/k_results.db gpurun_out/prof_WRITE_SIZE/k_results.db > gpurun_out/${TAG}_pmc.txt
 cp profiles/pmc_latest.json gpurun_out/pmc_latest.json 2>/dev/null
