@@ -172,10 +172,20 @@ struct FinishArgs {
     float* out;                 // [N][C] probabilities
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// sum over the 64 lanes of a wave on DPP moves (six dependent VALU steps; the butterfly of __shfl_xor is six ds_bpermute round
+// trips, and three of those chains per sample were most of k_dense_finish); the result is wave-uniform; a fixed order
+__device__ __forceinline__ float wave_sum(float r) {
+    r += dpp_mov<0xB1, 0xF, true>(0.0f, r);     // quad_perm [1,0,3,2]
+    r += dpp_mov<0x4E, 0xF, true>(0.0f, r);     // quad_perm [2,3,0,1]
+    r += dpp_mov<0x141, 0xF, true>(0.0f, r);    // row_half_mirror
+    r += dpp_mov<0x140, 0xF, true>(0.0f, r);    // row_mirror: every lane of a 16-lane row holds the row's sum
+    r += dpp_mov<0x142, 0xA, false>(0.0f, r);   // row_bcast15 into rows 1 and 3
+    r += dpp_mov<0x143, 0xC, false>(0.0f, r);   // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
 }
 
 __global__ __launch_bounds__(256) void k_dense_finish(FinishArgs a) {
