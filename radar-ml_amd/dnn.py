@@ -198,7 +198,9 @@ class Classifier(_module_base()):
         """True when trunk and dense tail can hand the features over in the K-block layout: planes the register-resident trunk
         kernel takes (the 80 x 80 of dnn.py does), an even number of output pixels, the reference's 64 / 64 / n dense layers."""
         P = (H // 4) * (W // 4)
-        return (H % 4 == 0 and W % 8 == 0 and P % 2 == 0 and H <= 96 and W <= 96 and len(self.branches) == 3
+        # k_dnn_trunk_rf's LDS layout (csrc/dnn.hip RfLayout): eight wave-private bf16 planes with a 4-pixel border + 36 KB of weights
+        rf_lds = 8 * (((H + 4) * (W + 4) * 2 + 15) // 16 * 16) + 36 * 1024 + 160
+        return (H % 4 == 0 and W % 8 == 0 and P % 2 == 0 and rf_lds <= 160 * 1024 and len(self.branches) == 3
                 and tuple(self.fc2.weight.shape) == (64, 64) and self.fc1.weight.shape[0] == 64 and self.n_classes <= 16
                 and self.fc1.weight.shape[1] == P * 96)
 

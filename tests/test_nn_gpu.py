@@ -417,6 +417,44 @@ def test_fused_preprocessing_tracks_the_pillow_exact_resize(rml, grid, rescale):
         assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.01
 
 
+def test_fused_preprocessing_random_shapes_property(rml):
+    """Property test: csrc/preprocess.hip on random supported geometries (rows of 16..256 voxels, planes of 1..40 rows, outputs of
+    4..96 columns, either axis unchanged or stretched) against the Pillow-exact kernel rounded to bf16: never more than one bf16 ulp
+    apart, code rows and float rows of the same integers bit-identical; and the support predicate says no where it must."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    seen = {"ok": 0, "no": 0}
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 40), st.integers(1, 40), st.integers(1, 16), st.integers(1, 30), st.integers(1, 24), st.integers(1, 5),
+           st.integers(0, 2 ** 31 - 1))
+    def check(X, Y, z16, oh, ow4, B, seed):
+        Z, OW = 16 * z16, 4 * ow4
+        OH = max(oh, X, Y)                                     # no vertical shrink (else: unsupported, checked below)
+        grid, rescale = (X, Y, Z), (OW, OH)
+        if not nc.preprocess_supported(grid, rescale):
+            seen["no"] += 1
+            return
+        seen["ok"] += 1
+        rng = np.random.default_rng(seed)
+        D = X * Z + Y * Z + X * Y
+        feat = torch.from_numpy(rng.integers(0, 256, (B, D)).astype(np.float32)).cuda()
+        want = nc.preprocess_features(feat, grid, rescale, out_dtype="bfloat16")
+        ldq = (D + 127) // 128 * 128
+        codes = torch.zeros((B, ldq), dtype=torch.uint8, device="cuda")
+        codes[:, :D] = feat.to(torch.uint8) ^ 0x80
+        got_c = nc.preprocess_rows(grid, rescale, codes=codes)
+        got_f = nc.preprocess_rows(grid, rescale, feat=feat)
+        for pl in range(3):
+            assert torch.equal(got_c[pl], got_f[pl]), (grid, rescale, pl)
+            assert int(_bf16_ulps(got_c[pl], want[pl]).max()) <= 1, (grid, rescale, pl)
+
+    check()
+    assert seen["ok"] >= 10
+    assert not nc.preprocess_supported((22, 31, 176), (80, 20))           # the height would shrink
+    assert not nc.preprocess_supported((22, 31, 100), (80, 80))           # rows that are not whole 16-byte code chunks
+
+
 def test_fused_preprocessing_from_volumes(rml):
     """rml_dnn_preprocess_volumes: volumes -> code rows (+ device-predicated float pass) -> the trunk's inputs.  uint8 and float32
     ingest of the same integers: same bits; volumes with non-integer returns: every row through the float pass, still within one
