@@ -8,8 +8,9 @@
 //
 //  * k_fc1_splitk: 128 rows x 64 outputs per workgroup and K-step of 64 elements (128 B per row), split-K so that the grid is one
 //    round of three workgroups per CU; the tiles of a step are loaded lane-contiguously into registers three K-steps ahead and go
-//    through two XOR-swizzled [rows][128 B] LDS stages, one LDS-only barrier per step; v_mfma_f32_32x32x16_bf16 with the weights as the A (row) operand and the samples as B, so a lane ends
-//    up with 4 consecutive outputs of ONE sample per accumulator quad: float4 stores of the float32 partial sums.
+//    through two XOR-swizzled [rows][128 B] LDS stages, one LDS-only barrier per step; v_mfma_f32_32x32x16_bf16 with the weights
+//    as the A (row) operand and the samples as B, so a lane ends up with 4 consecutive outputs of ONE sample per accumulator quad:
+//    float4 stores of the float32 partial sums.
 //  * k_dense_finish: one wave per sample sums the partials in split order (deterministic), adds the bias, relu; the two small
 //    layers run in float32 in the wave (lane = output unit, the previous layer's activations broadcast with v_readlane), softmax in
 //    lane order.  Activations between the layers stay float32 (the autocast chain this replaces rounded them to bf16).

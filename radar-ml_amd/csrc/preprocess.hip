@@ -9,16 +9,21 @@
 // bf16 result differs from the rounded exact one by at most one bf16 ulp on a small fraction of the pixels (tests/test_nn_gpu.py
 // measures both).  It is NOT the parity surface: rml_resize_bicubic stays the Pillow-exact entry point.
 //
-// Input per row, chosen by a per-row flag: the biased uint8 code row the projection kernels write (a quarter of the float row's
-// bytes; exact whenever the projections are integers 0..255, which the flag says) or the float32 feature row.
+// Input per row, chosen by a per-row flag, one kernel instantiation per kind: the biased uint8 code row the projection kernels write
+// (k_pre3<true>: a quarter of the float row's bytes; exact whenever the projections are integers 0..255, which the flag says) or the
+// float32 feature row (k_pre3<false>: the rows whose flag is clear; predicated on the device in rml_dnn_preprocess_volumes).
 //
-// One 256-thread workgroup per sample, persistent, the next sample's row prefetched into registers:
-//  * staging: codes / floats -> normalised float32 images in LDS, row strides an odd number of 16-byte slots;
-//  * horizontal pass: a thread owns an output column (its <= 16 window weights, shifted to the 16-byte grid and zero padded, stay in
-//    registers for the whole launch) and walks the rows: the window is 2-4 ds_read_b128 -- lanes of a wave start 0.4-2.2 floats apart,
-//    so the 16 lanes of an LDS lane group touch distinct (or identical: broadcast) slots: conflict-free at 256 B/clk;
-//  * vertical pass: a thread produces four adjacent outputs of a row from four ds_read_b128 (the rows' weights from a 16-byte record
-//    in LDS) and stores them as one 8-byte piece -- consecutive threads write consecutive bytes.
+// One 256-thread workgroup per sample, persistent, the next sample's code row prefetched into registers:
+//  * staging: the raw codes as float16 (exact; float rows: float32) images in LDS, row strides an odd number of 16-byte slots; the
+//    small xy image linear;
+//  * horizontal pass: a thread owns an output column (its <= 16 window weights, shifted to the 8- / 16-byte grid and zero padded,
+//    stay in registers for the whole launch) and walks the rows: the window is four ds_read_b64 (float32 images: ds_read_b128) and
+//    v_fma_mix_f32 taps -- lanes of a wave start 0.4-2.2 elements apart, so a lane group touches distinct or identical (broadcast)
+//    slots: conflict-free; (p - 127.5) / 127.5 is applied to the result (the weights of a window sum to 1);
+//  * vertical pass: a thread produces four adjacent outputs of a row from four ds_read_b128 (the row's weights from a 16-byte record
+//    in LDS) with v_pk_fma_f32 and stores them as one 8-byte piece -- consecutive threads write consecutive bytes.
+// Where its time goes, and what was tried on top (matrix-core horizontal pass, projection-by-projection intermediate):
+// tools/exp/README.md, round 4.
 #include "rml_internal.h"
 #include "resize_tables.h"
 #include <type_traits>
