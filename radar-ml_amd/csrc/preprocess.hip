@@ -472,7 +472,20 @@ __global__ __launch_bounds__(256) void k_all_set(int32_t* flags, int64_t B) {
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
     int mine = 0;
-    for (int64_t i = threadIdx.x; i < B; i += 256) mine |= flags[i] == 0;
+    if ((reinterpret_cast<uintptr_t>(flags) & 15) == 0) {       // eight independent 16-byte loads per thread and trip
+        const int4* f4 = reinterpret_cast<const int4*>(flags);
+        const int64_t n4 = B >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += 256 * 8) {
+            int4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int64_t idx = i + u * 256; v[u] = idx < n4 ? f4[idx] : make_int4(1, 1, 1, 1); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine |= (v[u].x == 0) | (v[u].y == 0) | (v[u].z == 0) | (v[u].w == 0);
+        }
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < B; i += 256) mine |= flags[i] == 0;
+    } else {
+        for (int64_t i = threadIdx.x; i < B; i += 256) mine |= flags[i] == 0;
+    }
     if (mine) bad = 1;
     __syncthreads();
     if (threadIdx.x == 0) flags[B] = bad ? 0 : 1;

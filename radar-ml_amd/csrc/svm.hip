@@ -986,7 +986,25 @@ __global__ __launch_bounds__(256) void k_tile_flags(const int32_t* flags, int64_
         if (policy == 1) mine = 0;
         else if (policy != 2) {
             if (!(model_exact && flags != nullptr)) mine = 0;
-            else for (int64_t r = threadIdx.x; r < N; r += blockDim.x) mine &= flags[r] != 0;
+            else if ((reinterpret_cast<uintptr_t>(flags) & 15) == 0) {
+                // eight independent 16-byte loads per thread and trip (a plain `mine &= flags[r]` loop waits out a memory latency per
+                // flag: 65-75 us for 8 192 rows in the kernel timeline of session r4aq -- on the stream whose chain is the period)
+                const int4* f4 = reinterpret_cast<const int4*>(flags);
+                const int64_t n4 = N >> 2;
+                for (int64_t i = threadIdx.x; i < n4; i += (int64_t)blockDim.x * 8) {
+                    int4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t idx = i + (int64_t)u * blockDim.x;
+                        v[u] = idx < n4 ? f4[idx] : make_int4(1, 1, 1, 1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mine &= (v[u].x != 0) & (v[u].y != 0) & (v[u].z != 0) & (v[u].w != 0);
+                }
+                for (int64_t r = (n4 << 2) + threadIdx.x; r < N; r += blockDim.x) mine &= flags[r] != 0;
+            } else {
+                for (int64_t r = threadIdx.x; r < N; r += blockDim.x) mine &= flags[r] != 0;
+            }
         }
         const int e = __syncthreads_and(mine);
         if (threadIdx.x == 0) *all_exact = e;
