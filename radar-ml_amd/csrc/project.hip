@@ -381,9 +381,14 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
         int lane_f = lane, Y_f = Y;
         asm volatile("" : "+v"(lane_f), "+s"(Y_f));
         const bool act_f = lane_f < ZQ;
+        uint32_t oldw[NY];                                  // read-compare-write of the code rows: all old words in flight at once
         static_for<NY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j]);
+            oldw[j] = em.old_word(1, (j < Y_f && act_f) ? (int64_t)j * Z + 4 * lane_f : 0);
+        });
+        static_for<NY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j], true, oldw[j]);
         });
         em.flush_wave(lane_f);
         em.finish_wave(lane_f);

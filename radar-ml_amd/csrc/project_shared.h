@@ -127,23 +127,33 @@ struct Emitter {
             }
         }
     }
+    // Read-compare-write of the code rows (ProjOut::q_rmw): the dword a later put4 / put_bytes4 of (pl, idx) would overwrite, so that
+    // a kernel can have the old words of a whole region in flight before it compares the first one
+    __device__ __forceinline__ uint32_t old_word(int pl, int64_t idx) const {
+        if (!(a.o.q_rmw && a.o.q[pl] && ((a.o.sel >> pl) & 1u))) return 0u;
+        return *reinterpret_cast<const uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
+    }
     // four projection values that ARE bytes (uint8 volumes; idx a multiple of 4): when only codes and their statistics are
     // wanted the bytes are the codes -- biased with one xor, summed and squared with v_dot4_u32_u8 -- and nothing is widened
-    __device__ __forceinline__ void put_bytes4(int pl, int64_t idx, uint32_t w) {
+    __device__ __forceinline__ void put_bytes4(int pl, int64_t idx, uint32_t w, bool have_old = false, uint32_t old = 0u) {
         if (!((a.o.sel >> pl) & 1u)) return;
-        if (a.o.p[pl] || a.o.row_nsq) { put4(pl, idx, bytes_to_float4(w)); return; }
+        if (a.o.p[pl] || a.o.row_nsq) { put4(pl, idx, bytes_to_float4(w), have_old, old); return; }
         if (want_stats) {
             isum += (int32_t)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
             isq = __builtin_amdgcn_udot4(w, w, isq, false);
 #if RML_EMIT_ABL == 1
             asm volatile("" :: "v"(w));
 #else
-            if (a.o.q[pl]) *reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx) = w ^ 0x80808080u;
+            if (a.o.q[pl]) {
+                uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
+                const uint32_t nv = w ^ 0x80808080u;
+                if (!a.o.q_rmw || (have_old ? old : *dq) != nv) *dq = nv;
+            }
 #endif
         }
     }
     // idx is a multiple of 4
-    __device__ __forceinline__ void put4(int pl, int64_t idx, float4 v) {
+    __device__ __forceinline__ void put4(int pl, int64_t idx, float4 v, bool have_old = false, uint32_t old = 0u) {
         if (!((a.o.sel >> pl) & 1u)) return;
         if (a.o.p[pl]) {
             float* dst = a.o.p[pl] + b * a.o.stride[pl] + idx;
@@ -171,7 +181,10 @@ struct Emitter {
 #elif RML_CODE_NT
                 else __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx));
 #else
-                else *reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx) = packed;
+                else {
+                    uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
+                    if (!a.o.q_rmw || (have_old ? old : *dq) != packed) *dq = packed;
+                }
 #endif
             }
         }
@@ -193,17 +206,52 @@ struct Emitter {
         for (int r = 0; r < 2; ++r) {
             int done = 0;
             if ((reinterpret_cast<uintptr_t>(dst[r]) & 15) == 0) {
-                for (int i = lane; i < (len[r] >> 4); i += 64) {
+                const int n16 = len[r] >> 4;
+                u32x4* dq = reinterpret_cast<u32x4*>(dst[r]);
+                if (a.o.q_rmw) {
+                    // the old words of four stores in flight, then compare and store what changed
+                    for (int i0 = lane; i0 < n16; i0 += 4 * 64) {
+                        u32x4 ov[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; ov[u] = dq[i < n16 ? i : i0]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + 64 * u;
+                            if (i < n16) {
+                                const u32x4 nv = ((lds_u128*)src[r])[i];
+                                if (((ov[u].x ^ nv.x) | (ov[u].y ^ nv.y) | (ov[u].z ^ nv.z) | (ov[u].w ^ nv.w)) != 0) dq[i] = nv;
+                            }
+                        }
+                    }
+                } else {
+                    for (int i = lane; i < n16; i += 64) {
 #if RML_CODE_NT
-                    __builtin_nontemporal_store(((lds_u128*)src[r])[i], reinterpret_cast<u32x4*>(dst[r]) + i);
+                        __builtin_nontemporal_store(((lds_u128*)src[r])[i], dq + i);
 #else
-                    reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
+                        dq[i] = ((lds_u128*)src[r])[i];
 #endif
+                    }
                 }
                 done = len[r] & ~15;
             }
-            for (int i = done + 4 * lane; i + 4 <= len[r]; i += 256)       // rows are 4-byte aligned (rml_project's contract)
-                *reinterpret_cast<uint32_t*>(dst[r] + i) = *(lds_u32*)(src[r] + i);
+            // rows are 4-byte aligned (rml_project's contract)
+            const int n4 = (len[r] - done) >> 2;
+            uint32_t* dw = reinterpret_cast<uint32_t*>(dst[r] + done);
+            lds_u32* sw = (lds_u32*)(src[r] + done);
+            if (a.o.q_rmw) {
+                for (int i0 = lane; i0 < n4; i0 += 4 * 64) {
+                    uint32_t ov[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; ov[u] = dw[i < n4 ? i : i0]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < n4) { const uint32_t nv = sw[i]; if (ov[u] != nv) dw[i] = nv; }
+                    }
+                }
+            } else {
+                for (int i = lane; i < n4; i += 64) dw[i] = sw[i];
+            }
             for (int i = (len[r] & ~3) + lane; i < len[r]; i += 64) dst[r][i] = src[r][i];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -181,23 +181,34 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     __syncthreads();
 
     Emitter em(a, b);
+    // eight words per thread and trip: with read-compare-write of the code rows (ProjOut::q_rmw) their old words are in flight together
+    auto emit_plane = [&](int pl, int n4, auto word_of) __attribute__((always_inline)) {
+        for (int idx0 = tid; idx0 < n4; idx0 += 8 * kThreads) {
+            uint32_t ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int idx = idx0 + u * kThreads; ov[u] = em.old_word(pl, (int64_t)(idx < n4 ? idx : idx0) * 4); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = idx0 + u * kThreads;
+                if (idx < n4) em.put_bytes4(pl, (int64_t)idx * 4, word_of(idx), true, ov[u]);
+            }
+        }
+    };
     const int nxz4 = (X * Z) >> 2;
-    for (int idx = tid; idx < nxz4; idx += kThreads)
-        em.put_bytes4(0, (int64_t)idx * 4, *reinterpret_cast<const uint32_t*>(xz_s + idx * 4));
+    emit_plane(0, nxz4, [&](int idx) { return *reinterpret_cast<const uint32_t*>(xz_s + idx * 4); });
     const int nyz4 = (Y * Z) >> 2;
     const int nw = X < 4 ? X : 4;       // waves that saw a plane
-    for (int idx = tid; idx < nyz4; idx += kThreads) {
+    emit_plane(1, nyz4, [&](int idx) {
         uint32_t lo = 0u, hi = 0u;
         for (int w = 0; w < nw; ++w) {
             const uint32_t v = *reinterpret_cast<const uint32_t*>(yz_s + (size_t)w * Y * Z + idx * 4);
             lo = pkmax_u16(lo, v & 0x00FF00FFu);
             hi = pkmax_u16(hi, (v >> 8) & 0x00FF00FFu);
         }
-        em.put_bytes4(1, (int64_t)idx * 4, lo | (hi << 8));
-    }
+        return lo | (hi << 8);
+    });
     const int nxy = X * Y, nxy4 = nxy >> 2;
-    for (int idx = tid; idx < nxy4; idx += kThreads)
-        em.put_bytes4(2, (int64_t)idx * 4, *reinterpret_cast<const uint32_t*>(xy_s + idx * 4));
+    emit_plane(2, nxy4, [&](int idx) { return *reinterpret_cast<const uint32_t*>(xy_s + idx * 4); });
     for (int idx = nxy4 * 4 + tid; idx < nxy; idx += kThreads) em.put1(2, idx, (float)xy_s[idx]);
     em.finish(red);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -146,7 +147,29 @@ struct ProjOut {
     // the predicated (usually skipped) second pass of the fused pipeline: launch without the LDS pad of share_cu, so that its
     // workgroups can start -- and exit at once -- on CUs whose LDS a resident projection workgroup of the next chunk holds
     int no_pad;
+    // Read-compare-write of the code rows: read the old 4 / 16 bytes and store only what changed (always correct: whatever the row
+    // held before, it holds the new codes afterwards).  Radar projections are mostly background -- 17 % / 9 % of the codes of a
+    // Walabot / 64x64x128 frame are non-zero -- and the rows land in buffers that are re-used batch after batch (the chunk workspaces
+    // of the fused pipelines, a caller's code buffer), so most of a row's HBM WRITE traffic -- what the streaming kernels pay
+    // 3-15 % for, DESIGN.md 3.1b' -- becomes reads.  The kernels put the old words of a region in flight together (Emitter::old_word).
+    int q_rmw;
 };
+// rml_code_rmw: the default of ProjOut::q_rmw in the fused pipelines, for frames of frame_bytes volume bytes and D codes.  The
+// read-back costs its bytes whatever the rows hold and the stores it saves depend on the data, so the rule is what was measured
+// (tools/exp/README.md round 4, two boxes, interleaved A/B of whole bench rounds, synthetic frames with the sparsity above):
+//   rows / frame   8.3 %  uint8 Walabot      -2.5 %            off
+//                  3.9 %  uint8 64x64x128    +3.9 / +4.0 %     on
+//                  2.1 %  float32 Walabot    +0.7 / +1.1 %     on
+//                  1.0 %  float32 64x64x128  +0.4 / -0.7 %     off (nothing to win: the rows are 1 % of the traffic)
+//   derive -> slice (the gather's stores sit in the streaming waves' instruction streams): +2.7 / +1.6 % and +0.5 / +1.0 %: on
+// The CNN chain's first pass keeps plain stores (5.98 / 5.97 M frames/s without, 5.87 / 5.96 with).
+// RML_CODE_RMW=0 / 1 forces it off / on (read per call: the tests flip it).
+inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive) {
+    const char* e = getenv("RML_CODE_RMW");
+    if (e && *e) return atoi(e) != 0;
+    if (D * 16 > frame_bytes) return 0;
+    return derive || D * 64 >= frame_bytes;
+}
 
 // true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then
 // pairs it with the 128x128 GEMM, whose workgroups fit beside it on a CU)

@@ -276,6 +276,39 @@ def test_fused_multi_chunk_deterministic(rml):
     np.testing.assert_array_equal(a["label_vote"][4000:4400].cpu().numpy(), O.svm_vote_labels(want, 3))
 
 
+@pytest.mark.parametrize("name,shape", [("svm_small.npz", (8, 10, 16)), ("svm_walabot.npz", (22, 31, 176))])
+@pytest.mark.parametrize("u8", [False, True])
+@pytest.mark.parametrize("derive", [False, True])
+def test_read_compare_write_of_the_code_rows_changes_nothing(rml, name, shape, u8, derive, monkeypatch):
+    """ProjOut::q_rmw (rml_internal.h): the chunk workspaces' code rows are read and only the words that changed are stored.
+    Whatever the workspace held -- here the rows of a different batch, of the same batch, and of a batch with frames off the
+    code grid -- the outputs are the bits of the plain stores."""
+    g = load_golden(name)
+    svc, m = _model(rml, g)
+    mask = rml.ProjMask(*[bool(b) for b in g["mask"]])
+    X, Y, Z = shape
+    B = 4096 * 2 + 77                                   # three chunks: two workspaces in rotation
+    batches = []
+    for seed in (3, 4):
+        v, _ = rml.synth_volumes(B, X, Y, Z, seed=seed)
+        batches.append(v.to(torch.uint8) if u8 else v)
+    if not u8:
+        off = batches[1].clone()
+        off[5, 1, 2, 3] = 0.25                          # its tile leaves the exact path
+        batches.append(off)
+    kw = dict(mode="slice") if derive else dict(mode="max")      # slice without ijk: the fused derive -> slice -> SVM pass
+    want = []
+    monkeypatch.setenv("RML_CODE_RMW", "0")
+    for v in batches:
+        want.append({k: t.clone() for k, t in svc.decide_volumes(v, proj_mask=mask, scale=True, **kw).items()})
+    monkeypatch.setenv("RML_CODE_RMW", "1")
+    for order in ((0, 1, 1, 0), (2, 0, 2) if not u8 else (1, 0)):
+        for i in order:
+            got = svc.decide_volumes(batches[i], proj_mask=mask, scale=True, **kw)
+            for k in want[i]:
+                assert torch.equal(got[k], want[i][k]), (k, i)
+
+
 def test_linear_classifier_golden(rml):
     g = load_golden("linear_golden.npz")
     clf = rml.GpuLinearClassifier(g["coef"], g["intercept"], g["classes"], g["calib_a"], g["calib_b"])
