@@ -444,6 +444,139 @@ __global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ ima
     }
 }
 
+// k_c1_bwd1_pk<BF, NB>: the same pass for C = 128 and rows of W = 8 * NB pixels, written for the VALU it is bound by.  k_c1_bwd1<., 4>
+// issues ~160 vector instructions per pixel and thread of which 36 are the packed FMAs the sums need (rocprof: 134 us per branch
+// at configs[4] = the kernel's own instruction count at 2 waves per SIMD; the 268 MB of dy would take 42 us): address arithmetic of
+// the nine LDS reads, register copies that duplicate a tap into both halves of a packed operand, row-end tests.  Here a pixel's taps
+// arrive as three pairs + three singles (ds_read_b64 on an even row stride) and feed v_pk_fma_f32 through op_sel -- the tap is
+// broadcast by the instruction, not by a copy --, the pixel loop has no bounds, and the next row's gradients and image rows are
+// in flight (registers / the other LDS buffer) while this row is summed: one barrier per row.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 p) {       // a * p.lo
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
+    return r;
+}
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.lo
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(p));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.hi
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(p));
+}
+
+template <bool BF, int NB>
+__global__ __launch_bounds__(kT) void k_c1_bwd1_pk(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
+                                                   int64_t N, int H, int ph, int pw, const float* mean, const float* rstd,
+                                                   const float* gamma, const float* beta, float slope, float* part /* [G][11][128] */) {
+    constexpr int C = 128, CPT = 4, CG = 32, PL = 8, W = NB * PL;
+    constexpr int IW = 2 * W + 1, IWp = IW + 1;         // even row stride: a pixel's taps (2w, 2w+1), (2w+2, -) are aligned pairs
+    constexpr int NS = (3 * IW + kT - 1) / kT;          // staged image values per thread and row
+    __shared__ __align__(16) float lds[kT * 8];         // two image buffers [3][IWp]; the reductions afterwards
+    constexpr int BS = 3 * IWp + 2;                     // buffer stride; [3 * IWp] is a slot for the staging threads past the rows
+    static_assert(2 * BS <= kT * 8, "image rows do not fit");
+    const int Wp = W + pw, Hp = H + ph, IH = 2 * H + 1;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    f32x2 wk[9][2], acc[11][2], mu[2], rs[2], ga[2], be[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wk[k][i] = f32x2{wgt[k * C + cg * CPT + 2 * i], wgt[k * C + cg * CPT + 2 * i + 1]};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) acc[k][0] = acc[k][1] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = cg * CPT + 2 * i;
+        mu[i] = f32x2{mean[c], mean[c + 1]}; rs[i] = f32x2{rstd[c], rstd[c + 1]};
+        ga[i] = f32x2{gamma[c], gamma[c + 1]}; be[i] = f32x2{beta[c], beta[c + 1]};
+    }
+    const f32x2 sl2 = f32x2{slope, slope};
+    const int64_t rows = N * H;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 dq[NB], dqn[NB];
+    uint16_t img[NS];
+    auto load_row = [&](int64_t row, u32x2 (&d)[NB]) __attribute__((always_inline)) {
+        const int64_t n = row / H;
+        const int h = (int)(row - n * H);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i0 = tid + s * kT, i = i0 < 3 * IW ? i0 : 3 * IW - 1, ky = i / IW, xx = i - ky * IW;      // unconditional (clamped):
+            img[s] = image[(n * IH + 2 * h + ky) * (int64_t)IW + xx];                          // a branch here drains the queue
+        }
+        const uint16_t* dyr = dy + ((n * Hp + h) * (int64_t)Wp) * C + cg * CPT;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) d[u] = *reinterpret_cast<const u32x2*>(dyr + (int64_t)(pl + u * PL) * C);
+    };
+    auto stage = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + s * kT, ky = i / IW, xx = i - ky * IW;
+            buf[i < 3 * IW ? ky * IWp + xx : 3 * IWp] = h2f<BF>(img[s]);        // unconditional: hipcc sinks the LOAD into a branch here
+        }
+    };
+    int64_t row = blockIdx.x;
+    int cur = 0;
+    if (row < rows) {
+        load_row(row, dq);
+        stage(lds);
+        if (tid < 3) { lds[tid * IWp + IW] = 0.0f; lds[BS + tid * IWp + IW] = 0.0f; }     // the unused half of the last pair
+    }
+    __syncthreads();
+    for (; row < rows; row += gridDim.x) {
+        const int64_t nxt = row + gridDim.x < rows ? row + gridDim.x : row;     // past the end: this row again (never used)
+        load_row(nxt, dqn);
+        __builtin_amdgcn_sched_barrier(0);              // the loads stay here (left alone hipcc sinks them below the sums: a full latency per row)
+        const float* buf = lds + cur * BS + 2 * pl;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            f32x2 P[3][2];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                P[ky][0] = *reinterpret_cast<const f32x2*>(buf + ky * IWp + 2 * u * PL);
+                P[ky][1] = *reinterpret_cast<const f32x2*>(buf + ky * IWp + 2 * u * PL + 2);
+            }
+            f32x2 d[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t q = dq[u][i];
+                d[i] = f32x2{h2f<BF>((uint16_t)(q & 0xFFFFu)), h2f<BF>((uint16_t)(q >> 16))};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // the convolution output again, in the tap order of the forward pass (k = 0 first: fma(w, t, 0) is the product)
+                f32x2 v = pk_mul_lo(wk[0][i], P[0][0]);
+                pk_fma_hi(v, wk[1][i], P[0][0]); pk_fma_lo(v, wk[2][i], P[0][1]);
+                pk_fma_lo(v, wk[3][i], P[1][0]); pk_fma_hi(v, wk[4][i], P[1][0]); pk_fma_lo(v, wk[5][i], P[1][1]);
+                pk_fma_lo(v, wk[6][i], P[2][0]); pk_fma_hi(v, wk[7][i], P[2][0]); pk_fma_lo(v, wk[8][i], P[2][1]);
+                const f32x2 xh = (v - mu[i]) * rs[i];
+                const f32x2 zz = xh * ga[i] + be[i];
+                const f32x2 ds = d[i] * sl2;
+                const f32x2 g = f32x2{zz.x > 0.0f ? d[i].x : ds.x, zz.y > 0.0f ? d[i].y : ds.y};
+                acc[9][i] += g;
+                acc[10][i] = __builtin_elementwise_fma(g, xh, acc[10][i]);
+                pk_fma_lo(acc[0][i], g, P[0][0]); pk_fma_hi(acc[1][i], g, P[0][0]); pk_fma_lo(acc[2][i], g, P[0][1]);
+                pk_fma_lo(acc[3][i], g, P[1][0]); pk_fma_hi(acc[4][i], g, P[1][0]); pk_fma_lo(acc[5][i], g, P[1][1]);
+                pk_fma_lo(acc[6][i], g, P[2][0]); pk_fma_hi(acc[7][i], g, P[2][0]); pk_fma_lo(acc[8][i], g, P[2][1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(lds + (cur ^ 1) * BS);               // the next row's image rows: their loads went out before this row's sums
+#pragma unroll
+        for (int u = 0; u < NB; ++u) dq[u] = dqn[u];
+        cur ^= 1;
+        __syncthreads();
+    }
+    for (int k = 0; k < 11; ++k) {
+        __syncthreads();
+        lds[tid * CPT + 0] = acc[k][0].x; lds[tid * CPT + 1] = acc[k][0].y; lds[tid * CPT + 2] = acc[k][1].x; lds[tid * CPT + 3] = acc[k][1].y;
+        __syncthreads();
+        for (int c = tid; c < C; c += kT) {
+            float s = 0.0f;
+            for (int q = 0; q < PL; ++q) s += lds[(q * CG + (c / CPT)) * CPT + (c % CPT)];
+            part[((size_t)blockIdx.x * 11 + k) * C + c] = s;
+        }
+    }
+}
+
 // sums [11][C] (A, sum g, sum g*x_hat) and img [54] (B, packed upper triangle of T2) -> dW[9][C], dgamma, dbeta
 __global__ void k_c1_wgrad_combine(const float* sums, const float* img, const float* wgt, const float* mean, const float* rstd,
                                    const float* gamma, int C, double M, float* dweight, float* dgamma, float* dbeta) {
@@ -629,7 +762,7 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t M = N * H * W;
-    const int G = stats_grid(ctx, M, C);
+    int G = stats_grid(ctx, M, C);
     const uint16_t* is = static_cast<const uint16_t*>(image);
     const uint16_t* ds = static_cast<const uint16_t*>(dy);
     // workspace: [G][11][C] partials | sums [11][C]
@@ -639,7 +772,22 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     // four channels per thread where the channel groups divide the workgroup (C = 128: 32 groups x 8 pixels); RML_C1_CPT=8: round 2's
     static const bool cpt8 = [] { const char* e = getenv("RML_C1_CPT"); return e && atoi(e) == 8; }();
     const bool four = !cpt8 && C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
-    if (four) {
+    // C = 128 and rows of 16 / 32 / 64 pixels: the packed kernel (RML_C1_PK=0: the general one)
+    static const bool pk_on = [] { const char* e = getenv("RML_C1_PK"); return !e || atoi(e) != 0; }();
+    const bool pk = pk_on && !cpt8 && C == 128 && (W == 16 || W == 32 || W == 64);
+    if (pk) {
+        // one round of resident workgroups (166 registers at W = 64: three per CU), rows strided over them
+        auto go = [&](auto bf, auto nb) {
+            constexpr bool BFV = decltype(bf)::value;
+            constexpr int NBV = decltype(nb)::value;
+            static const int per_cu = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_c1_bwd1_pk<BFV, NBV>, kT, 0) == hipSuccess && n > 0 ? n : 2; }();
+            G = std::min(G, per_cu * ctx->num_cu);
+            hipLaunchKernelGGL((k_c1_bwd1_pk<BFV, NBV>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
+        };
+        using T = std::true_type; using F = std::false_type;
+        if (dtype) { if (W == 64) go(T{}, std::integral_constant<int, 8>{}); else if (W == 32) go(T{}, std::integral_constant<int, 4>{}); else go(T{}, std::integral_constant<int, 2>{}); }
+        else { if (W == 64) go(F{}, std::integral_constant<int, 8>{}); else if (W == 32) go(F{}, std::integral_constant<int, 4>{}); else go(F{}, std::integral_constant<int, 2>{}); }
+    } else if (four) {
         if (dtype) hipLaunchKernelGGL((k_c1_bwd1<true, 4>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
         else hipLaunchKernelGGL((k_c1_bwd1<false, 4>), dim3(G), dim3(kT), 0, st, is, weight, ds, N, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope, part);
     } else {

@@ -177,6 +177,88 @@ def preprocess_volumes(volumes, rescale, mode="max", ijk=None):
     return outs
 
 
+class fused_step_scope:
+    """Collects the small side effects of the fused SGAN layers over one forward pass and applies them as multi-tensor launches
+    on exit: ``num_batches_tracked += 1`` and the running-mean correction for the dropped convolution bias of every
+    ``bn_lrelu_pad`` / ``conv1_bn_lrelu_pad`` layer (18 launches of ~4.5 us per forward of the three-branch discriminator ->
+    2; the step is GPU-bound and a third of its 480 launches are kernels of that size, `tools/step_gaps.py`).
+    ``bias_grads=False``: the backward of those layers hands back no gradient for the dropped convolution bias instead of a
+    tensor of zeros (it IS exactly zero; Adam leaves a parameter without gradient alone, which is what a zero gradient does to
+    it) -- torch's DistributedDataParallel needs the zeros, nothing else does."""
+    active = None
+
+    def __init__(self, bias_grads=True):
+        self.bias_grads = bool(bias_grads)
+        self.items = []                 # (bn, conv_bias or None)
+
+    def __enter__(self):
+        self.prev = fused_step_scope.active
+        fused_step_scope.active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        fused_step_scope.active = self.prev
+        if et is None:
+            self.flush()
+        return False
+
+    def flush(self):
+        torch = _torch()
+        if not self.items:
+            return
+        with torch.no_grad():
+            torch._foreach_add_([bn.num_batches_tracked for bn, _ in self.items], 1)
+            by_m = {}
+            for bn, b in self.items:
+                if b is not None:
+                    by_m.setdefault((float(bn.momentum), bn.running_mean.dtype), []).append((bn.running_mean, b.detach()))
+            for (m, dt), pairs in by_m.items():
+                torch._foreach_add_([rm for rm, _ in pairs], [b if b.dtype == dt else b.to(dt) for _, b in pairs], alpha=m)
+        self.items = []
+
+
+def _bn_side_effects(bn, conv_bias):
+    """after a fused training-mode batch norm: the batch counter, and the running mean of conv(x) + bias (the kernel tracked the
+    mean of the bias-free activations; eval mode and the unfused layers normalise conv(x) + bias, whose mean is larger by exactly
+    the bias: running_mean += momentum * bias keeps both in step) -- now, or at the end of the enclosing fused_step_scope"""
+    torch = _torch()
+    sc = fused_step_scope.active
+    if sc is not None:
+        sc.items.append((bn, conv_bias))
+        return
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        if conv_bias is not None:
+            bn.running_mean.add_(conv_bias.detach().to(bn.running_mean.dtype), alpha=float(bn.momentum))
+
+
+def cast_all(dtype, *tensors):
+    """``[t.to(dtype) for t in tensors]`` as ONE multi-tensor launch forward and one backward (autocast casts every weight where
+    it is used: a ~4.5 us launch per parameter in each direction)."""
+    torch = _torch()
+    if getattr(cast_all, "_cls", None) is None:
+        class CastAll(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, dtype, *ws):
+                outs = [torch.empty_like(w, dtype=dtype) for w in ws]          # empty_like keeps channels_last kernels as they are
+                torch._foreach_copy_(outs, list(ws))
+                ctx.src_dtypes = [w.dtype for w in ws]
+                return tuple(outs)
+
+            @staticmethod
+            def backward(ctx, *gs):
+                idx = [i for i, g in enumerate(gs) if g is not None]
+                outs = [torch.empty_like(gs[i], dtype=ctx.src_dtypes[i]) for i in idx]
+                if idx:
+                    torch._foreach_copy_(outs, [gs[i] for i in idx])
+                res = [None] * len(gs)
+                for i, o in zip(idx, outs):
+                    res[i] = o
+                return (None, *res)
+        cast_all._cls = CastAll
+    return cast_all._cls.apply(dtype, *tensors)
+
+
 def _bn_lrelu_pad_function():
     """torch.autograd.Function around csrc/bnact.hip (built lazily: torch is imported on first use)."""
     torch = _torch()
@@ -205,7 +287,8 @@ def _bn_lrelu_pad_function():
                     _lib.ptr(rstd), _lib.ptr(ws), _lib.ptr(y), _lib.stream_ptr(dev)), "rml_bn_lrelu_pad_forward")
             ctx.save_for_backward(x, gamma, beta, mean, rstd)
             ctx.meta = (float(slope), int(pad))
-            ctx.bias_like = conv_bias
+            sc = fused_step_scope.active
+            ctx.bias_like = conv_bias if (sc is None or sc.bias_grads) else None
             return y
 
         @staticmethod
@@ -254,12 +337,7 @@ def bn_lrelu_pad(x, bn, slope=0.2, pad=0, conv_bias=None):
         x = x.contiguous(memory_format=torch.channels_last)
     y = _bn_lrelu_pad_function().apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope, pad,
                                        conv_bias)
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
-        if conv_bias is not None:
-            # the kernel tracked the mean of the bias-free activations; eval mode (and the unfused layers) normalise
-            # conv(x) + bias, whose mean is larger by exactly the bias: running_mean += momentum * bias keeps both in step
-            bn.running_mean.add_(conv_bias.detach().to(bn.running_mean.dtype), alpha=float(bn.momentum))
+    _bn_side_effects(bn, conv_bias)
     return y
 
 
@@ -283,7 +361,8 @@ def _conv1_bn_lrelu_pad_function():
             lib = _lib.load()
             xh = x_padded.to(dtype).contiguous()                               # (N, 1, 2H+1, 2W+1), half
             c = weight.shape[0]
-            wk = weight.to(dtype).float().reshape(c, 9).t().contiguous()       # [tap][c], rounded like the autocast operand
+            # [tap][c], rounded like the autocast operand (transpose + rounding in one copy, widening in a second)
+            wk = weight.reshape(c, 9).t().to(dtype, memory_format=torch.contiguous_format).float()
             n = xh.shape[0]
             h, w = (xh.shape[2] - 1) // 2, (xh.shape[3] - 1) // 2
             dev = xh.device
@@ -301,7 +380,8 @@ def _conv1_bn_lrelu_pad_function():
                     "rml_conv1_bn_lrelu_pad_forward")
             ctx.save_for_backward(xh, wk, gamma, beta, mean, rstd, istat)
             ctx.meta = (float(slope), int(pad), weight.shape, weight.dtype, h, w)
-            ctx.bias_like = conv_bias
+            sc = fused_step_scope.active
+            ctx.bias_like = conv_bias if (sc is None or sc.bias_grads) else None
             return y
 
         @staticmethod
@@ -337,8 +417,5 @@ def conv1_bn_lrelu_pad(x_padded, conv, bn, slope, pad, dtype):
     torch = _torch()
     y = _conv1_bn_lrelu_pad_function().apply(x_padded, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                              bn.eps, bn.momentum, slope, pad, dtype)
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
-        if conv.bias is not None:       # see bn_lrelu_pad: running statistics of conv(x) + bias
-            bn.running_mean.add_(conv.bias.detach().to(bn.running_mean.dtype), alpha=float(bn.momentum))
+    _bn_side_effects(bn, conv.bias)
     return y

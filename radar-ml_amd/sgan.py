@@ -46,13 +46,16 @@ class Discriminator(_nn().Module):
         self.fc3 = nn.Linear(64, n_classes)
         self.act = nn.LeakyReLU(0.2)
         self.drop = nn.Dropout(0.5)
+        # backward of the fused conv + batch-norm layers: zeros for the (cancelled) convolution bias, or no gradient at all
+        # (nn_common.fused_step_scope; DiscriminatorTrainer turns the zeros off unless torch's DDP wraps the model)
+        self.zero_bias_grads = True
         for mod in self.modules():
             if isinstance(mod, (nn.Conv2d, nn.Linear)):
                 nn.init.normal_(mod.weight, 0.0, 0.02)      # RandomNormal(stddev=0.02), sgan.py:176
                 nn.init.zeros_(mod.bias)
 
     @staticmethod
-    def _branch(x, br):
+    def _branch(x, br, half=None):
         """[Conv2D 'same' s2 + BatchNorm + LeakyReLU] x 3 (sgan.py:137-158).  On the GPU under half-precision autocast and
         in training mode: batch norm + LeakyReLU + the bottom/right zero pad of the next convolution are one fused HIP op
         (nn_common.bn_lrelu_pad), the convolutions run without their bias (batch norm cancels it; its gradient is exactly
@@ -80,18 +83,33 @@ class Discriminator(_nn().Module):
                     and c % 8 == 0 and 256 % (c // 8) == 0 and bn.track_running_stats and bn.affine and bn.momentum is not None):
                 x = conv1_bn_lrelu_pad(x, conv, bn, act.negative_slope, pad, adt)
                 continue
-            z = F.conv2d(x, conv.weight, None, stride=2)
+            z = F.conv2d(x, half[conv.weight] if half else conv.weight, None, stride=2)
             x = bn_lrelu_pad(z, bn, act.negative_slope, pad=pad, conv_bias=conv.bias)
         return x
 
     def forward(self, xz, yz, xy):
         """Pre-activation class scores (N, n_classes) -- the shared ``cls`` tensor of sgan.py:199."""
         import torch
-        outs = [self._branch(x, br) for x, br in zip((xz, yz, xy), self.branches)]
+        import torch.nn.functional as F
+        from .nn_common import cast_all, fused_step_scope
+        adt = torch.get_autocast_dtype("cuda") if (xz.is_cuda and torch.is_autocast_enabled("cuda")) else None
+        if not (self.training and adt in (torch.float16, torch.bfloat16)):
+            outs = [self._branch(x, br) for x, br in zip((xz, yz, xy), self.branches)]
+            fv = flatten_nhwc(torch.cat(outs, dim=1))
+            h = self.drop(self.act(self.bn1(self.fc1(fv))))
+            h = self.drop(self.act(self.bn2(self.fc2(h))))
+            return self.fc3(h)
+        # training under half-precision autocast on the GPU: the weights the matrix cores read are cast in one launch (and
+        # their gradients cast back in one), the batch-norm bookkeeping of the fused layers is applied in two (nn_common)
+        ws = [layers[i].conv.weight for layers in (list(br) for br in self.branches) for i in range(3, len(layers), 3)]
+        ws += [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.fc3.weight, self.fc3.bias]
+        half = dict(zip(ws, cast_all(adt, *ws)))
+        with fused_step_scope(bias_grads=self.zero_bias_grads):
+            outs = [self._branch(x, br, half) for x, br in zip((xz, yz, xy), self.branches)]
         fv = flatten_nhwc(torch.cat(outs, dim=1))
-        h = self.drop(self.act(self.bn1(self.fc1(fv))))
-        h = self.drop(self.act(self.bn2(self.fc2(h))))
-        return self.fc3(h)
+        h = self.drop(self.act(self.bn1(F.linear(fv, half[self.fc1.weight], half[self.fc1.bias]))))
+        h = self.drop(self.act(self.bn2(F.linear(h, half[self.fc2.weight], half[self.fc2.bias]))))
+        return F.linear(h, half[self.fc3.weight], half[self.fc3.bias])
 
 
     # ---- Keras layout in / out -------------------------------------------------------------------------
@@ -232,6 +250,7 @@ class DiscriminatorTrainer:
             mode = None
         self.ddp_mode = mode
         self._flat = None
+        model.zero_bias_grads = mode == "torch"         # DDP wants a gradient for every parameter; Adam does not (exactly zero)
         if mode == "torch":
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.net = DDP(model, device_ids=[self.device.index] if self.device.type == "cuda" else None,

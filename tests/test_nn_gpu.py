@@ -614,6 +614,18 @@ def test_sgan_trainer_hip_graph_matches_eager(rml):
     assert "graph" in trs[1]._graphs["c"] and "graph" in trs[1]._graphs["d"]
     a, b = np.array(hist[0]), np.array(hist[1])
     assert np.abs(a - b).max() < 2e-2, (a, b)
+    # the batch-norm bookkeeping of the fused layers is applied once per forward as multi-tensor launches (nn_common.fused_step_scope):
+    # every counter saw 14 forwards, the running statistics of the two trainers agree, and the convolution biases in front of a batch
+    # norm -- whose gradient is exactly zero and is not materialised in the trainer -- have not moved
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    for k in sd0:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd0[k]) == 14 and int(sd1[k]) == 14, k
+        elif "running_" in k:
+            assert (sd0[k] - sd1[k]).abs().max() <= 2e-3 * (1 + sd0[k].abs().max()), k
+        elif k.endswith(".conv.bias"):
+            assert torch.equal(sd0[k], base.state_dict()[k]) and torch.equal(sd1[k], base.state_dict()[k]), k
+    assert all(m.conv.bias.grad is None for br in nets[1].branches for m in list(br)[0::3])
 
 
 def _sgan_param_class(name):
