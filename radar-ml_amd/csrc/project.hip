@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     }
 
     Emitter em(a, b);
+    em.rmw = false;                                     // plain stores here (see Emitter::rmw)
     // yz straight from registers: lane owns (j_m, 4kq..4kq+3)
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
     }
 
     Emitter em(a, b);
+    em.rmw = false;                                     // plain stores here (see Emitter::rmw)
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int j = slot + R * m;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
     };
     constexpr int PPT = NG == 1 ? 2 : 1;                // planes per trip; whole-plane buffers need an even X
     Emitter em(a, cf);
+    em.rmw = false;                                     // plain stores here (see Emitter::rmw)
     extern __shared__ __align__(16) unsigned char wave_dyn[];      // codes-only launches: the wave's code stage (see Emitter::stage)
     if (a.stage_bytes) em.set_stage(wave_dyn + wave * a.stage_bytes, (X * Zr + 15) & ~15);
     fetch(buf[0], std::integral_constant<int, 0>{});    // group 0 of the first plane
@@ -381,14 +384,9 @@ __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_pr
         int lane_f = lane, Y_f = Y;
         asm volatile("" : "+v"(lane_f), "+s"(Y_f));
         const bool act_f = lane_f < ZQ;
-        uint32_t oldw[NY];                                  // read-compare-write of the code rows: all old words in flight at once
         static_for<NY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            oldw[j] = em.old_word(1, (j < Y_f && act_f) ? (int64_t)j * Z + 4 * lane_f : 0);
-        });
-        static_for<NY>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j], true, oldw[j]);
+            if (j < Y_f && act_f) em.put4(1, (int64_t)j * Z + 4 * lane_f, yz[j]);
         });
         em.flush_wave(lane_f);
         em.finish_wave(lane_f);

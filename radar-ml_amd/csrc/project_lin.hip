@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
         });
     };
     Emitter em(a, cf);
+    em.rmw = false;                                     // plain stores here (see Emitter::rmw)
     if (a.stage_bytes) {                                // codes-only launches: the wave's code stage behind the images (Emitter::stage)
         em.set_stage(lin_smem + (size_t)4 * (NI * 64 * sizeof(float4) + NT * 64 * sizeof(float)) + wave * a.stage_bytes, (X * Z + 15) & ~15);
     }
@@ -148,16 +149,10 @@ __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
         // yz leaves linearly: quad q of the plane = 4 consecutive values of the yz row image
         int lane_f = lane, pq_f = pq;
         asm volatile("" : "+v"(lane_f), "+s"(pq_f));
-        uint32_t oldw[NT];                                  // read-compare-write of the code rows: all old words in flight at once
         static_for<NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int q = t * 64 + lane_f;
-            oldw[t] = em.old_word(1, (int64_t)(q < pq_f ? q : 0) * 4);
-        });
-        static_for<NT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int q = t * 64 + lane_f;
-            if (q < pq_f) em.put4(1, (int64_t)q * 4, yz[t], true, oldw[t]);
+            if (q < pq_f) em.put4(1, (int64_t)q * 4, yz[t]);
         });
         em.flush_wave(lane_f);
         em.finish_wave(lane_f);

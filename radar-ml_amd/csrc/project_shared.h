@@ -76,6 +76,10 @@ struct Emitter {
     int ok = 1;
     double nsq = 0.0;
     bool want_stats;
+    // read-compare-write of the code rows (ProjOut::q_rmw).  A member and not the launch argument: the float32 max kernels set it to
+    // false after construction -- their stores then compile to what they were before (with the test and the prefetched old words in
+    // place k_project_lin lost 9 % in situ at the Walabot grid, session r4be) --, and inside an `if (!em.rmw)` block the test folds away
+    bool rmw;
     // Codes-only launches of the wave-per-frame kernels: a frame's xz and xy codes are finished plane by plane -- a 176-byte and a
     // 31-byte store per 21.8 KB plane at the Walabot grid, from each of 2 048 waves -- and those small writes, scattered in time
     // between the reads, cost the streaming kernels far more than their bytes (stand-alone, Walabot grid: 0.70 of 8 TB/s with them,
@@ -93,6 +97,7 @@ struct Emitter {
 
     __device__ Emitter(const ProjParams& a_, int64_t b_) : a(a_), b(b_) {
         want_stats = a.o.row_isum || a.o.row_isq || a.o.row_flags || a.o.q[0] || a.o.q[1] || a.o.q[2];
+        rmw = a.o.q_rmw != 0;
     }
     __device__ __forceinline__ float scaled(float v) const {
         // true IEEE division: bit-identical to NumPy's float32 "x / 255." (common.py:148)
@@ -130,7 +135,7 @@ struct Emitter {
     // Read-compare-write of the code rows (ProjOut::q_rmw): the dword a later put4 / put_bytes4 of (pl, idx) would overwrite, so that
     // a kernel can have the old words of a whole region in flight before it compares the first one
     __device__ __forceinline__ uint32_t old_word(int pl, int64_t idx) const {
-        if (!(a.o.q_rmw && a.o.q[pl] && ((a.o.sel >> pl) & 1u))) return 0u;
+        if (!(rmw && a.o.q[pl] && ((a.o.sel >> pl) & 1u))) return 0u;
         return *reinterpret_cast<const uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
     }
     // four projection values that ARE bytes (uint8 volumes; idx a multiple of 4): when only codes and their statistics are
@@ -147,7 +152,7 @@ struct Emitter {
             if (a.o.q[pl]) {
                 uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
                 const uint32_t nv = w ^ 0x80808080u;
-                if (!a.o.q_rmw || (have_old ? old : *dq) != nv) *dq = nv;
+                if (!rmw || (have_old ? old : *dq) != nv) *dq = nv;
             }
 #endif
         }
@@ -183,7 +188,7 @@ struct Emitter {
 #else
                 else {
                     uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
-                    if (!a.o.q_rmw || (have_old ? old : *dq) != packed) *dq = packed;
+                    if (!rmw || (have_old ? old : *dq) != packed) *dq = packed;
                 }
 #endif
             }
@@ -206,52 +211,17 @@ struct Emitter {
         for (int r = 0; r < 2; ++r) {
             int done = 0;
             if ((reinterpret_cast<uintptr_t>(dst[r]) & 15) == 0) {
-                const int n16 = len[r] >> 4;
-                u32x4* dq = reinterpret_cast<u32x4*>(dst[r]);
-                if (a.o.q_rmw) {
-                    // the old words of four stores in flight, then compare and store what changed
-                    for (int i0 = lane; i0 < n16; i0 += 4 * 64) {
-                        u32x4 ov[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; ov[u] = dq[i < n16 ? i : i0]; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = i0 + 64 * u;
-                            if (i < n16) {
-                                const u32x4 nv = ((lds_u128*)src[r])[i];
-                                if (((ov[u].x ^ nv.x) | (ov[u].y ^ nv.y) | (ov[u].z ^ nv.z) | (ov[u].w ^ nv.w)) != 0) dq[i] = nv;
-                            }
-                        }
-                    }
-                } else {
-                    for (int i = lane; i < n16; i += 64) {
+                for (int i = lane; i < (len[r] >> 4); i += 64) {
 #if RML_CODE_NT
-                        __builtin_nontemporal_store(((lds_u128*)src[r])[i], dq + i);
+                    __builtin_nontemporal_store(((lds_u128*)src[r])[i], reinterpret_cast<u32x4*>(dst[r]) + i);
 #else
-                        dq[i] = ((lds_u128*)src[r])[i];
+                    reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
 #endif
-                    }
                 }
                 done = len[r] & ~15;
             }
-            // rows are 4-byte aligned (rml_project's contract)
-            const int n4 = (len[r] - done) >> 2;
-            uint32_t* dw = reinterpret_cast<uint32_t*>(dst[r] + done);
-            lds_u32* sw = (lds_u32*)(src[r] + done);
-            if (a.o.q_rmw) {
-                for (int i0 = lane; i0 < n4; i0 += 4 * 64) {
-                    uint32_t ov[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; ov[u] = dw[i < n4 ? i : i0]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + 64 * u;
-                        if (i < n4) { const uint32_t nv = sw[i]; if (ov[u] != nv) dw[i] = nv; }
-                    }
-                }
-            } else {
-                for (int i = lane; i < n4; i += 64) dw[i] = sw[i];
-            }
+            for (int i = done + 4 * lane; i + 4 <= len[r]; i += 256)       // rows are 4-byte aligned (rml_project's contract)
+                *reinterpret_cast<uint32_t*>(dst[r] + i) = *(lds_u32*)(src[r] + i);
             for (int i = (len[r] & ~3) + lane; i < len[r]; i += 64) dst[r][i] = src[r][i];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -35,7 +35,7 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
 
-template <int NM, bool PRED, int FCPR>
+template <int NM, bool PRED, int FCPR, bool RMW = false>
 // 192 registers: two of these workgroups and the 128-register waves of one k_svm_gemm workgroup share a SIMD's 512 in the fused pipeline
 __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int CPR_rt, int S) {
 #ifdef RML_PRIO_PROJ
@@ -181,8 +181,15 @@ __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int C
     __syncthreads();
 
     Emitter em(a, b);
-    // eight words per thread and trip: with read-compare-write of the code rows (ProjOut::q_rmw) their old words are in flight together
+    em.rmw = RMW;                       // compile-time here: the plain launch is the kernel it was before read-compare-write came
+    // plain stores: a word per thread and trip.  Read-compare-write of the code rows (ProjOut::q_rmw): eight words per thread and
+    // trip, their old words in flight together.  (The batched loop for both cost the plain path 10 % at the Walabot grid, whose
+    // planes are 1-6 words per thread -- sessions r4av / r4aw, 21.98 -> 19.95 M frames/s --, and a run-time choice between the two
+    // loops still 5 %: session r4bf, 22.35 -> 21.28.)
     auto emit_plane = [&](int pl, int n4, auto word_of) __attribute__((always_inline)) {
+        if constexpr (!RMW) {
+            for (int idx = tid; idx < n4; idx += kThreads) em.put_bytes4(pl, (int64_t)idx * 4, word_of(idx));
+        } else
         for (int idx0 = tid; idx0 < n4; idx0 += 8 * kThreads) {
             uint32_t ov[8];
 #pragma unroll
@@ -219,6 +226,9 @@ void launch_u8_max_f(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hip
     if (pp.o.skip_if_set) {
         RML_MAX_DYN_LDS(160 * 1024, (&k_project_u8_max<NM, true, FCPR>));
         hipLaunchKernelGGL((k_project_u8_max<NM, true, FCPR>), grid, block, lds_bytes, st, pp, CPR, S);
+    } else if (pp.o.q_rmw) {
+        RML_MAX_DYN_LDS(160 * 1024, (&k_project_u8_max<NM, false, FCPR, true>));
+        hipLaunchKernelGGL((k_project_u8_max<NM, false, FCPR, true>), grid, block, lds_bytes, st, pp, CPR, S);
     } else {
         RML_MAX_DYN_LDS(160 * 1024, (&k_project_u8_max<NM, false, FCPR>));
         hipLaunchKernelGGL((k_project_u8_max<NM, false, FCPR>), grid, block, lds_bytes, st, pp, CPR, S);

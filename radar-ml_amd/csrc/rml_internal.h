@@ -155,20 +155,22 @@ struct ProjOut {
     int q_rmw;
 };
 // rml_code_rmw: the default of ProjOut::q_rmw in the fused pipelines, for frames of frame_bytes volume bytes and D codes.  The
-// read-back costs its bytes whatever the rows hold and the stores it saves depend on the data, so the rule is what was measured
-// (tools/exp/README.md round 4, two boxes, interleaved A/B of whole bench rounds, synthetic frames with the sparsity above):
-//   rows / frame   8.3 %  uint8 Walabot      -2.5 %            off
-//                  3.9 %  uint8 64x64x128    +3.9 / +4.0 %     on
-//                  2.1 %  float32 Walabot    +0.7 / +1.1 %     on
-//                  1.0 %  float32 64x64x128  +0.4 / -0.7 %     off (nothing to win: the rows are 1 % of the traffic)
-//   derive -> slice (the gather's stores sit in the streaming waves' instruction streams): +2.7 / +1.6 % and +0.5 / +1.0 %: on
+// read-back costs its bytes (and, in a per-frame epilogue, its latency) whatever the rows hold; the stores it saves depend on the
+// data.  So the rule is what was measured (tools/exp/README.md round 4; synthetic frames with the sparsity above; sessions r4be /
+// r4bf: this library against the library of the commit before, three interleaved whole-round runs on one box):
+//   64x64x128 uint8 (rows 3.9 % of the frame): 7.41 -> 7.86 M frames/s (+6 %; +11 % on another box)                        on
+//   64x64x128 derive -> slice (rows 1 %): 2.193 -> 2.264 M (+3.2 %)                                                          on
+//   Walabot grid, uint8 (rows 8.3 %): -2.5 %;  derive -> slice (rows 2.1 %): 7.94 -> 7.89 M (-0.6 %; kernel in situ -7 %)      off
+//   float32 max projections: +0.7 / +1.1 % end to end at the Walabot grid and +-0.5 % at 64x64x128 against the same library
+//     without -- but the prefetched old words and the test in front of every store cost k_project_lin 9 % in situ (0.735 -> 0.665)
+//     and the headline 1 % against the library before: those kernels store plainly again (Emitter::rmw = false)              off
 // The CNN chain's first pass keeps plain stores (5.98 / 5.97 M frames/s without, 5.87 / 5.96 with).
-// RML_CODE_RMW=0 / 1 forces it off / on (read per call: the tests flip it).
-inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive) {
+// RML_CODE_RMW=0 / 1 forces it off / on where a kernel has it (read per call: the tests flip it).
+inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
     const char* e = getenv("RML_CODE_RMW");
     if (e && *e) return atoi(e) != 0;
-    if (D * 16 > frame_bytes) return 0;
-    return derive || D * 64 >= frame_bytes;
+    if (derive) return D * 64 <= frame_bytes;
+    return u8 && D * 64 >= frame_bytes && D * 16 <= frame_bytes;
 }
 
 // true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then

@@ -1863,7 +1863,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
         o.share_cu = part ? 0 : 1;
         if (derive && !small_gemm) o.share_cu = 0;       // taking turns with the ring GEMM: the stand-alone configuration
-        o.q_rmw = rml_code_rmw(m->D, frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4), derive);
+        o.q_rmw = rml_code_rmw(m->D, frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4), derive, vdtype == RML_VOL_U8);
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // fused derive -> slice: the first pass derives (i,j,k) per frame and slices there in one launch; a second pass (float rows

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-4 GPU session BF: float32 max kernels back on plain stores (Emitter::rmw = false), rule = uint8 + derive -- tests, then this library against commit c3ef2bc's on one box
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+O=gpurun_out/r4bf; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_projection_gpu.py tests/test_svm_gpu.py -x -q 2>&1 | tail -n 2
+B="python bench.py --steps 8 --warmup 3 --no-general --no-dnn --no-sgan --no-cpu --no-pmc --parity 1024"
+for rep in 1 2 3; do for k in old new; do
+  unset RML_LIB
+  if [ $k = old ]; then export RML_LIB=$PWD/radar-ml_amd/libradarml_hip_c3ef2bc.so; fi
+  timeout 900 $B > $O/${k}_$rep.json 2>> $O/b.err
+  python tools/exp/show_bench.py $O/${k}_$rep.json $k | grep -v "gate\|slice_mode" | cut -c1-125
+done; done
