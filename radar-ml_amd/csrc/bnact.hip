@@ -289,6 +289,115 @@ __global__ __launch_bounds__(kT) void k_c1_apply_pad(const uint16_t* __restrict_
     }
 }
 
+// packed float32 FMAs with one operand broadcast by the instruction (op_sel), not by a register copy
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 p) {       // a * p.lo
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
+    return r;
+}
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.lo
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(p));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.hi
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(p));
+}
+
+// k_c1_apply_pad_pk<BF, NB>: the same pass for C = 128 and rows of W = 8 * NB pixels.  The general kernel above waits for nine
+// dependent image loads per pixel and thread with nothing else in flight (3.7-3.9 TB/s of output: latency, not bandwidth); here
+// the three image rows of an output row go through LDS (the next row's are loaded while this one is computed), a pixel's taps are
+// aligned pairs feeding v_pk_fma_f32 through op_sel, a thread owns four channels (an 8-byte store; two pixels of a wave are 512
+// contiguous bytes).  Same products in the same order: bit-identical output.
+template <bool BF, int NB>
+__global__ __launch_bounds__(kT) void k_c1_apply_pad_pk(const uint16_t* __restrict__ image, const float* __restrict__ wgt, uint16_t* __restrict__ y,
+                                                        int64_t nrows, int H, int ph, int pw, const float* mean, const float* rstd,
+                                                        const float* gamma, const float* beta, float slope) {
+    constexpr int C = 128, CPT = 4, CG = 32, PL = 8, W = NB * PL;
+    constexpr int IW = 2 * W + 1, IWp = IW + 1;
+    constexpr int NS = (3 * IW + kT - 1) / kT;
+    constexpr int BS = 3 * IWp + 2;
+    __shared__ __align__(16) float lds[2 * BS];
+    const int Wp = W + pw, Hp = H + ph, IH = 2 * H + 1;
+    const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+    f32x2 wk[9][2], sc[2], sh[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wk[k][i] = f32x2{wgt[k * C + cg * CPT + 2 * i], wgt[k * C + cg * CPT + 2 * i + 1]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = cg * CPT + 2 * i;
+        sc[i] = f32x2{rstd[c] * gamma[c], rstd[c + 1] * gamma[c + 1]};
+        sh[i] = f32x2{beta[c] - mean[c] * sc[i].x, beta[c + 1] - mean[c + 1] * sc[i].y};
+    }
+    uint16_t img[NS];
+    auto load_img = [&](int64_t row) __attribute__((always_inline)) {
+        const int64_t n = row / Hp;
+        const int h0 = (int)(row - n * Hp), h = h0 < H ? h0 : H - 1;      // a pad row loads a real one (unused)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i0 = tid + s * kT, i = i0 < 3 * IW ? i0 : 3 * IW - 1, ky = i / IW, xx = i - ky * IW;
+            img[s] = image[(n * IH + 2 * h + ky) * (int64_t)IW + xx];
+        }
+    };
+    auto stage = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + s * kT, ky = i / IW, xx = i - ky * IW;
+            buf[i < 3 * IW ? ky * IWp + xx : 3 * IWp] = h2f<BF>(img[s]);
+        }
+    };
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    int64_t row = blockIdx.x;
+    int cur = 0;
+    if (row < nrows) {
+        load_img(row);
+        stage(lds);
+        if (tid < 3) { lds[tid * IWp + IW] = 0.0f; lds[BS + tid * IWp + IW] = 0.0f; }
+    }
+    __syncthreads();
+    for (; row < nrows; row += gridDim.x) {
+        const int64_t nxt = row + gridDim.x < nrows ? row + gridDim.x : row;
+        load_img(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t n = row / Hp;
+        const int h = (int)(row - n * Hp);
+        uint16_t* yr = y + row * (int64_t)Wp * C + cg * CPT;
+        if (h < H) {
+            const float* buf = lds + cur * BS + 2 * pl;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                f32x2 P[3][2];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    P[ky][0] = *reinterpret_cast<const f32x2*>(buf + ky * IWp + 2 * u * PL);
+                    P[ky][1] = *reinterpret_cast<const f32x2*>(buf + ky * IWp + 2 * u * PL + 2);
+                }
+                u32x2 out;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x2 v = pk_mul_lo(wk[0][i], P[0][0]);
+                    pk_fma_hi(v, wk[1][i], P[0][0]); pk_fma_lo(v, wk[2][i], P[0][1]);
+                    pk_fma_lo(v, wk[3][i], P[1][0]); pk_fma_hi(v, wk[4][i], P[1][0]); pk_fma_lo(v, wk[5][i], P[1][1]);
+                    pk_fma_lo(v, wk[6][i], P[2][0]); pk_fma_hi(v, wk[7][i], P[2][0]); pk_fma_lo(v, wk[8][i], P[2][1]);
+                    const f32x2 zz = __builtin_elementwise_fma(v, sc[i], sh[i]);
+                    const float r0 = zz.x > 0.0f ? zz.x : zz.x * slope, r1 = zz.y > 0.0f ? zz.y : zz.y * slope;
+                    out[i] = (uint32_t)f2h<BF>(r0) | ((uint32_t)f2h<BF>(r1) << 16);
+                }
+                *reinterpret_cast<u32x2*>(yr + (int64_t)(pl + u * PL) * C) = out;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) *reinterpret_cast<u32x2*>(yr + (int64_t)(pl + u * PL) * C) = u32x2{0u, 0u};
+        }
+        for (int w = W + pl; w < Wp; w += PL) *reinterpret_cast<u32x2*>(yr + (int64_t)w * C) = u32x2{0u, 0u};     // the pad columns
+        __builtin_amdgcn_sched_barrier(0);
+        stage(lds + (cur ^ 1) * BS);
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
 // ---- single-pass backward of the first layer -------------------------------------------------------------------------
 // dW[k][c] = sum_p dz * t_k with dz = gamma*rstd*(g - c1 - x_hat*c2) expands to
 //     gamma*rstd * ( A[k][c] - c1[c]*B[k] - c2[c]*D[k][c] ),
@@ -451,19 +560,6 @@ __global__ __launch_bounds__(kT) void k_c1_bwd1(const uint16_t* __restrict__ ima
 // arrive as three pairs + three singles (ds_read_b64 on an even row stride) and feed v_pk_fma_f32 through op_sel -- the tap is
 // broadcast by the instruction, not by a copy --, the pixel loop has no bounds, and the next row's gradients and image rows are
 // in flight (registers / the other LDS buffer) while this row is summed: one barrier per row.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 p) {       // a * p.lo
-    f32x2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
-    return r;
-}
-__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.lo
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(p));
-}
-__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 a, f32x2 p) {     // acc += a * p.hi
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(p));
-}
-
 template <bool BF, int NB>
 __global__ __launch_bounds__(kT) void k_c1_bwd1_pk(const uint16_t* __restrict__ image, const float* __restrict__ wgt, const uint16_t* __restrict__ dy,
                                                    int64_t N, int H, int ph, int pw, const float* mean, const float* rstd,
@@ -743,7 +839,19 @@ extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, c
                        save_mean, save_rstd, running_mean, running_var);
     const unsigned rows = (unsigned)(N * (H + pad_h));
     const unsigned ga = rows < (unsigned)(ctx->num_cu * 8) ? rows : (unsigned)(ctx->num_cu * 8);
-    if (dtype) hipLaunchKernelGGL(k_c1_apply_pad<true>, dim3(ga), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+    const char* pke = getenv("RML_C1_PK");             // read per call: the tests flip it (0: the general kernels)
+    if ((!pke || atoi(pke) != 0) && C == 128 && (W == 16 || W == 32 || W == 64)) {
+        auto go = [&](auto bf, auto nb) {
+            constexpr bool BFV = decltype(bf)::value;
+            constexpr int NBV = decltype(nb)::value;
+            static const int per_cu = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_c1_apply_pad_pk<BFV, NBV>, kT, 0) == hipSuccess && n > 0 ? n : 4; }();
+            const unsigned g = std::min<unsigned>(rows, (unsigned)(per_cu * ctx->num_cu));
+            hipLaunchKernelGGL((k_c1_apply_pad_pk<BFV, NBV>), dim3(g), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
+        };
+        using T = std::true_type; using F = std::false_type;
+        if (dtype) { if (W == 64) go(T{}, std::integral_constant<int, 8>{}); else if (W == 32) go(T{}, std::integral_constant<int, 4>{}); else go(T{}, std::integral_constant<int, 2>{}); }
+        else { if (W == 64) go(F{}, std::integral_constant<int, 8>{}); else if (W == 32) go(F{}, std::integral_constant<int, 4>{}); else go(F{}, std::integral_constant<int, 2>{}); }
+    } else if (dtype) hipLaunchKernelGGL(k_c1_apply_pad<true>, dim3(ga), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
     else hipLaunchKernelGGL(k_c1_apply_pad<false>, dim3(ga), dim3(kT), 0, st, is, weight, ys, (int64_t)rows, H, W, C, pad_h, pad_w, save_mean, save_rstd, gamma, beta, slope);
     RML_HIP(hipGetLastError());
     return RML_OK;
@@ -773,7 +881,8 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     static const bool cpt8 = [] { const char* e = getenv("RML_C1_CPT"); return e && atoi(e) == 8; }();
     const bool four = !cpt8 && C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
     // C = 128 and rows of 16 / 32 / 64 pixels: the packed kernel (RML_C1_PK=0: the general one)
-    static const bool pk_on = [] { const char* e = getenv("RML_C1_PK"); return !e || atoi(e) != 0; }();
+    const char* pke = getenv("RML_C1_PK");             // read per call: the tests flip it
+    const bool pk_on = !pke || atoi(pke) != 0;
     const bool pk = pk_on && !cpt8 && C == 128 && (W == 16 || W == 32 || W == 64);
     if (pk) {
         // one round of resident workgroups (166 registers at W = 64: three per CU), rows strided over them

@@ -1786,7 +1786,10 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && pge && pge[0] == '0'));
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
-    const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384 : 8192;
+    // derive -> slice beside the 128x128 GEMM, frames of at most 1 MiB: 12 288 (six interleaved runs, session r4bk, Walabot grid:
+    // 8.05 M frames/s at 8192, 8.21 at 12 288, 8.21 at 16 384; 64x64x128: 2.28 / 2.24 / 2.20 -- stays at 8192)
+    const int64_t small_chunk = (vdtype == RML_VOL_U8 && (int64_t)X * Y * Z <= 200000) ? 16384
+                                : (derive && vdtype != RML_VOL_U8 && (int64_t)X * Y * Z * 4 <= (1 << 20)) ? 12288 : 8192;
     // rows off the code grid: the multi-digit int8 kernel (256 x 256 tiles: chunks sized for whole rounds) where the model has a
     // digit frame and the batch is large enough, the float64 MFMA kernel otherwise
     // Only for models off the code grid: with a grid model the rows off the grid are the exception, and the digit kernel's
