@@ -406,6 +406,23 @@ int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, const float
                                     const float* save_mean, const float* save_rstd, const float* img_stats /* from forward */,
                                     float slope, float* workspace, float* dweight, float* dgamma, float* dbeta, void* stream);
 
+/* ---- Adam update of the SGAN discriminator (sgan.py:206, 214: Adam(lr=0.0002, beta_1=0.5) inside train_on_batch, sgan.py:525-532) ----
+ * ONE pass over all parameters with the loss-scale bookkeeping of a half-precision step on the device (csrc/optim.hip).
+ * table: DEVICE array of n_tensors + 1 records of rml_adam_entry_bytes() bytes each,
+ *     { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t start; }
+ * start = the tensor's first element in the concatenation of all tensors, record n_tensors holds { 0, 0, 0, 0, total }.  The four
+ * tensors of a record are dense float32 with identical strides (the update runs over the storage order).
+ * step: device float, the number of updates applied so far (incremented here unless the step is skipped).
+ * scale: device float loss scale, or NULL (no scaling: gradients taken as they are, inv_scale = 1).  With check != 0 every gradient is
+ * tested first; a non-finite one skips the whole update and multiplies the scale by `backoff`, `growth_interval` clean steps in
+ * a row multiply it by `growth` (torch.amp.GradScaler's rule).  state: device int32[3] (non-finite count, growth tracker, skip flag
+ * of the last call), zero-initialised by the caller once.  inv_scale: device float scratch.
+ * The update is torch.optim.Adam's: m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps). */
+int rml_adam_entry_bytes(void);
+int rml_adam_step(rml_ctx* ctx, const void* table, int n_tensors, int64_t total, float lr, float beta1, float beta2, float eps,
+                  float* step, float* scale, int32_t* state, float* inv_scale, int check, float growth, float backoff,
+                  int growth_interval, void* stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------- */
 int rml_synth_volumes(rml_ctx* ctx, uint64_t seed, int64_t frame0, int64_t B, int X, int Y, int Z,
                       int n_classes, float* V, int32_t* cls /* B or NULL */, void* stream);

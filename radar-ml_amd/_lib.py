@@ -96,6 +96,9 @@ SIGNATURES = {
     "rml_conv1_bn_lrelu_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p]),
+    "rml_adam_entry_bytes": (c_int, []),
+    "rml_adam_step": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
     "rml_augment": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),

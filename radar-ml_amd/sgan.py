@@ -12,6 +12,8 @@ DistributedDataParallel (backend "nccl" = RCCL all-reduce of ~1.86 M gradient el
 BatchNorm statistics stay per replica (what Keras does per replica).
 Only the discriminator/classifier train step is in scope; the generator is not.
 """
+import os
+
 import numpy as np
 
 from .nn_common import make_same_conv, to_nchw, flatten_nhwc
@@ -280,7 +282,28 @@ class DiscriminatorTrainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_dtype == torch.float16)
         self.use_graph = bool(use_graph) and self.device.type == "cuda" and mode != "torch"
         self._params = [q for q in model.parameters() if q.requires_grad]
+        # on the GPU the update itself and the loss-scale rule run as three launches over all parameters (nn_common.DeviceAdam,
+        # csrc/optim.hip); opt_c / opt_d stay the description of the optimizers (and the CPU path).  RML_DEVICE_ADAM=0: torch's.
+        self._dev_adam = None
+        if self.device.type == "cuda" and mode != "torch" and os.environ.get("RML_DEVICE_ADAM", "1") != "0":
+            from .nn_common import DeviceAdam
+            self._scale_t = torch.full((1,), 65536.0, dtype=torch.float32, device=self.device) if self.amp_dtype == torch.float16 else None
+            shared = torch.zeros((3,), dtype=torch.int32, device=self.device)
+            self._dev_adam = {id(o): DeviceAdam(self._params, lr, (beta1, 0.999), 1e-7, scale=self._scale_t, scaler_state=shared)
+                              for o in (self.opt_c, self.opt_d)}
         self._graphs = {}           # head -> dict(graph, static inputs / targets, loss, logits, eager_calls)
+
+    def _scaled(self, loss):
+        if self._dev_adam is not None:
+            return loss if self._scale_t is None else loss * self._scale_t
+        return self.scaler.scale(loss)
+
+    def _opt_step(self, opt):
+        if self._dev_adam is not None:
+            self._dev_adam[id(opt)].step()
+            return
+        self.scaler.step(opt)
+        self.scaler.update()
 
     def _zero_grad(self, opt):
         if self._flat is not None:
@@ -315,10 +338,9 @@ class DiscriminatorTrainer:
                 with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
                     logits = self.net(*xs)
                 loss = make_loss(logits, *targets)
-                self.scaler.scale(loss).backward()
+                self._scaled(loss).backward()
                 self._allreduce_grads()
-                self.scaler.step(opt)
-                self.scaler.update()
+                self._opt_step(opt)
                 return loss.detach(), logits.detach()
             st["xs"] = [t.clone() for t in xs]
             st["targets"] = [t.clone() for t in targets]
@@ -338,7 +360,7 @@ class DiscriminatorTrainer:
                 with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
                     logits = self.net(*st["xs"])
                 loss = make_loss(logits, *st["targets"])
-                self.scaler.scale(loss).backward()
+                self._scaled(loss).backward()
             st["graph"], st["loss"], st["logits"] = g, loss, logits
             st["grads"] = [q.grad for q in self._params] if self._flat is None else None
             # the capture itself does not run the kernels: fall through to the first replay
@@ -353,8 +375,7 @@ class DiscriminatorTrainer:
             for q, gr in zip(self._params, st["grads"]):       # this head's gradients (the other head's graph owns other tensors)
                 q.grad = gr
         self._allreduce_grads()
-        self.scaler.step(opt)
-        self.scaler.update()
+        self._opt_step(opt)
         return st["loss"].detach(), st["logits"].detach()
 
     def _tuned(self, fn, *args):
@@ -393,10 +414,9 @@ class DiscriminatorTrainer:
         else:
             logits = self.net(*xs)
         loss = loss_fn(logits)
-        self.scaler.scale(loss).backward()
+        self._scaled(loss).backward()
         self._allreduce_grads()
-        self.scaler.step(opt)
-        self.scaler.update()
+        self._opt_step(opt)
         return loss.detach(), logits.detach()
 
     def train_on_batch_c(self, x, y, sync=True):

@@ -626,6 +626,57 @@ def test_packed_conv1_backward_equals_the_general_kernel(rml, hw, n, monkeypatch
         assert (a - b).abs().max() <= 2e-5 * (1 + b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
+def test_device_adam_matches_torch_adam_and_grad_scaler(rml):
+    """nn_common.DeviceAdam (csrc/optim.hip: one pass over all parameters + the loss-scale rule on the device) against
+    torch.optim.Adam + torch.amp.GradScaler on the same gradients: parameters, skipped steps and the scale."""
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    torch.manual_seed(11)
+    shapes = [(64,), (128, 64, 3, 3), (3, 64), (19200, 64), (1,), (7, 5)]
+    ref = [torch.randn(s, device="cuda") * 0.1 for s in shapes]
+    ref[1] = ref[1].contiguous(memory_format=torch.channels_last)            # a convolution kernel as the trainer holds it
+    mine = [r.clone(memory_format=torch.preserve_format) for r in ref]
+    assert mine[1].stride() == ref[1].stride()
+    for t in ref + mine:
+        t.requires_grad_(True)
+    opt = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=3)
+    scale = torch.full((1,), 1024.0, device="cuda")
+    dev = nc.DeviceAdam(mine, 2e-4, (0.5, 0.999), 1e-7, scale=scale, growth_interval=3)
+    want_scale = []
+    for it in range(9):
+        g = [torch.randn_like(r) * (10.0 ** (it % 3 - 1)) for r in ref]
+        if it == 4:
+            g[3].view(-1)[12345] = float("inf")                            # one non-finite gradient: the whole step is skipped
+        if it == 7:
+            g[0][5] = float("nan")
+        s_now = float(scaler.get_scale()) if it else 1024.0
+        assert float(scale) == s_now, (it, float(scale), s_now)
+        for r, m, gi in zip(ref, mine, g):
+            r.grad = (gi * s_now).clone(memory_format=torch.preserve_format)
+            m.grad = (gi * s_now).clone(memory_format=torch.preserve_format)
+        mine[4].grad = None; ref[4].grad = None                             # a parameter without gradient is left alone
+        scaler.scale(torch.zeros((), device="cuda"))                        # GradScaler creates its scale tensor on first use
+        scaler.step(opt)
+        scaler.update()
+        dev.step()
+        want_scale.append(float(scaler.get_scale()))
+        for r, m in zip(ref, mine):
+            assert torch.isfinite(m).all()
+            assert (r - m).abs().max() <= 2e-6 * (1 + r.abs().max()), (it, tuple(r.shape), float((r - m).abs().max()))
+    assert float(dev.step_count) == 7.0                                    # two of nine steps skipped
+    assert float(scale) == want_scale[-1] and min(want_scale) < 1024.0 < max(want_scale + [2048.0])
+    # without a scale: plain Adam, no test of the gradients
+    p0 = torch.randn(1000, device="cuda", requires_grad=True)
+    p1 = p0.detach().clone().requires_grad_(True)
+    o0 = torch.optim.Adam([p0], lr=1e-2, betas=(0.5, 0.999), eps=1e-7)
+    o1 = nc.DeviceAdam([p1], 1e-2, (0.5, 0.999), 1e-7)
+    for it in range(5):
+        gi = torch.randn(1000, device="cuda")
+        p0.grad = gi.clone(); p1.grad = gi.clone()
+        o0.step(); o1.step()
+    assert (p0 - p1).abs().max() <= 1e-6
+
+
 def test_sgan_trainer_hip_graph_matches_eager(rml):
     """DiscriminatorTrainer(use_graph=True): forward + backward of each head replayed from a HIP graph (after three eager
     warm-up steps) gives the losses of the eager trainer, step for step."""
