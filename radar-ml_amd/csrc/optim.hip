@@ -37,18 +37,27 @@ __device__ __forceinline__ int find_entry(const AdamEntry* __restrict__ tab, int
     return lo;
 }
 
+// The table in LDS (up to kMaxLds tensors; more: searched in global memory): the search is six dependent loads per element
+constexpr int kMaxLds = 127;
+__device__ __forceinline__ const AdamEntry* stage_table(const AdamEntry* __restrict__ tab, int n, AdamEntry* lds) {
+    if (n > kMaxLds) return tab;
+    for (int i = threadIdx.x; i <= n; i += kAT) lds[i] = tab[i];
+    __syncthreads();
+    return lds;
+}
+
 // state: int32 [0] found (non-finite gradients seen, reset by k_adam_decide), [1] growth tracker, [2] skip flag of this step
-__global__ __launch_bounds__(kAT) void k_adam_check(const AdamEntry* __restrict__ tab, int n, int64_t total, int* state) {
-    const int64_t base = ((int64_t)blockIdx.x * kAT + threadIdx.x) * kPer;
+__global__ __launch_bounds__(kAT) void k_adam_check(const AdamEntry* tab, int n, int64_t total, int* state) {
+    // element j of a thread sits kAT elements behind element j - 1: neighbouring lanes read neighbouring floats
+    __shared__ AdamEntry ltab[kMaxLds + 1];
+    tab = stage_table(tab, n, ltab);
+    const int64_t base = (int64_t)blockIdx.x * kAT * kPer + threadIdx.x;
     bool bad = false;
-    if (base < total) {
-        int e = find_entry(tab, n, base);
-        int64_t end = tab[e + 1].start;
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int64_t idx = base + i;
-            if (idx >= total) break;
-            while (idx >= end) { ++e; end = tab[e + 1].start; }
+    for (int i = 0; i < kPer; ++i) {
+        const int64_t idx = base + (int64_t)i * kAT;
+        if (idx < total) {
+            const int e = find_entry(tab, n, idx);
             const float g = tab[e].g[idx - tab[e].start];
             bad |= !(fabsf(g) <= 3.4028234663852886e38f);     // NaN or infinity
         }
@@ -71,23 +80,22 @@ __global__ void k_adam_decide(int* state, float* scale, float* step, float* inv_
     if (!skip) *step += 1.0f;
 }
 
-__global__ __launch_bounds__(kAT) void k_adam_apply(const AdamEntry* __restrict__ tab, int n, int64_t total, float lr, float beta1, float beta2,
+__global__ __launch_bounds__(kAT) void k_adam_apply(const AdamEntry* tab, int n, int64_t total, float lr, float beta1, float beta2,
                                                     float eps, const float* __restrict__ step, const float* __restrict__ inv_scale,
                                                     const int* __restrict__ state) {
-    if (state[2]) return;                                // a non-finite gradient somewhere: the whole step is skipped
-    const int64_t base = ((int64_t)blockIdx.x * kAT + threadIdx.x) * kPer;
-    if (base >= total) return;
+    if (state[2]) return;                                // a non-finite gradient somewhere: the whole step is skipped (uniform)
+    __shared__ AdamEntry ltab[kMaxLds + 1];
+    tab = stage_table(tab, n, ltab);
+    const int64_t base = (int64_t)blockIdx.x * kAT * kPer + threadIdx.x;
     const float t = *step, inv = *inv_scale;
     // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     const float step_size = lr / bc1, rsq_bc2 = 1.0f / sqrtf(bc2);
-    int e = find_entry(tab, n, base);
-    int64_t end = tab[e + 1].start;
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-        const int64_t idx = base + i;
-        if (idx >= total) break;
-        while (idx >= end) { ++e; end = tab[e + 1].start; }
+        const int64_t idx = base + (int64_t)i * kAT;
+        if (idx >= total) break;                       // no barrier below
+        const int e = find_entry(tab, n, idx);
         const int64_t o = idx - tab[e].start;
         const float g = tab[e].g[o] * inv;
         const float m = beta1 * tab[e].m[o] + (1.0f - beta1) * g;
