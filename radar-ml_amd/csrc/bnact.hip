@@ -404,6 +404,21 @@ __global__ __launch_bounds__(kT) void k_c1_apply_pad_pk(const uint16_t* __restri
 // A[k][c] = sum g*t_k, B[k] = sum t_k, D[k][c] = sum x_hat*t_k = rstd*(sum_j w[j][c]*T2[j][k] - mean*B[k]), T2 = sum t_j*t_k.
 // B and T2 depend on the image only (k_c1_imgstats, 8.5 MB), so ONE pass over dy accumulates A, sum g and sum g*x_hat
 // (k_c1_bwd1) and k_c1_wgrad_combine finishes in float64 -- dy is read once instead of twice.
+// sum over the 64 lanes of a wave on DPP moves (fixed order; the result is wave-uniform) -- see wave_sum in dense.hip
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+__device__ __forceinline__ float wave_sum_dpp(float r) {
+    r += dpp_mov_f<0xB1, 0xF, true>(0.0f, r);     // quad_perm [1,0,3,2]
+    r += dpp_mov_f<0x4E, 0xF, true>(0.0f, r);     // quad_perm [2,3,0,1]
+    r += dpp_mov_f<0x141, 0xF, true>(0.0f, r);    // row_half_mirror
+    r += dpp_mov_f<0x140, 0xF, true>(0.0f, r);    // row_mirror
+    r += dpp_mov_f<0x142, 0xA, false>(0.0f, r);   // row_bcast15 into rows 1 and 3
+    r += dpp_mov_f<0x143, 0xC, false>(0.0f, r);   // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63));
+}
+
 template <bool BF>
 __global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__ image, int64_t N, int H, int W, float* part /* [G][54] */) {
     const int IH = 2 * H + 1, IW = 2 * W + 1;
@@ -432,14 +447,13 @@ __global__ __launch_bounds__(kT) void k_c1_imgstats(const uint16_t* __restrict__
             for (int k = j; k < 9; ++k) { t2[q] = fmaf(t[j], t[k], t2[q]); ++q; }
         }
     }
-    // 54 block sums: butterfly inside each wave, then the four waves through LDS (fixed order)
+    // 54 block sums: each wave's on DPP moves (six VALU steps per value; the __shfl_xor butterfly was 324 ds_bpermute round trips
+    // per wave -- most of this kernel), then the four waves through LDS (fixed order)
     __shared__ float wsum[kT / 64][54];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int v = 0; v < 54; ++v) {
-        float x = v < 9 ? b[v] : t2[v - 9];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        const float x = wave_sum_dpp(v < 9 ? b[v] : t2[v - 9]);
         if (lane == 0) wsum[wave][v] = x;
     }
     __syncthreads();
@@ -828,7 +842,9 @@ extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, c
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t M = N * H * W;
-    const int GI = 256;                                     // image-statistics workgroups
+    // image-statistics workgroups: eight per CU (with 256 -- one per CU, 16 pixels per thread, each waiting for its own nine loads --
+    // the pass took 22 us for an 8.5 MB image); the partials fit the workspace for every C >= 8 (num_cu * 8 * 54 <= num_cu * 8 * 11 * C)
+    const int GI = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, (M + kT - 1) / kT));
     const uint16_t* is = static_cast<const uint16_t*>(image);
     uint16_t* ys = static_cast<uint16_t*>(y);
     // statistics of the image (B[9], T2 packed [45]) -> batch statistics of the convolution output, no pass over it
