@@ -138,6 +138,10 @@ struct Emitter {
         if (!(rmw && a.o.q[pl] && ((a.o.sel >> pl) & 1u))) return 0u;
         return *reinterpret_cast<const uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
     }
+    // the same without the tests (a launch with rmw set has the code rows; the caller checked the plane): an unconditional load
+    __device__ __forceinline__ uint32_t old_word_nocheck(int pl, int64_t idx) const {
+        return *reinterpret_cast<const uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
+    }
     // four projection values that ARE bytes (uint8 volumes; idx a multiple of 4): when only codes and their statistics are
     // wanted the bytes are the codes -- biased with one xor, summed and squared with v_dot4_u32_u8 -- and nothing is widened
     __device__ __forceinline__ void put_bytes4(int pl, int64_t idx, uint32_t w, bool have_old = false, uint32_t old = 0u) {

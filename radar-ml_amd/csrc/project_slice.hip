@@ -46,12 +46,14 @@ template <typename VT> struct Cell;
 template <> struct Cell<float> {
     typedef float4 Q;
     static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, const float4& v) { em.put4(pl, idx, v); }
+    static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, const float4& v, uint32_t old) { em.put4(pl, idx, v, true, old); }
     static __device__ __forceinline__ float4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
     static __device__ __forceinline__ float4 widen(const float4& v) { return v; }
 };
 template <> struct Cell<uint8_t> {
     typedef uint32_t Q;
     static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, uint32_t w) { em.put_bytes4(pl, idx, w); }
+    static __device__ __forceinline__ void emit4(Emitter& em, int pl, int64_t idx, uint32_t w, uint32_t old) { em.put_bytes4(pl, idx, w, true, old); }
     static __device__ __forceinline__ uint32_t pack(uint8_t a, uint8_t b, uint8_t c, uint8_t d) {
         return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
     }
@@ -69,7 +71,9 @@ __device__ __forceinline__ int div_small(int q, int d, float rcp) {
 // the three planes through (i, j, k) of the frame at Vf, by one wave; indices already wrapped into range.  Every address is the
 // wave-uniform frame base plus a 32-bit element offset (a frame is far below 4 G elements): the loads take the scalar-base form
 // and need one offset register each instead of a 64-bit pointer pair
-template <typename VT, int UB>
+// RMW (read-compare-write of the code rows, Emitter::rmw): the old words of a batch are loaded with the batch's volume quads --
+// unconditionally, their latency under the gather's own -- and handed to the stores
+template <typename VT, int UB, bool RMW = false>
 __device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int j, int k, int X, int Y, int Z, int ZQ,
                                            Emitter& em, int lane) {
     typedef typename Cell<VT>::Q QT;
@@ -81,15 +85,18 @@ __device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int
         const uint32_t o0 = (uint32_t)i * pq;
         for (uint32_t base = 0; base < pq; base += 64 * UB) {
             QT v[UB];
+            uint32_t ow[UB];
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const uint32_t q = base + u * 64 + ul;
                 v[u] = Vq[o0 + (q < pq ? q : pq - 1)];
+                if constexpr (RMW) ow[u] = em.old_word_nocheck(1, (int64_t)(q < pq ? q : pq - 1) * 4);
             });
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const uint32_t q = base + u * 64 + ul;
-                if (q < pq) Cell<VT>::emit4(em, 1, (int64_t)q * 4, v[u]);
+                if constexpr (RMW) { if (q < pq) Cell<VT>::emit4(em, 1, (int64_t)q * 4, v[u], ow[u]); }
+                else if (q < pq) Cell<VT>::emit4(em, 1, (int64_t)q * 4, v[u]);
             });
         }
     }
@@ -99,17 +106,20 @@ __device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int
         const uint32_t o0 = (uint32_t)(j * ZQ);
         for (uint32_t base = 0; base < n; base += 64 * UB) {
             QT v[UB];
+            uint32_t ow[UB];
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 uint32_t q = base + u * 64 + ul;
                 q = q < n ? q : n - 1;
                 const uint32_t ii = (uint32_t)div_small((int)q, ZQ, rcp);
                 v[u] = Vq[o0 + ii * pq + (q - ii * (uint32_t)ZQ)];
+                if constexpr (RMW) ow[u] = em.old_word_nocheck(0, (int64_t)q * 4);
             });
             static_for<UB>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const uint32_t q = base + u * 64 + ul;
-                if (q < n) Cell<VT>::emit4(em, 0, (int64_t)q * 4, v[u]);
+                if constexpr (RMW) { if (q < n) Cell<VT>::emit4(em, 0, (int64_t)q * 4, v[u], ow[u]); }
+                else if (q < n) Cell<VT>::emit4(em, 0, (int64_t)q * 4, v[u]);
             });
         }
     }
@@ -119,17 +129,20 @@ __device__ __forceinline__ void slice_emit(const VT* __restrict__ Vf, int i, int
         constexpr int UG = UB / 2 > 0 ? UB / 2 : 1;
         for (uint32_t base = 0; base < n4; base += 64 * UG) {
             VT v[UG][4];
+            uint32_t ow[UG];
             static_for<UG>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 uint32_t q = base + u * 64 + ul;
                 q = q < n4 ? q : n4 - 1;
                 const uint32_t e0 = q * 4 * uz + uk;
                 v[u][0] = Vf[e0]; v[u][1] = Vf[e0 + uz]; v[u][2] = Vf[e0 + 2 * uz]; v[u][3] = Vf[e0 + 3 * uz];
+                if constexpr (RMW) ow[u] = em.old_word_nocheck(2, (int64_t)q * 4);
             });
             static_for<UG>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const uint32_t q = base + u * 64 + ul;
-                if (q < n4) Cell<VT>::emit4(em, 2, (int64_t)q * 4, Cell<VT>::pack(v[u][0], v[u][1], v[u][2], v[u][3]));
+                if constexpr (RMW) { if (q < n4) Cell<VT>::emit4(em, 2, (int64_t)q * 4, Cell<VT>::pack(v[u][0], v[u][1], v[u][2], v[u][3]), ow[u]); }
+                else if (q < n4) Cell<VT>::emit4(em, 2, (int64_t)q * 4, Cell<VT>::pack(v[u][0], v[u][1], v[u][2], v[u][3]));
             });
         }
         const uint32_t idx = n4 * 4 + ul;
@@ -361,7 +374,9 @@ __global__ __launch_bounds__(512) void k_derive_slice(ProjParams a) {
                 const int j = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 1]);
                 const int k = __builtin_amdgcn_readfirstlane(tgt[t * 3 + 2]);
                 em.reset(cf * T + t);
-                slice_emit<VT, RML_DERIVE_UB>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
+                // codes only (the pipelines' first pass) with read-compare-write: the batched form; float rows or plain stores: as before
+                if (em.rmw && !a.o.p[0] && !a.o.p[1] && !a.o.p[2] && !a.o.row_nsq) slice_emit<VT, RML_DERIVE_UB, true>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
+                else slice_emit<VT, RML_DERIVE_UB>(Vf, i, j, k, X, Y, Z, ZQ, em, lane);
                 em.finish_wave(lane);
             }
         }

@@ -160,7 +160,10 @@ struct ProjOut {
 // r4bf: this library against the library of the commit before, three interleaved whole-round runs on one box):
 //   64x64x128 uint8 (rows 3.9 % of the frame): 7.41 -> 7.86 M frames/s (+6 %; +11 % on another box)                        on
 //   64x64x128 derive -> slice (rows 1 %): 2.193 -> 2.264 M (+3.2 %)                                                          on
-//   Walabot grid, uint8 (rows 8.3 %): -2.5 %;  derive -> slice (rows 2.1 %): 7.94 -> 7.89 M (-0.6 %; kernel in situ -7 %)      off
+//   Walabot grid, uint8 (rows 8.3 %): -2.5 %                                                                                off
+//   Walabot grid, derive -> slice (rows 2.1 %): per store 7.94 -> 7.89 M (kernel in situ -7 %); with the old words loaded
+//     alongside the gather's batches (slice_emit<., ., true>, session r4bs) 8.33-8.35 -> 8.33-8.39 M, kernel 0.576 -> 0.585;
+//     64x64x128 in that form 2.24 -> 2.26 M, kernel 0.618 -> 0.634                                                          on
 //   float32 max projections: +0.7 / +1.1 % end to end at the Walabot grid and +-0.5 % at 64x64x128 against the same library
 //     without -- but the prefetched old words and the test in front of every store cost k_project_lin 9 % in situ (0.735 -> 0.665)
 //     and the headline 1 % against the library before: those kernels store plainly again (Emitter::rmw = false)              off
@@ -169,7 +172,7 @@ struct ProjOut {
 inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
     const char* e = getenv("RML_CODE_RMW");
     if (e && *e) return atoi(e) != 0;
-    if (derive) return D * 64 <= frame_bytes;
+    if (derive) return D * 16 <= frame_bytes;
     return u8 && D * 64 >= frame_bytes && D * 16 <= frame_bytes;
 }
 
