@@ -9,7 +9,9 @@ RBF-SVM label (BASELINE.json metric; workload = configs[2]: projection + RBF-SVM
 
 A "step" is one pass of the hot path over the rank's resident batch (frames shard across ranks,
 weak scaling, no data-path collective; the per-frame labels are all-gathered over RCCL at the end
-of every step, inside the timed region).  Rank 0 prints ONE JSON line.
+of every step, inside the timed region).  Rank 0 prints the verbose rows as {"doc": ...} on one line and then,
+LAST, the contract line (one JSON object < 4 KB: metric, value, roofline, cpu_baseline, summary).
+`python bench.py --gpus N` without a launcher starts its own N ranks.
 """
 import argparse
 import ctypes
@@ -47,7 +49,7 @@ def _bench_support():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE of the launcher, else 1")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (configs[2]: 65536)")
@@ -72,6 +74,7 @@ def parse():
     ap.add_argument("--general-frames", type=int, default=16384, help="frames per GPU of the general_rows row")
     ap.add_argument("--dnn-parity", type=int, default=1024, help="frames of the CNN row checked against the NumPy restatement")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--doc-file", default=None, help="also write the verbose rows (and the contract line) to this JSON file")
     return ap.parse_args()
 
 
@@ -805,22 +808,65 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
             "c_loss": round(float(lc), 4), "d_loss": round(float(ld), 4), "d_fake_loss": round(float(lf), 4)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on 127.0.0.1, the contract's own command line) and return their exit status.  A request the box
+    cannot serve -- fewer visible devices than ranks -- is refused loudly; RML_BENCH_ONE_DEVICE=1 is the declared dry run
+    of the N > 1 control flow on one device (gloo)."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus and not os.environ.get("RML_BENCH_ONE_DEVICE"):
+        sys.stderr.write("bench.py: --gpus %d requested but %d device(s) visible; refusing to print an n_gpus=%d line "
+                         "(RML_BENCH_ONE_DEVICE=1 runs the ranks on one device over gloo as a control-flow dry run)\n"
+                         % (a.gpus, have, a.gpus))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        a.gpus = world
-    if os.environ.get("RML_BENCH_ONE_DEVICE"):      # dry run of the N > 1 control flow on a 1-GPU box: every rank on cuda:0
+        # the launcher decides how many ranks exist; a line that claims another n_gpus than asked for is never printed
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or drop the launcher: "
+                             "`python bench.py --gpus N` starts its own ranks)\n" % (a.gpus, world, a.gpus))
+        sys.exit(2)
+    one_device = bool(os.environ.get("RML_BENCH_ONE_DEVICE"))
+    if world > 1 and not one_device and torch.cuda.device_count() < world:
+        if rank == 0:
+            sys.stderr.write("bench.py: %d ranks but %d device(s) visible\n" % (world, torch.cuda.device_count()))
+        sys.exit(2)
+    if one_device:      # dry run of the N > 1 control flow on a 1-GPU box: every rank on cuda:0
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("RML_BENCH_ONE_DEVICE"):
+        if one_device:
             dist.init_process_group("gloo")         # RCCL refuses two ranks on one device; gloo stages CUDA tensors through the host
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -930,8 +976,8 @@ def main():
             res["roofline"]["frac_of_measured_copy"] = round(res["roofline"]["achieved"] / copy_gbs, 4)
         except Exception:
             pass
-        # ---- the line.  The driver keeps only the LAST kilobytes of stdout, so the verbose material goes FIRST (under "doc") and
-        #      the contract keys, the compact roofline / cpu_baseline objects and a one-screen summary of every row go last ----
+        # ---- the output.  The verbose material ("doc") goes on an EARLIER line; the contract keys, the compact roofline /
+        #      cpu_baseline objects and a one-screen summary of every row are the LAST line ----
         doc = {"config_detail": res["config"], "roofline": res["roofline"], "gemm_roofline": res["gemm_roofline"],
                "cpu_baseline": res["cpu_baseline"], "parity": res["parity"], "projection_only_configs1": res["projection_only"],
                "uint8_ingest": res["uint8_ingest"], "slice_rows": res.get("slice_rows"), "model": res["model"]}
@@ -1008,7 +1054,6 @@ def main():
         rf = res["roofline"]
         cb = res["cpu_baseline"]
         line = {
-            "doc": doc,
             "metric": "radar frames/s (3D-proj->SVM)", "value": res["value"], "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -1025,7 +1070,22 @@ def main():
                                                      "label_mismatch_vs_gpu": cb.get("label_mismatch_vs_gpu")},
             "summary": summ,
         }
-        print(json.dumps(line))
+        # TWO lines: the verbose rows first, on a line of their own ({"doc": ...}; --doc-file also writes them to a file), and
+        # LAST the self-contained contract object, kept under 4 KB so that whatever the driver keeps of stdout holds all of it
+        # (round 4 printed one 22.6 KB object and the driver could not parse it).
+        print(json.dumps({"doc": doc}))
+        if a.doc_file:
+            os.makedirs(os.path.dirname(os.path.abspath(a.doc_file)), exist_ok=True)
+            with open(a.doc_file, "w") as f:
+                json.dump({"doc": doc, "line": line}, f, indent=1)
+        last = json.dumps(line)
+        for drop in ("general_rows_walabot", "proj_only_configs1", "general_rows", "sgan_configs4", "dnn_configs3"):
+            if len(last) < 4000:
+                break
+            summ.pop(drop, None)
+            summ["dropped"] = summ.get("dropped", []) + [drop]
+            last = json.dumps(line)
+        print(last)
         sys.stdout.flush()
         gate_failed = bool(fails)
     else:

@@ -166,7 +166,10 @@ void launch_lin(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     // wave-private images: 4 x (NI * 64 float4 + NT * 64 floats) (44 quads: 66 KB) + the code stage of a codes-only launch (4 x 4.6 KB
     // at the Walabot grid).  Beside a GEMM (share_cu = 1) the request is padded past half of the CU's LDS so that the dispatcher cannot
     // put two of these persistent workgroups on one CU (see launch_wave)
-    const size_t mine = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4) + (size_t)4 * pp.stage_bytes;
+    constexpr size_t kMaxLds = 160 * 1024;              // the attribute set below: a CU's whole LDS (as k_derive_slice does)
+    const size_t images = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
+    if (images + (size_t)4 * pp.stage_bytes > kMaxLds) pp.stage_bytes = 0;      // no room for the code stage: direct stores
+    const size_t mine = images + (size_t)4 * pp.stage_bytes;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
     int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
     if (per_cu * mine > 160 * 1024) per_cu = 1;         // (measured: one or two of these workgroups per CU stream equally fast)
@@ -175,10 +178,10 @@ void launch_lin(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     dim3 grid((unsigned)(want < cap ? want : cap)), block(kThreads);
     const size_t lds = (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine < 81 * 1024) ? 81 * 1024 : mine;
     if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(112 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>);
+        RML_MAX_DYN_LDS(kMaxLds, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>);
         hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, true>), grid, block, lds, st, pp);
     } else {
-        RML_MAX_DYN_LDS(112 * 1024, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>);
+        RML_MAX_DYN_LDS(kMaxLds, &k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>);
         hipLaunchKernelGGL((k_project_lin<MODE, ZQ4, NI, RG, NGRP, NMASK, false>), grid, block, lds, st, pp);
     }
 }

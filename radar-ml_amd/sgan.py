@@ -85,7 +85,7 @@ class Discriminator(_nn().Module):
                     and c % 8 == 0 and 256 % (c // 8) == 0 and bn.track_running_stats and bn.affine and bn.momentum is not None):
                 x = conv1_bn_lrelu_pad(x, conv, bn, act.negative_slope, pad, adt)
                 continue
-            z = F.conv2d(x, half[conv.weight] if half else conv.weight, None, stride=2)
+            z = F.conv2d(x, half.get(conv.weight, conv.weight) if half else conv.weight, None, stride=2)
             x = bn_lrelu_pad(z, bn, act.negative_slope, pad=pad, conv_bias=conv.bias)
         return x
 

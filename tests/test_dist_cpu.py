@@ -1,12 +1,16 @@
 """N>1 path on CPU: world_size-2 gloo processes exercise the frame sharding and the label all-gather."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -139,3 +143,19 @@ def test_bench_helpers_resolve_every_name_they_call():
     import bench_support
     for name in ("reference_libs_baseline", "reference_libs_process_pool", "measure_traffic"):
         assert callable(getattr(bench_support, name))
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`bench.py --gpus 8` on a box with fewer devices must fail loudly instead of printing an n_gpus = 1 line; a launcher whose
+    WORLD_SIZE disagrees with --gpus is refused the same way (neither reaches the GPU work)."""
+    import torch
+    n = max(torch.cuda.device_count(), 1) + 1
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RML_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"refusing" in r.stderr and b'"n_gpus"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr and b'"n_gpus"' not in r.stdout

@@ -25,10 +25,23 @@ def _free_port():
 
 
 def _line(out):
-    for ln in reversed(out.strip().splitlines()):
-        if ln.startswith("{"):
-            return json.loads(ln)
-    raise AssertionError("no JSON line in:\n" + out[-2000:])
+    """bench.py prints {"doc": verbose rows} on one line and, LAST, the contract line: return the contract object with the
+    verbose rows attached under "doc".  The contract line must stand alone under 4 KB (what the driver parses)."""
+    lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) >= 2, "expected a doc line and a contract line in:\n" + out[-2000:]
+    last = lines[-1]
+    assert len(last) < 4096, len(last)
+    line = json.loads(last)
+    assert "doc" not in line and list(line.keys())[-1] == "summary"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    doc = json.loads(lines[-2])
+    assert list(doc.keys()) == ["doc"]
+    line["doc"] = doc["doc"]
+    return line
 
 
 def test_two_rank_bench_on_one_device_matches_the_single_process_run():
@@ -47,8 +60,10 @@ def test_two_rank_bench_on_one_device_matches_the_single_process_run():
     assert one.returncode == 0, one.stderr.decode()[-3000:]
     l1 = _line(one.stdout.decode())
     env2 = dict(env, RML_BENCH_ONE_DEVICE="1")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", str(per_rank),
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env2.pop(k, None)
+    # no launcher: `python bench.py --gpus 2` starts its own two ranks (torch.distributed.run on 127.0.0.1)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", str(per_rank),
                           "--walabot-frames", str(per_rank)] + common, cwd=ROOT, env=env2, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=1500)
     assert two.returncode == 0, two.stderr.decode()[-3000:]
@@ -58,8 +73,7 @@ def test_two_rank_bench_on_one_device_matches_the_single_process_run():
 
 
 def _check_pair(l1, l2, per_rank):
-    """l1: the single-process line of the global batch, l2: the two-rank line (bench.py prints the verbose rows under "doc" and
-    the compact ones last)."""
+    """l1: the single-process line of the global batch, l2: the two-rank line (_line attaches the verbose rows under "doc")."""
     assert l2["n_gpus"] == 2 and l2["config"]["global_frames"] == 2 * per_rank == l1["config"]["global_frames"]
     # every rank classified its slab of the same global batch: gathered labels == single-process labels, both grids
     assert l2["labels_crc32"] == l1["labels_crc32"]
@@ -76,10 +90,6 @@ def _check_pair(l1, l2, per_rank):
                 assert par["label_calib_mismatch"] == 0 and par["label_vote_mismatch"] == 0 and par["dec_ovo_max_abs_err"] <= 1e-5
             assert g["slice_rows"]["derive_slice_svm"]["parity"]["derived_target_mismatch"] == 0
         assert ln["summary"]["parity_gate"] == "pass"
-        # the compact objects at the END of the line (the driver keeps the last kilobytes): standard keys + summary within 4 KB
-        tail = json.dumps({k: v for k, v in ln.items() if k != "doc"})
-        assert len(tail) < 4096, len(tail)
-        assert list(ln.keys())[0] == "doc" and list(ln.keys())[-1] == "summary"
     sg = l2["doc"]["sgan_train_step"]
     assert "error" not in sg, sg
     assert sg["replicas_identical"] is True and sg["hip_graph"] is True and sg["n_gpus"] == 2
@@ -113,3 +123,4 @@ def test_two_rank_bench_over_rccl_when_two_devices_are_visible():
     l1, l2 = _line(one.stdout.decode()), _line(two.stdout.decode())
     _check_pair(l1, l2, per_rank)
     assert l2["config"]["collective_backend"] == "nccl"           # = RCCL on ROCm
+
