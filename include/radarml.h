@@ -119,6 +119,17 @@ int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_ms, int64_t*
  * milliseconds, and the algorithmic operations 2*D*M per frame they covered. */
 int rml_profile_read_gemm(rml_ctx* ctx, int64_t* launches, double* total_ms, double* ops);
 
+/* What a pure streaming READ of `bytes` resident bytes reaches on this device, in GB/s: `reps` launches of a persistent
+ * non-temporal 16-byte-load kernel over `buf` (16-byte aligned, >= 1 MiB), timed with a hipEvent pair on `stream`; synchronises.
+ * bench.py's second roofline denominator beside the 8 TB/s specification (SURVEY.md 8d "measured copy bandwidth"); replaces no
+ * reference interface -- the reference publishes no bandwidth figure. */
+int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, int reps, double* gb_per_s, void* stream);
+
+/* 1 when the fused pipelines store a frame's code row read-compare-write (read the old words, store what changed) for frames of
+ * frame_bytes volume bytes and D codes, 0 for plain stores (the rule and its measurements: csrc/rml_internal.h rml_code_rmw;
+ * RML_CODE_RMW=0/1 in the environment overrides it).  Reporting only: bench.py prints it beside the with/without pair. */
+int rml_code_rmw_default(int64_t D, int64_t frame_bytes, int derive, int u8);
+
 /* Feature-row length for a grid and mask: X*Z + Y*Z + X*Y over the selected planes
  * (train_svc.log:19 "Feature vector length: 10010" at (22,31,176)). */
 int64_t rml_feature_len(int X, int Y, int Z, uint32_t mask);

@@ -100,6 +100,8 @@ SIGNATURES = {
     "rml_adam_step": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
     "rml_augment": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rml_code_rmw_default": (c_int, [c_int64, c_int64, c_int, c_int]),
+    "rml_probe_stream": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rml_synth_volumes": (c_int, [c_void_p, c_uint64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),
 }

@@ -201,3 +201,67 @@ extern "C" int rml_ctx_set_option(rml_ctx* ctx, int option, int value) {
         default: RML_REQUIRE(false, RML_ERR_INVALID, "rml_ctx_set_option: unknown option %d", option);
     }
 }
+
+// ---- rml_probe_stream: what a pure streaming READ reaches on this device ------------------------------------------------------------
+// The "measured" denominator beside the 8 TB/s specification: a persistent kernel, 2 x 256 threads per CU, every
+// lane keeps 16 non-temporal 16-byte loads in flight over workgroup-contiguous 64 KB pieces and folds them with a max (the
+// access pattern and the arithmetic of a projection without its epilogue); nothing is written unless a sentinel matches.
+namespace {
+typedef float probe_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_stream(const probe_v4* __restrict__ src, int64_t n16, float* sink) {
+    constexpr int PF = 16;
+    const int64_t piece = (int64_t)256 * PF;                 // 16-byte words per workgroup step (64 KB)
+    probe_v4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int64_t base = (int64_t)blockIdx.x * piece; base < n16; base += (int64_t)gridDim.x * piece) {
+        probe_v4 v[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            int64_t q = base + (int64_t)u * 256 + threadIdx.x;
+            q = q < n16 ? q : n16 - 1;
+            v[u] = __builtin_nontemporal_load(src + q);
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+        }
+    }
+    const float r = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+    if (r == 12345.678f) sink[blockIdx.x] = r;               // never true for the caller's data in practice: keeps the loads alive
+}
+}  // namespace
+
+extern "C" int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, int reps, double* gb_per_s, void* stream) {
+    RML_REQUIRE(ctx && buf && gb_per_s, RML_ERR_INVALID, "rml_probe_stream: NULL argument");
+    RML_REQUIRE(bytes >= (1 << 20) && reps >= 1 && (reinterpret_cast<uintptr_t>(buf) & 15) == 0, RML_ERR_INVALID,
+                "rml_probe_stream: needs a 16-byte aligned buffer of at least 1 MiB and reps >= 1");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void* sink = nullptr;
+    int rc = rml_ws_reserve(ctx, (size_t)4 * 2 * ctx->num_cu, &sink);
+    if (rc) return rc;
+    const int64_t n16 = bytes / 16;
+    hipEvent_t e0, e1;
+    RML_HIP(hipEventCreate(&e0));
+    RML_HIP(hipEventCreate(&e1));
+    const dim3 grid((unsigned)(2 * ctx->num_cu)), block(256);
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL(k_probe_stream, grid, block, 0, st, static_cast<const probe_v4*>(buf), n16, static_cast<float*>(sink));
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(k_probe_stream, grid, block, 0, st, static_cast<const probe_v4*>(buf), n16, static_cast<float*>(sink));
+    (void)hipEventRecord(e1, st);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    RML_HIP(e);
+    RML_HIP(hipGetLastError());
+    *gb_per_s = ms > 0.0f ? (double)reps * (double)(n16 * 16) / ((double)ms * 1e-3) / 1e9 : 0.0;
+    return RML_OK;
+}
+
+// the pipelines' default for read-compare-write code stores (rml_internal.h rml_code_rmw; honours RML_CODE_RMW): bench.py reports it
+extern "C" int rml_code_rmw_default(int64_t D, int64_t frame_bytes, int derive, int u8) {
+    return rml_code_rmw(D, frame_bytes, derive != 0, u8 != 0);
+}

@@ -399,7 +399,8 @@ void launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     constexpr int per_cu_max = (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2;
     const size_t mine = (size_t)4 * NY * 68 * sizeof(float);
     pp.stage_bytes = code_stage_bytes(pp, sizeof(VT));
-    if (mine + (size_t)4 * pp.stage_bytes > 160 * 1024) pp.stage_bytes = 0;      // past the attribute set below: direct stores
+    // `mine` is the kernel's STATIC xy stage; the dynamic part (code stage / pad) may take what is left of the CU's 160 KB
+    if (mine + (size_t)4 * pp.stage_bytes > 160 * 1024) pp.stage_bytes = 0;      // no room: direct stores
     const size_t stage = (size_t)4 * pp.stage_bytes;
     const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
     int per_cu = env && atoi(env) >= 1 && atoi(env) <= per_cu_max ? atoi(env) : (pp.o.share_cu ? 1 : per_cu_max);
@@ -412,10 +413,10 @@ void launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     size_t pad = stage;
     if (pp.o.share_cu && per_cu == 1 && !pp.o.no_pad && mine + stage < 81 * 1024) pad = 81 * 1024 - mine;
     if (pp.o.skip_if_set) {
-        RML_MAX_DYN_LDS(160 * 1024, &k_project_wave<VT, MODE, NY, G, true>);
+        RML_MAX_DYN_LDS(160 * 1024 - (int)mine, &k_project_wave<VT, MODE, NY, G, true>);
         hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, true>), grid, block, pad, st, pp);
     } else {
-        RML_MAX_DYN_LDS(160 * 1024, &k_project_wave<VT, MODE, NY, G, false>);
+        RML_MAX_DYN_LDS(160 * 1024 - (int)mine, &k_project_wave<VT, MODE, NY, G, false>);
         hipLaunchKernelGGL((k_project_wave<VT, MODE, NY, G, false>), grid, block, pad, st, pp);
     }
 }

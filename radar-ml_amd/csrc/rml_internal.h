@@ -220,6 +220,16 @@ struct rml_svm {
     uint32_t mask_hint = 0;
 };
 
+// host-side packed operands of a model (rml_svm_pack_host fills them, rml_svm_load uploads them)
+struct rml_svm_pack {
+    std::vector<double> W, nsq, term, dnsq;
+    std::vector<float> svf;
+    std::vector<uint8_t> svq;
+    std::vector<int8_t> svd;
+};
+int rml_svm_pack_host(const double* sv, int64_t M, int64_t D, const double* dual_coef, const int32_t* n_support,
+                      int n_classes, int kernel, double gamma, double code_scale, bool has_calib, rml_svm* m, rml_svm_pack* pk);
+
 struct rml_linear {
     int64_t D = 0;
     int C = 0;

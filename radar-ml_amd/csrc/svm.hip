@@ -1467,22 +1467,17 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
 }  // namespace
 
 // ---- model load ---------------------------------------------------------------------------
-extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D,
-                            const double* dual_coef, const double* intercept, const int32_t* n_support,
-                            int n_classes, int kernel, double gamma, double code_scale,
-                            const double* calib_a, const double* calib_b, rml_svm** out) {
-    RML_REQUIRE(ctx && sv && dual_coef && intercept && n_support && out, RML_ERR_INVALID, "rml_svm_load: NULL argument");
+// The host half of rml_svm_load: validation, geometry and every packed operand, no HIP call (the sanitizer build of
+// tools/sanitize drives it on a box without a GPU).  Fills the geometry / flags of *m and the arrays of *pk.
+int rml_svm_pack_host(const double* sv, int64_t M, int64_t D, const double* dual_coef, const int32_t* n_support,
+                      int n_classes, int kernel, double gamma, double code_scale, bool has_calib, rml_svm* m, rml_svm_pack* pk) {
+    RML_REQUIRE(sv && dual_coef && n_support && m && pk, RML_ERR_INVALID, "rml_svm_load: NULL argument");
     RML_REQUIRE(M > 0 && D > 0, RML_ERR_INVALID, "rml_svm_load: empty model");
     RML_REQUIRE(n_classes >= 2 && n_classes <= kMaxC, RML_ERR_UNSUPPORTED, "rml_svm_load: %d classes (supported: 2..%d)", n_classes, kMaxC);
     RML_REQUIRE(kernel == RML_KERNEL_RBF || kernel == RML_KERNEL_LINEAR, RML_ERR_UNSUPPORTED, "rml_svm_load: kernel %d", kernel);
-    RML_REQUIRE((calib_a == nullptr) == (calib_b == nullptr), RML_ERR_INVALID, "rml_svm_load: calib_a/calib_b must both be given");
     int64_t msum = 0;
     for (int c = 0; c < n_classes; ++c) { RML_REQUIRE(n_support[c] >= 0, RML_ERR_INVALID, "rml_svm_load: negative n_support"); msum += n_support[c]; }
     RML_REQUIRE(msum == M, RML_ERR_INVALID, "rml_svm_load: sum(n_support)=%lld != M=%lld", (long long)msum, (long long)M);
-    *out = nullptr;
-    RML_HIP(hipSetDevice(ctx->device));
-    rml_svm* m = new (std::nothrow) rml_svm();
-    RML_REQUIRE(m != nullptr, RML_ERR_NOMEM, "rml_svm_load: out of host memory");
     m->M = M; m->D = D; m->C = n_classes; m->P = n_classes * (n_classes - 1) / 2;
     m->PT = m->P <= 1 ? 1 : (m->P <= 3 ? 3 : (m->P <= 6 ? 6 : (m->P <= 10 ? 10 : 15)));
     m->kernel = kernel; m->gamma = gamma; m->code_scale = code_scale > 1.0 ? code_scale : 1.0;
@@ -1490,10 +1485,11 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
     m->Kq = round_up(D, kStepBytes); m->Kf = round_up(D, 32);
     m->Dq = ((m->Kq / 128) & 1) ? m->Kq : m->Kq + 128;
     m->Df = ((m->Kf / 32) & 1) ? m->Kf : m->Kf + 32;
-    m->has_calib = calib_a != nullptr;
+    m->has_calib = has_calib;
 
     // per-pair SV weights: the pair loop of svm_predict_values (svm.cpp:2864-2883)
-    std::vector<double> W((size_t)m->PT * m->Mpad, 0.0);
+    std::vector<double>& W = pk->W;
+    W.assign((size_t)m->PT * m->Mpad, 0.0);
     {
         std::vector<int64_t> start(n_classes, 0);
         for (int c = 1; c < n_classes; ++c) start[c] = start[c - 1] + n_support[c - 1];
@@ -1505,11 +1501,15 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
             }
     }
     // float operand + norms
-    std::vector<float> svf((size_t)m->Mpad * m->Df, 0.0f);
-    std::vector<double> nsq(m->Mpad, 0.0);
+    std::vector<float>& svf = pk->svf;
+    std::vector<double>& nsq = pk->nsq;
+    svf.assign((size_t)m->Mpad * m->Df, 0.0f);
+    nsq.assign(m->Mpad, 0.0);
     // exact codes: every SV must be bit-identical to float32(c/scale) (or to c when unscaled)
-    std::vector<uint8_t> svq((size_t)m->Mpad * m->Dq, 0);
-    std::vector<double> term(m->Mpad, 0.0);
+    std::vector<uint8_t>& svq = pk->svq;
+    std::vector<double>& term = pk->term;
+    svq.assign((size_t)m->Mpad * m->Dq, 0);
+    term.assign(m->Mpad, 0.0);
     bool exact = true;
     const float fscale = (float)m->code_scale;
     for (int64_t r = 0; r < M; ++r) {
@@ -1542,8 +1542,10 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
     // [-1/2, 1/2] + rounding of c0; rows may leave the SV range by s/2 on either side before they fall back to float64) and
     // c0 the mid-range on a grid of s/256 (so that v - c0 is exact in float64 for float32 v).  Four digit groups share one
     // int32 accumulator: 4 * 128^2 * K < 2^31.
-    std::vector<int8_t> svd;
-    std::vector<double> dnsq;
+    std::vector<int8_t>& svd = pk->svd;
+    std::vector<double>& dnsq = pk->dnsq;
+    svd.clear(); dnsq.clear();
+    m->dig_ok = false;
     if (kernel == RML_KERNEL_RBF && m->Kq < 32768 && m->PT <= 6) {
         double lo = sv[0], hi = sv[0];
         bool finite = true;
@@ -1567,26 +1569,45 @@ extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D
                     const int32_t I = (int32_t)t;
                     const double u = (double)I * 0x1p-31;
                     nn += u * u;
-                    const uint32_t pk = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;     // bytes = balanced digits, a0 on top
-                    for (int dg = 0; dg < 4; ++dg) svd[(size_t)dg * plane + (size_t)r * m->Dq + d] = (int8_t)((pk >> (8 * (3 - dg))) & 255u);
+                    const uint32_t pk4 = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;     // bytes = balanced digits, a0 on top
+                    for (int dg = 0; dg < 4; ++dg) svd[(size_t)dg * plane + (size_t)r * m->Dq + d] = (int8_t)((pk4 >> (8 * (3 - dg))) & 255u);
                 }
                 dnsq[r] = nn;
             }
             if (ok) { m->dig_ok = true; m->dig_c0 = c0; m->dig_s = sd; }
         }
     }
-    int rc = RML_OK;
+    return RML_OK;
+}
+
+extern "C" int rml_svm_load(rml_ctx* ctx, const double* sv, int64_t M, int64_t D,
+                            const double* dual_coef, const double* intercept, const int32_t* n_support,
+                            int n_classes, int kernel, double gamma, double code_scale,
+                            const double* calib_a, const double* calib_b, rml_svm** out) {
+    RML_REQUIRE(ctx && sv && dual_coef && intercept && n_support && out, RML_ERR_INVALID, "rml_svm_load: NULL argument");
+    RML_REQUIRE((calib_a == nullptr) == (calib_b == nullptr), RML_ERR_INVALID, "rml_svm_load: calib_a/calib_b must both be given");
+    *out = nullptr;
+    rml_svm* m = new (std::nothrow) rml_svm();
+    RML_REQUIRE(m != nullptr, RML_ERR_NOMEM, "rml_svm_load: out of host memory");
+    rml_svm_pack pk;
+    int rc = rml_svm_pack_host(sv, M, D, dual_coef, n_support, n_classes, kernel, gamma, code_scale, calib_a != nullptr, m, &pk);
+    if (rc) { delete m; return rc; }
+    {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) { delete m; RML_HIP(e); }
+    }
+    const bool exact = m->exact;
     do {
-        if ((rc = dev_upload(&m->W, W))) break;
-        if ((rc = dev_upload(&m->sv_f32, svf))) break;
-        if ((rc = dev_upload(&m->sv_nsq, nsq))) break;
+        if ((rc = dev_upload(&m->W, pk.W))) break;
+        if ((rc = dev_upload(&m->sv_f32, pk.svf))) break;
+        if ((rc = dev_upload(&m->sv_nsq, pk.nsq))) break;
         if (exact) {
-            if ((rc = dev_upload(&m->sv_q, svq))) break;
-            if ((rc = dev_upload(&m->sv_term_q, term))) break;
+            if ((rc = dev_upload(&m->sv_q, pk.svq))) break;
+            if ((rc = dev_upload(&m->sv_term_q, pk.term))) break;
         }
         if (m->dig_ok) {
-            if ((rc = dev_upload(&m->sv_dig, svd))) break;
-            if ((rc = dev_upload(&m->sv_dig_nsq, dnsq))) break;
+            if ((rc = dev_upload(&m->sv_dig, pk.svd))) break;
+            if ((rc = dev_upload(&m->sv_dig_nsq, pk.dnsq))) break;
         }
         std::vector<double> ic(intercept, intercept + m->P);
         if ((rc = dev_upload(&m->intercept, ic))) break;

@@ -10,9 +10,16 @@ through PyTorch, which the north star allows for these layers.
 """
 import numpy as np
 
-from .nn_common import make_same_conv, to_nchw, flatten_nhwc
+from .nn_common import make_same_conv, to_nchw, flatten_nhwc, tf_same_pad
 
 RESCALE = (80, 80)          # dnn.py:33
+# Margin guard of predict_volumes / predict: rows whose top-2 probability gap is below this are re-scored in float64.  The bf16
+# chain moves a probability by <= 3.4e-3 on trained weights (larger logits) and <= 4.8e-4 on random-init ones (measured against
+# the float64 restatement, tests/test_nn_gpu.py DNN_BF16_PROBA_TOL / _RANDOM_INIT_TOL), i.e. a gap by <= 6.8e-3: 3 x that.
+LABEL_GUARD = 2e-2
+# Second level: the float32 layers on exact inputs are within ~1e-6 of float64 (measured 7e-8 .. 1e-6); rows whose float32 gap is
+# below this go to float64.
+LABEL_GUARD_F32 = 1e-4
 
 
 def define_classifier(xz_shape=(80, 80, 1), yz_shape=(80, 80, 1), xy_shape=(80, 80, 1), n_classes=3,
@@ -275,7 +282,7 @@ class Classifier(_module_base()):
         return torch.softmax(lg.float(), dim=-1)
 
     def predict_volumes(self, volumes, rescale=(80, 80), mode="max", batch_size=16384, overlap=False, trunk_events=None,
-                        exact_resize=False):
+                        exact_resize=False, label_guard=LABEL_GUARD):
         """The whole inference path of BASELINE configs[3] on the GPU: (N,X,Y,Z) volumes (float32 or uint8) ->
         projections as uint8 code rows (csrc/project*.hip) -> [-1,1] scaling + bicubic resize of the three projections in one
         launch, bf16 out (csrc/preprocess.hip: Pillow's windows and weights in float32) -> fused conv trunk (csrc/dnn.hip) ->
@@ -291,6 +298,14 @@ class Classifier(_module_base()):
         (both live on the LDS pipe and the issue ports) and the projection 1.25 x, so the pair costs what the two cost in turn:
         4.6-4.7 against 4.7-4.8 M frames/s.  Kept as a knob.  ``trunk_events``: a list that receives one (start, stop, frames)
         torch.cuda.Event triple per trunk launch (bench.py's in-situ roofline of k_dnn_trunk_rf).
+
+        ``label_guard`` (default LABEL_GUARD = 2e-2; None or 0 turns it off): the margin guard that makes ``argmax`` of the result
+        the float64 label.  The bf16 chain moves a probability by at most 3.4e-3 (measured against the float64 restatement of the
+        Keras layers, trained weights; 4.8e-4 on random-init ones), so a row whose two largest probabilities are more than ``label_guard`` apart
+        has the label the float64 arithmetic gives; the rows closer than that -- and only those -- are scored again from their
+        volumes on the GPU from exact inputs (exact projection, Pillow-bit-identical resize: :meth:`rescore_exact`), in float32 first
+        and, where the float32 gap is below LABEL_GUARD_F32, in float64; their probabilities are replaced.  A device->host count
+        per level; ``self.last_guard`` = {"rows", "rescored", "rescored_float64"}.
         """
         import torch
         from . import common, nn_common, _lib
@@ -299,14 +314,19 @@ class Classifier(_module_base()):
         n = int(volumes.shape[0])
         X, Y, Z = (int(v) for v in volumes.shape[1:])
         if n == 0:
-            return torch.zeros((0, self.n_classes), device=volumes.device if volumes.is_cuda else "cuda")
-        if not volumes.is_cuda:
-            volumes = volumes.to(next(self.parameters()).device)
-        dev = volumes.device
+            return torch.zeros((0, self.n_classes), device=volumes.device if volumes.is_cuda else next(self.parameters()).device)
+        dev = volumes.device if volumes.is_cuda else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("predict_volumes runs on the GPU: move the model to a CUDA device (there is no CPU path)")
+        host = not volumes.is_cuda          # host volumes stay on the host: one slice per pass crosses PCIe, not the whole data set
+
+        def vol(sel):
+            v = volumes[sel.cpu() if (host and isinstance(sel, torch.Tensor)) else sel]
+            return v.to(dev, non_blocking=False) if host else v
         bs = int(min(batch_size, n))
         nb = (n + bs - 1) // bs
         D = common.feature_len(X, Y, Z)
-        overlap = bool(overlap) and nb > 1
+        overlap = bool(overlap) and nb > 1 and not host
         out = torch.empty((n, self.n_classes), dtype=torch.float32, device=dev)
         with torch.no_grad(), torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
@@ -315,12 +335,12 @@ class Classifier(_module_base()):
                 for b in range(nb):
                     s0, s1 = b * bs, min(n, (b + 1) * bs)
                     if fused:
-                        xs = nn_common.preprocess_volumes(volumes[s0:s1], rescale, mode=mode)
+                        xs = nn_common.preprocess_volumes(vol(slice(s0, s1)), rescale, mode=mode)
                     else:
-                        feat = common.process_volumes(volumes[s0:s1], mode=mode, scale=False)
+                        feat = common.process_volumes(vol(slice(s0, s1)), mode=mode, scale=False)
                         xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
                     out[s0:s1] = self._forward_timed(xs, trunk_events)
-                return out
+                return self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(vol(idx), rescale, mode, prec))
             lib = _lib.load()
             ctx = _lib.context(dev)
             sp = getattr(self, "_proj_stream", None)
@@ -368,7 +388,79 @@ class Classifier(_module_base()):
             finally:
                 _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0), "rml_ctx_set_option")
             cur.wait_stream(sp)
+            out = self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(volumes[idx], rescale, mode, prec))
         return out
+
+    # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
+    def _guard(self, proba, eps, rescore, chunk=4096):
+        """Replace the rows of ``proba`` (N, C) whose top-2 gap is below ``eps`` by what exact-input arithmetic gives:
+        ``rescore(row_indices, "float32")`` first (the plain float32 layers: MIOpen / hipBLASLt, error ~1e-6), and for the rows
+        whose float32 gap is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``."""
+        import torch
+        self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
+        if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
+            return proba
+
+        def close(p, gap):
+            top2 = p.float().topk(2, dim=1).values
+            return ((top2[:, 0] - top2[:, 1]) < float(gap)).nonzero().squeeze(1)
+
+        idx = close(proba, eps)                            # the call's first device -> host count
+        self.last_guard["rescored"] = int(idx.numel())
+        for s in range(0, int(idx.numel()), chunk):
+            sel = idx[s:s + chunk]
+            p32 = rescore(sel, "float32")
+            proba[sel] = p32.to(proba.dtype)
+            sel64 = sel[close(p32, LABEL_GUARD_F32)]
+            if sel64.numel():
+                self.last_guard["rescored_float64"] += int(sel64.numel())
+                proba[sel64] = rescore(sel64, "float64").to(proba.dtype)
+        return proba
+
+    def _f64_weights(self):
+        """float64 copies of every parameter, cached until one is written."""
+        import torch
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        if getattr(self, "_f64_key", None) != key:
+            self._f64_key = key
+            self._f64 = {"conv": [[(cv.conv.weight.detach().double(), cv.conv.bias.detach().double()) for cv in br] for br in self.branches],
+                         "fc": [(fc.weight.detach().double(), fc.bias.detach().double()) for fc in (self.fc1, self.fc2, self.fc3)]}
+        return self._f64
+
+    def forward_float64(self, xz, yz, xy):
+        """The layers of dnn.py:45-91 in float64 on the inputs' device: (N,H,W) or (N,1,H,W) planes -> (N, n_classes) float64
+        probabilities.  The guard's arithmetic (a few rows per batch), not a fast path."""
+        import torch
+        import torch.nn.functional as F
+        w = self._f64_weights()
+        outs = []
+        for x, convs in zip((xz, yz, xy), w["conv"]):
+            x = x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).double()
+            for (k, b) in convs:
+                ph, pw = tf_same_pad(x.shape[-2], k.shape[-2], 2), tf_same_pad(x.shape[-1], k.shape[-1], 2)
+                x = F.relu(F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), k, b, stride=2))
+            outs.append(x)
+        h = flatten_nhwc(torch.cat(outs, dim=1))
+        (w1, b1), (w2, b2), (w3, b3) = w["fc"]
+        h = F.relu(F.linear(h, w1, b1))
+        h = F.relu(F.linear(h, w2, b2))
+        return torch.softmax(F.linear(h, w3, b3), dim=-1)
+
+    def rescore_exact(self, volumes, rescale=(80, 80), mode="max", precision="float64"):
+        """(n,X,Y,Z) volumes -> (n, n_classes) probabilities through the reference's chain without a rounding the reference does
+        not have: projection (exact), (p - 127.5) / 127.5 and Pillow's bicubic resize in float64 rounded to float32 planes as
+        Pillow stores them (csrc/resize.hip, bit-identical), then the layers in ``precision``: "float32" (the reference's own
+        arithmetic, dnn.py runs Keras in float32) or "float64" (the oracle's)."""
+        import torch
+        from . import common, nn_common
+        X, Y, Z = (int(v) for v in volumes.shape[1:])
+        with torch.no_grad():
+            feat = common.process_volumes(volumes, mode=mode, scale=False)
+            xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="float32")
+            if precision == "float64":
+                return self.forward_float64(*xs)
+            with torch.autocast("cuda", enabled=False):
+                return self(*[x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]) for x in xs])
 
     def _features_timed(self, xs, trunk_events, layout="nhwc"):
         import torch
@@ -385,8 +477,10 @@ class Classifier(_module_base()):
         kb = self.kblock_supported(int(xs[0].shape[-2]), int(xs[0].shape[-1]))
         return self.dense_tail(self._features_timed(xs, trunk_events, "kblock" if kb else "nhwc"), kblock=kb)
 
-    def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16"):
-        """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy."""
+    def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16", label_guard=LABEL_GUARD):
+        """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy.  Under autocast on the
+        GPU the margin guard of :meth:`predict_volumes` applies: rows whose top-2 gap is below ``label_guard`` are scored again
+        in float64 from the same input planes, so ``argmax`` is the float64 label."""
         import torch
         dev = next(self.parameters()).device
         dt = getattr(torch, autocast_dtype) if autocast_dtype else None
@@ -400,6 +494,8 @@ class Classifier(_module_base()):
                 if dt is not None and dev.type == "cuda":
                     with torch.autocast("cuda", dtype=dt):
                         p = self(*xs)
+                    p = self._guard(p.float(), label_guard,
+                                    lambda idx, prec: self.forward_float64(*[x[idx] for x in xs]) if prec == "float64" else self(*[x[idx] for x in xs]))
                 else:
                     p = self(*xs)
                 outs.append(p.float().cpu())

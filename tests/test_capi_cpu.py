@@ -214,3 +214,23 @@ def test_slice_indices_accept_every_integer_dtype():
             _slice_indices(bad, 1, X, Y, Z, cpu)
     with pytest.raises(IndexError):
         _slice_indices(np.array([[0.0, 1.0, 2.0]]), 1, X, Y, Z, cpu)
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """SURVEY.md 5 (sanitizer target): the HOST half of every csrc/*.hip compiled with -fsanitize=address,undefined
+    (tools/sanitize/build.py: hipcc --cuda-host-only, seconds) and driven through the C ABI and the host-only internals --
+    argument validation of every front door, thread-local error messages from four threads, the model packing of rml_svm_load on
+    edge shapes (on / off the code grid, NaN, 2..6 classes, linear kernel), Pillow's table builder, the shape predicates, and the
+    graceful failure of rml_ctx_create on a box without a GPU.  A sanitizer report aborts the driver; its own checks exit 1."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sanitize"))
+    import importlib
+    sb = importlib.import_module("build")
+    sys.path.pop(0)
+    lib, drv = sb.build()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([drv], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env, cwd="/tmp")
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-4000:]
+    assert "phase A: ok" in out and "ALL OK" in out and "runtime error" not in out and "AddressSanitizer" not in out, out[-4000:]

@@ -288,3 +288,105 @@ def test_cnn_chain_entry_points_reject_bad_arguments(rml):
     xf = torch.zeros((2, 12, 12), device="cuda")
     assert lib.rml_dnn_trunk_kblock(ctx, _lib.ptr(xf), _lib.ptr(xf), _lib.ptr(xf), 0, 2, 12, 12, _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(w2c),
                                     _lib.ptr(b2c), _lib.ptr(fk), st) == -2 and b"even" in lib.rml_last_error()
+
+
+def test_probe_stream_and_rmw_default(rml):
+    """rml_probe_stream: the streaming-read denominator of bench.py -- argument checks and a plausible MI355X figure (between a
+    third of the 8 TB/s specification and the specification); rml_code_rmw_default follows the rule and the environment."""
+    import os
+    import torch
+    from radar_ml_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.context()
+    st = _lib.stream_ptr()
+    gbs = C.c_double()
+    buf = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda")
+    assert lib.rml_probe_stream(ctx, None, buf.numel(), 3, C.byref(gbs), st) == -1
+    assert lib.rml_probe_stream(ctx, _lib.ptr(buf), 1000, 3, C.byref(gbs), st) == -1 and b"1 MiB" in lib.rml_last_error()
+    assert lib.rml_probe_stream(ctx, C.c_void_p(buf.data_ptr() + 4), buf.numel() - 16, 3, C.byref(gbs), st) == -1
+    assert lib.rml_probe_stream(ctx, _lib.ptr(buf), buf.numel(), 10, C.byref(gbs), st) == 0
+    print("rml_probe_stream: %.0f GB/s" % gbs.value)
+    assert 2600.0 < gbs.value < 8000.0
+    old = os.environ.pop("RML_CODE_RMW", None)
+    try:
+        # 64x64x128: uint8 volumes on, float32 max off, derive on; Walabot grid uint8 off (csrc/rml_internal.h)
+        assert lib.rml_code_rmw_default(20480, 64 * 64 * 128, 0, 1) == 1
+        assert lib.rml_code_rmw_default(20480, 4 * 64 * 64 * 128, 0, 0) == 0
+        assert lib.rml_code_rmw_default(20480, 4 * 64 * 64 * 128, 1, 0) == 1
+        assert lib.rml_code_rmw_default(10010, 22 * 31 * 176, 0, 1) == 0
+        os.environ["RML_CODE_RMW"] = "1"
+        assert lib.rml_code_rmw_default(10010, 22 * 31 * 176, 0, 1) == 1
+    finally:
+        os.environ.pop("RML_CODE_RMW", None)
+        if old is not None:
+            os.environ["RML_CODE_RMW"] = old
+
+
+def test_four_threads_two_streams_one_context(rml):
+    """one rml_ctx shared by host threads -- the workspace users serialise on the context's mutex and on its
+    last-use event.  Four threads over two streams hammer the three workspace users at once (the fused projection -> SVM pipeline
+    with several chunks, rml_svm_decision on rows, derive + projection); every result must be the single-threaded one, bit for
+    bit, every time."""
+    import threading
+    import torch
+    import oracle_np as O
+    from conftest import load_golden, svm_model_arrays
+    g = load_golden("svm_walabot.npz")
+    sv = (g["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    svc = rml.GpuSVC(sv, g["dual_coef"], g["intercept"], g["n_support"], float(g["gamma"]), g["classes"],
+                     calib_a=g["calib_a"], calib_b=g["calib_b"])
+    vol = torch.from_numpy(g["test_vol_u8"].astype(np.float32)).cuda()                  # (128, 22, 31, 176)
+    big = vol.repeat(80, 1, 1, 1)                                                        # 10 240 frames: two pipeline chunks
+    rows = rml.process_volumes(vol, mode="max", scale=True)
+    want_pipe = {k: v.clone() for k, v in svc.decide_volumes(big, mode="max", scale=True, want_proba=True).items()}
+    want_rows = svc.decision_function(rows.cpu().numpy())
+    want_ijk = rml.derive_targets(vol, 2).cpu().numpy()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    errs = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i % 2]):
+                for it in range(12):
+                    if i in (0, 1):
+                        out = svc.decide_volumes(big, mode="max", scale=True, want_proba=True)
+                        streams[i % 2].synchronize()
+                        for k in ("dec_ovo", "proba", "label_vote", "label_calib"):
+                            assert torch.equal(out[k], want_pipe[k]), (i, it, k)
+                    elif i == 2:
+                        assert np.array_equal(svc.decision_function(rows.cpu().numpy()), want_rows), (i, it)
+                    else:
+                        assert np.array_equal(rml.derive_targets(vol, 2).cpu().numpy(), want_ijk), (i, it)
+                        p = rml.process_volumes(vol, mode="max", scale=True)
+                        assert torch.equal(p, rows), (i, it)
+        except Exception as e:          # pragma: no cover
+            errs.append(repr(e)[:500])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not any(t.is_alive() for t in ts), "a thread is stuck"
+    assert not errs, errs
+
+
+def test_c_driver_four_threads_on_one_context(rml):
+    """The sanitizer driver's device phase (tools/sanitize/driver.cpp), as a plain C++ program against the real library: no Python,
+    no torch allocator -- hipMalloc'ed buffers, four host threads on two streams through rml_project_svm on one rml_ctx, results
+    compared bit for bit.  (Its host phase runs under ASAN/UBSAN in the CPU suite.)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from radar_ml_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sanitize"))
+    import importlib
+    sb = importlib.import_module("build")
+    sys.path.pop(0)
+    drv = sb.build_driver_for(_lib.LIB_PATH)
+    r = subprocess.run([drv, "--need-device"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd="/tmp")
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-4000:]
+    assert "phase A: ok" in out and "phase B: 9000 frames x 4 threads" in out and "ALL OK" in out, out[-4000:]

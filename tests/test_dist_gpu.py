@@ -94,7 +94,7 @@ def _check_pair(l1, l2, per_rank):
     assert "error" not in sg, sg
     assert sg["replicas_identical"] is True and sg["hip_graph"] is True and sg["n_gpus"] == 2
     assert l2["roofline"].get("traffic") is None and "traffic_note" in l2["doc"]["roofline"]
-    assert l2["doc"]["dnn_forward"]["parity"]["label_mismatch"] <= 2
+    assert l1["doc"]["dnn_forward"]["parity"]["label_mismatch"] == 0 and l2["doc"]["dnn_forward"]["parity"]["label_mismatch"] == 0
 
 
 def test_two_rank_bench_over_rccl_when_two_devices_are_visible():

@@ -26,9 +26,22 @@ def test_dnn_forward_bf16_vs_fp32_cpu(rml):
     print("dnn bf16 autocast vs fp32 cpu (random init): max |dp| = %.2e, label agreement %.4f"
           % (np.abs(got16 - want).max(), (got16.argmax(1) == want.argmax(1)).mean()))
     assert np.abs(got16 - want).max() < DNN_BF16_RANDOM_INIT_TOL    # bf16 tolerance on probabilities
-    srt = np.sort(want, axis=1)
-    confident = (srt[:, -1] - srt[:, -2]) > 5e-3                  # random-init outputs sit near 1/3: compare labels off the ties only
-    np.testing.assert_array_equal(got16.argmax(1)[confident], want.argmax(1)[confident])
+    # labels: bit-exact against the float64 restatement of the Keras layers on EVERY row (north_star: "class labels bit-exact").
+    # Random-init outputs sit near 1/3 each, the hardest case for a bf16 chain: the margin guard (dnn.LABEL_GUARD) re-scores the
+    # rows whose top-2 gap the bf16 error could cross in float64; without it the disagreements are all inside that gap.
+    import oracle_np as O
+    convs, dense = cpu.keras_weights()
+    want64 = O.dnn_forward(*[a[..., 0].astype(np.float64) for a in x], convs, dense)
+    np.testing.assert_array_equal(got16.argmax(1), want64.argmax(1))
+    assert 0 < gpu.last_guard["rescored"] <= len(want64)
+    raw = gpu.predict(x, autocast_dtype="bfloat16", label_guard=None)
+    assert gpu.last_guard["rescored"] == 0
+    srt = np.sort(want64, axis=1)
+    off = raw.argmax(1) != want64.argmax(1)
+    print("unguarded bf16 labels: %d of %d differ from float64, largest oracle gap among them %.2e (guard %.0e re-scored %d rows)"
+          % (int(off.sum()), len(off), float((srt[:, -1] - srt[:, -2])[off].max()) if off.any() else 0.0, dnn.LABEL_GUARD,
+             int(((np.sort(raw, axis=1)[:, -1] - np.sort(raw, axis=1)[:, -2]) < dnn.LABEL_GUARD).sum())))
+    assert not off.any() or float((srt[:, -1] - srt[:, -2])[off].max()) < dnn.LABEL_GUARD / 2
 
 
 def test_resize_bit_exact_vs_pillow_golden(rml):
@@ -135,11 +148,11 @@ def _train_classifier_with_margins(dnn, steps=160, seed=21):
     return model.to("cpu"), vol[768:], np.asarray(cls)[768:]
 
 
-def test_dnn_trained_model_labels_match_the_oracle_where_its_margin_allows(rml):
+def test_dnn_trained_model_labels_match_the_oracle_on_every_row(rml):
     """a-9 on a model with real margins (random-init outputs sit at ~1/3 each and say nothing): the bf16 GPU chain
     (projection -> resize -> fused trunk -> dense tail) against the float64 NumPy restatement of the Keras layers on the same
-    trained weights: probabilities within DNN_BF16_PROBA_TOL and the SAME LABEL wherever the oracle's top-2 margin exceeds
-    1e-2; the rows inside the margin are counted and reported, not asserted."""
+    trained weights: probabilities within DNN_BF16_PROBA_TOL and the SAME LABEL ON EVERY ROW -- the margin guard of
+    predict_volumes re-scores the rows the bf16 error could flip in float64 (north_star: "class labels bit-exact")."""
     import oracle_np as O
     dnn = importlib.import_module("radar_ml_amd.dnn")
     cpu, vol, cls = _train_classifier_with_margins(dnn)
@@ -159,8 +172,13 @@ def test_dnn_trained_model_labels_match_the_oracle_where_its_margin_allows(rml):
     print("trained dnn: oracle accuracy %.3f, mean top-2 margin %.3f, %d of %d rows inside the 1e-2 margin, max |dp| bf16 vs float64 = %.2e"
           % (acc, float(margin.mean()), int((~confident).sum()), len(margin), err))
     assert acc > 0.6 and float(margin.mean()) > 0.2                  # the model did learn: outputs are not ~1/3
-    np.testing.assert_array_equal(got.argmax(1)[confident], want.argmax(1)[confident])
+    np.testing.assert_array_equal(got.argmax(1), want.argmax(1))
     assert err <= DNN_BF16_PROBA_TOL
+    print("margin guard: %d of %d rows re-scored in float64" % (gpu.last_guard["rescored"], gpu.last_guard["rows"]))
+    assert gpu.last_guard["rescored"] <= int((margin < 2 * dnn.LABEL_GUARD).sum())       # only rows near a tie pay for it
+    # host volumes stream through per batch (nothing but the slices crosses PCIe) and give the same answer
+    got_h = gpu.predict_volumes(torch.from_numpy(vol), batch_size=128).cpu().numpy()
+    np.testing.assert_array_equal(got_h, got)
 
 
 def test_dnn_full_size_batch_size_independent_properties(rml):
@@ -169,11 +187,11 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     properties that need no oracle of that size:
       * batching independence: the whole batch in one call against the same frames in three ragged calls (other internal batch
         boundaries, other last-batch sizes): probabilities equal to bf16 round-off (2e-3; hipBLASLt picks its kernel by the
-        batch's row count), labels equal outside the 1e-2 margin; the same batches again, on one stream or two: BIT-identical;
+        batch's row count), labels equal on every row (the margin guard); the same batches again, on one stream or two: BIT-identical;
       * ingest independence: the same frames as uint8 volumes give bit-identical probabilities (the projections are the same
         float32 values either way);
       * the float64 NumPy restatement of the chain on 96 frames drawn from the whole range, trained weights with real margins:
-        probabilities within DNN_BF16_PROBA_TOL and the same label wherever the oracle's top-2 margin exceeds 1e-2."""
+        probabilities within DNN_BF16_PROBA_TOL and the same label on every row."""
     import oracle_np as O
     import gc
     dnn = importlib.import_module("radar_ml_amd.dnn")
@@ -190,9 +208,7 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
         # count: a batch of another size gives the same probabilities to bf16 round-off, not the same bits
         a, b = a.float(), b.float()
         assert float((a - b).abs().max()) <= 2e-3, (what, float((a - b).abs().max()))
-        srt = torch.sort(b, dim=1).values
-        conf = (srt[:, -1] - srt[:, -2]) > 1e-2
-        assert torch.equal(a.argmax(1)[conf], b.argmax(1)[conf]), what
+        assert torch.equal(a.argmax(1), b.argmax(1)), what          # float64 labels either way (margin guard)
 
     cuts = [0, frames // 3 + 777, frames // 3 + 777 + 9999, frames]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
@@ -212,11 +228,8 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     convs, dense = cpu.keras_weights()
     want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
     got = whole[torch.as_tensor(pick, device=V.device)].float().cpu().numpy()
-    srt = np.sort(want, axis=1)
-    confident = (srt[:, -1] - srt[:, -2]) > 1e-2
     assert np.abs(got - want).max() <= DNN_BF16_PROBA_TOL
-    np.testing.assert_array_equal(got.argmax(1)[confident], want.argmax(1)[confident])
-    assert confident.sum() > len(pick) // 2
+    np.testing.assert_array_equal(got.argmax(1), want.argmax(1))
     del V, whole, v8
     gc.collect(); torch.cuda.empty_cache()
 
