@@ -824,7 +824,8 @@ def run_dnn(a, env):
                         "launches": len(ms_l), "min_launch_ms": round(float(np.min(ms_l)), 4), "max_launch_ms": round(float(np.max(ms_l)), 4),
                         "algorithmic_flop_per_frame": conv_flop, "traffic": None},
            # the margin guard (Classifier.predict_volumes: rows whose top-2 gap is below dnn.LABEL_GUARD are scored again in float64)
-           "margin_guard": {"gap": dnn.LABEL_GUARD, "gap_float32": dnn.LABEL_GUARD_F32, "rows": guard["f32"]["rows"], "rescored": guard["f32"]["rescored"],
+           "margin_guard": {"gap_initial": dnn.LABEL_GUARD, "gap_used": guard["f32"].get("gap"), "observed_bf16_error": guard["f32"].get("observed_error"),
+                            "gap_float32": dnn.LABEL_GUARD_F32, "rows": guard["f32"]["rows"], "rescored": guard["f32"]["rescored"],
                             "rescored_float64": guard["f32"]["rescored_float64"],
                             "value_without_guard": round(world * B * a.steps / res["f32_noguard"][0], 1),
                             "cost_frac": round(res["f32"][0] / res["f32_noguard"][0] - 1.0, 4),
@@ -899,7 +900,28 @@ def run_sgan(a, env, n=256, hw=128, steps=None):
         same = all(bool(torch.equal(b, both[0])) for b in both)
     if rank != 0:
         return None
+    # algorithmic FLOPs of one update on one sample (sgan.py:132-217): per branch three 3x3 stride-2 convolutions (1 -> 128 -> 64 ->
+    # 32 channels, hw -> hw/8), then the dense layers; a training update = forward + data gradient + weight gradient of every
+    # layer, the first convolution having no data gradient (its input is the data).  Batch norm / activations / optimizer: not counted.
+    fwd, first = 0.0, 0.0
+    for (h_, w_, c_) in d.shapes:
+        ch = c_
+        for li, co in enumerate((128, 64, 32)):
+            h_, w_ = -(-h_ // 2), -(-w_ // 2)
+            f = 2.0 * h_ * w_ * co * ch * 9
+            fwd += f
+            first += f if li == 0 else 0.0
+            ch = co
+    fwd += 2.0 * (d.flat_features * 64 + 64 * 64 + 64 * d.n_classes)
+    flop_update = 3.0 * fwd - first
+    F16_PEAK = 2500.0                                   # MI355X_MICROARCH.md: dense fp16 MFMA (= bf16)
+    tf = 3 * n * flop_update / dt / 1e12
     return {"metric": "sgan discriminator train step (c + d_real[class_weight] + d_fake updates, sgan.py:525-532)",
+            "roofline": {"bound": "mfma", "kernel": "MIOpen igemm fwd / bwd / wrw (layers 2-3) + csrc/bnact.hip first layer", "achieved": round(tf, 1),
+                         "peak": F16_PEAK, "unit": "TFLOP/s", "frac": round(tf / F16_PEAK, 4),
+                         "algorithmic_flop_per_sample_update": flop_update,
+                         "note": "whole three-update step over its wall time (launch-bound small convolutions: 128x128 planes, batch 256); "
+                                 "the convolutions' own share is in profiles/r05_stats_sgan.txt"},
             "value": round(world * 3 * n / dt, 1), "unit": "samples/s", "updates_per_step": 3,
             "ms_per_step": round(dt * 1e3, 2), "batch_per_gpu": n, "global_batch": world * n, "n_gpus": world,
             "parallelism": "data parallel x%d: one flat-bucket gradient all-reduce (%d parameters) per update"
@@ -1153,7 +1175,8 @@ def main():
                                     "guard": [dnn_row["margin_guard"]["rescored"], dnn_row["margin_guard"]["rescored_float64"], dnn_row["margin_guard"]["rows"],
                                               dnn_row["margin_guard"]["cost_frac"]]}
         if sgan_row is not None and "value" in sgan_row:
-            summ["sgan_configs4"] = {"v": sgan_row["value"], "ms": sgan_row["ms_per_step"], "same": sgan_row["replicas_identical"]}
+            summ["sgan_configs4"] = {"v": sgan_row["value"], "ms": sgan_row["ms_per_step"], "same": sgan_row["replicas_identical"],
+                                     "mfma": sgan_row["roofline"]["frac"]}
         summ["parity_gate"] = "pass" if not fails else fails
         rf = res["roofline"]
         cb = res["cpu_baseline"]

@@ -893,13 +893,12 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     float* part = workspace;
     float* sums = part + (size_t)G * 11 * C;
     const float* img = img_stats;
-    // four channels per thread where the channel groups divide the workgroup (C = 128: 32 groups x 8 pixels); RML_C1_CPT=8: round 2's
-    static const bool cpt8 = [] { const char* e = getenv("RML_C1_CPT"); return e && atoi(e) == 8; }();
-    const bool four = !cpt8 && C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
+    // four channels per thread where the channel groups divide the workgroup (C = 128: 32 groups x 8 pixels)
+    const bool four = C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
     // C = 128 and rows of 16 / 32 / 64 pixels: the packed kernel (RML_C1_PK=0: the general one)
     const char* pke = getenv("RML_C1_PK");             // read per call: the tests flip it
     const bool pk_on = !pke || atoi(pke) != 0;
-    const bool pk = pk_on && !cpt8 && C == 128 && (W == 16 || W == 32 || W == 64);
+    const bool pk = pk_on && C == 128 && (W == 16 || W == 32 || W == 64);
     if (pk) {
         // one round of resident workgroups (166 registers at W = 64: three per CU), rows strided over them
         auto go = [&](auto bf, auto nb) {

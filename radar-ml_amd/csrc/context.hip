@@ -64,30 +64,16 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
     RML_REQUIRE(c != nullptr, RML_ERR_NOMEM, "rml_ctx_create: out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    // CU masks on MI355X (measured, tools/exp/exp_cumask.hip): mask bit i selects local CU i/8 of XCD i%8; an XCD
-    // left without any CU makes the runtime ignore the mask for that XCD.
-    const char* env = getenv("RML_GEMM_CUS");
-    int g = env ? atoi(env) : 0;
-    hipError_t e = hipSuccess;
-    if (g > 0 && g < 32 && prop.multiProcessorCount == 256) {
-        uint32_t mg[8] = {0}, mp[8] = {0};
-        for (int bit = 0; bit < 256; ++bit) ((bit / 8) < g ? mg : mp)[bit / 32] |= 1u << (bit % 32);
-        e = hipExtStreamCreateWithCUMask(&c->aux_stream, 8, mg);
-        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->proj_stream, 8, mp);
-        c->gemm_cus_per_xcd = g;
-    } else {
-        e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    }
+    // (CU-masked streams for a GEMM / projection partition lived here in rounds 2-4 -- mask bit i selects local CU i/8 of XCD
+    // i%8, tools/exp/exp_cumask.hip -- and never won a measurement: DESIGN.md 3.3.)
+    hipError_t e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ev_proj[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_flags[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gemm[i], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
         return rml_hip_fail(e, "stream/event creation", __FILE__, __LINE__);
@@ -104,19 +90,15 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
         if (ctx->ev_proj[i]) (void)hipEventDestroy(ctx->ev_proj[i]);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
-        if (ctx->ev_flags[i]) (void)hipEventDestroy(ctx->ev_flags[i]);
-        if (ctx->ev_gemm[i]) (void)hipEventDestroy(ctx->ev_gemm[i]);
     }
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_ev_g) (void)hipEventDestroy(e);
     for (const rml_resize_tab& t : ctx->resize_tabs) (void)hipFree(const_cast<double*>(t.kk));
     for (const rml_pre_tab& t : ctx->pre_tabs) (void)hipFree(t.dev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    if (ctx->proj_stream) (void)hipStreamDestroy(ctx->proj_stream);
     delete ctx;
     return RML_OK;
 }

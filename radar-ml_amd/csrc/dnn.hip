@@ -643,8 +643,7 @@ namespace {
 template <bool INBF>
 int dispatch_trunk(const TrunkArgs& a, int num_cu, hipStream_t st) {
     int rc = RML_ERR_UNSUPPORTED;
-    static const int which = [] { const char* e = getenv("RML_DNN_TRUNK"); return e ? atoi(e) : 1; }();      // 0: LDS-image kernel only
-    if (which || a.kblock) rc = launch_trunk_rf<INBF>(a, num_cu, st);
+    rc = launch_trunk_rf<INBF>(a, num_cu, st);
     if (rc != RML_ERR_UNSUPPORTED || a.kblock) return rc;          // the K-block layout exists in the register-resident kernel only
     // (measured and dropped: a wave-specialised variant -- one 8-wave workgroup per CU, 4 producer waves doing conv1 and 4
     // consumer waves doing conv2 on a double-buffered conv1 image, one producer and one consumer per SIMD: 0.72 ms against

@@ -402,8 +402,7 @@ void launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     // `mine` is the kernel's STATIC xy stage; the dynamic part (code stage / pad) may take what is left of the CU's 160 KB
     if (mine + (size_t)4 * pp.stage_bytes > 160 * 1024) pp.stage_bytes = 0;      // no room: direct stores
     const size_t stage = (size_t)4 * pp.stage_bytes;
-    const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
-    int per_cu = env && atoi(env) >= 1 && atoi(env) <= per_cu_max ? atoi(env) : (pp.o.share_cu ? 1 : per_cu_max);
+    int per_cu = pp.o.share_cu ? 1 : per_cu_max;
     if (per_cu * (mine + stage) > 160 * 1024) per_cu = 1;      // (measured: one or two of these workgroups per CU stream equally fast)
     const int64_t want = (pp.B + 3) / 4;
     const int64_t cap = (int64_t)num_cu * per_cu;
@@ -658,8 +657,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
         }
     }
     if (fast_ok && try_launch_wave<VT, MODE>(pp, num_cu, st)) { *used_fast = true; return 0; }
-    static const bool allow_rowgroup = [] { const char* e = getenv("RML_ROWGROUP"); return !e || atoi(e) != 0; }();
-    if (fast_ok && allow_rowgroup && (Z / 4) != next_pow2(Z / 4) && (Z / 4) >= 8) {
+    if (fast_ok && (Z / 4) != next_pow2(Z / 4) && (Z / 4) >= 8) {
         // rows that are not a power-of-two number of float4: row groups with every lane busy
         const int zq = Z / 4;
         int R = 64 / gcd_int(zq, 64);
@@ -735,8 +733,7 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     pp.tpf = targets_per_frame;
     if (getenv("RML_WAVE_SHARE")) pp.o.share_cu = 1;    // measurement knob: the pipeline's kernel configuration in a stand-alone launch
     if (ctx && ctx->opt_project_share_cu) pp.o.share_cu = 1;      // rml_ctx_set_option(RML_OPT_PROJECT_SHARE_CU)
-    // with a CU partition (RML_GEMM_CUS) the masked projection stream owns 32 - g CUs of every XCD: persistent grids are sized for them
-    const int num_cu = !ctx ? 256 : ((ctx->gemm_cus_per_xcd > 0 && st == ctx->proj_stream) ? 8 * (32 - ctx->gemm_cus_per_xcd) : ctx->num_cu);
+    const int num_cu = !ctx ? 256 : ctx->num_cu;
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;
     RML_HIP(hipGetLastError());
@@ -751,7 +748,7 @@ int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, 
     ProjParams pp;
     fill_params(pp, V, B, X, Y, Z, nullptr, o);
     pp.ntgt = num_targets; pp.ijk_out = ijk_out; pp.profiles = profiles;
-    const int num_cu = !ctx ? 256 : ((ctx->gemm_cus_per_xcd > 0 && st == ctx->proj_stream) ? 8 * (32 - ctx->gemm_cus_per_xcd) : ctx->num_cu);
+    const int num_cu = !ctx ? 256 : ctx->num_cu;
     if (!try_launch_derive_slice(pp, vdtype == RML_VOL_U8 ? 1 : 4, num_cu, st)) return RML_ERR_UNSUPPORTED;
     RML_HIP(hipGetLastError());
     return RML_OK;

@@ -170,8 +170,7 @@ void launch_lin(const ProjParams& pp_in, int num_cu, hipStream_t st) {
     const size_t images = (size_t)4 * (NI * 64 * 16 + NI * NGRP * 64 * 4);
     if (images + (size_t)4 * pp.stage_bytes > kMaxLds) pp.stage_bytes = 0;      // no room for the code stage: direct stores
     const size_t mine = images + (size_t)4 * pp.stage_bytes;
-    const char* env = getenv("RML_WAVE_PERCU");        // experiment knob: persistent workgroups per CU
-    int per_cu = env && atoi(env) >= 1 && atoi(env) <= 2 ? atoi(env) : (pp.o.share_cu ? 1 : 2);
+    int per_cu = pp.o.share_cu ? 1 : 2;
     if (per_cu * mine > 160 * 1024) per_cu = 1;         // (measured: one or two of these workgroups per CU stream equally fast)
     const int64_t want = (pp.B + 3) / 4;
     const int64_t cap = (int64_t)num_cu * per_cu;

@@ -393,9 +393,7 @@ bool derive_geom(int X, int Y, int Z, int ntgt, DeriveGeom* g) {
     if (ZQ > 64) return false;
     const int P = odd_part(ZQ);
     if (P > 15) return false;
-    int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));
-    const char* ue = getenv("RML_DERIVE_U2");           // experiment knob: two periods in flight per wave (P = 1: 16, P = 11: 22)
-    if (ue && atoi(ue) == 1 && (P == 1 || P == 11)) U *= 2;
+    const int U = P == 1 ? 8 : (P == 3 ? 9 : (P == 5 ? 10 : P));     // (two periods in flight per wave -- U = 16 / 22 -- measured slower: tools/exp/README.md)
     const int pq = Y * ZQ;
     const int NI = (pq + 63) / 64, NG = (NI + U - 1) / U;
     const int UP = (U + 3) & ~3, PH = (P + 1) / 2;
@@ -420,8 +418,6 @@ void launch_derive_pu(const ProjParams& pp, size_t wave_lds, int num_cu, hipStre
     size_t lds = (size_t)wpb * wave_lds;
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 512));
     per_cu = per_cu < 1 ? 1 : (per_cu > 5 ? 5 : per_cu);
-    const char* env = getenv("RML_DERIVE_PERCU");       // experiment knob
-    if (env && atoi(env) >= 1 && atoi(env) <= 8) per_cu = atoi(env);
     if (share) {
         per_cu = 1;
         if (!pp.o.no_pad && lds < 81 * 1024) lds = 81 * 1024;
@@ -437,12 +433,12 @@ template <typename VT>
 bool launch_derive_t(const ProjParams& pp, const DeriveGeom& g, int num_cu, hipStream_t st) {
     const size_t lds = g.wave_lds;                      // per wave; the launcher multiplies by its waves per workgroup
     switch (g.P) {
-        case 1: if (g.U == 16) launch_derive_pu<VT, 1, 16>(pp, lds, num_cu, st); else launch_derive_pu<VT, 1, 8>(pp, lds, num_cu, st); return true;
+        case 1: launch_derive_pu<VT, 1, 8>(pp, lds, num_cu, st); return true;
         case 3: launch_derive_pu<VT, 3, 9>(pp, lds, num_cu, st); return true;
         case 5: launch_derive_pu<VT, 5, 10>(pp, lds, num_cu, st); return true;
         case 7: launch_derive_pu<VT, 7, 7>(pp, lds, num_cu, st); return true;
         case 9: launch_derive_pu<VT, 9, 9>(pp, lds, num_cu, st); return true;
-        case 11: if (g.U == 22) launch_derive_pu<VT, 11, 22>(pp, lds, num_cu, st); else launch_derive_pu<VT, 11, 11>(pp, lds, num_cu, st); return true;
+        case 11: launch_derive_pu<VT, 11, 11>(pp, lds, num_cu, st); return true;
         case 13: launch_derive_pu<VT, 13, 13>(pp, lds, num_cu, st); return true;
         case 15: launch_derive_pu<VT, 15, 15>(pp, lds, num_cu, st); return true;
         default: return false;

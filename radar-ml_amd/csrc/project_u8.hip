@@ -236,26 +236,23 @@ void launch_u8_max_f(const ProjParams& pp, int CPR, int S, size_t lds_bytes, hip
 }
 template <int NM>
 void launch_u8_max(const ProjParams& pp, int CPR, int S, int G, size_t lds_bytes, hipStream_t st) {
-    // rows of 128 / 256 voxels: the cross-lane steps on the VALU (RML_U8_XLANE=0: the ds_bpermute path, for A/B)
+    // rows of 128 / 256 voxels: the cross-lane steps on the VALU (the ds_bpermute path for the other geometries)
     // G: the power-of-two lane geometry try_launch_u8_max chose (0: the row's own chunk count -- S alone cannot tell, 64 / 13 is 4 too)
-    static const bool xlane = [] { const char* e = getenv("RML_U8_XLANE"); return !e || atoi(e) != 0; }();
-    if (xlane && G == 8) launch_u8_max_f<NM, 8>(pp, CPR, S, lds_bytes, st);
-    else if (xlane && G == 16) launch_u8_max_f<NM, 16>(pp, CPR, S, lds_bytes, st);
+    if (G == 8) launch_u8_max_f<NM, 8>(pp, CPR, S, lds_bytes, st);
+    else if (G == 16) launch_u8_max_f<NM, 16>(pp, CPR, S, lds_bytes, st);
     else launch_u8_max_f<NM, 0>(pp, CPR, S, lds_bytes, st);
 }
 
 }  // namespace
 
 bool rmlproj::try_launch_u8_max(const ProjParams& pp, hipStream_t st) {
-    static const bool allow = [] { const char* e = getenv("RML_U8_NATIVE"); return !e || atoi(e) != 0; }();
     const int X = pp.X, Y = pp.Y, Z = pp.Z;
-    if (!allow || Z % 16 != 0 || Z / 16 > 64 || (reinterpret_cast<uintptr_t>(pp.V) & 15) != 0) return false;
+    if (Z % 16 != 0 || Z / 16 > 64 || (reinterpret_cast<uintptr_t>(pp.V) & 15) != 0) return false;
     const int CPR = Z / 16;
     // lane geometry: the row's own chunk count, or -- rows of 5..7 / 9..15 chunks whose planes then still fit 8 rows per lane -- the
-    // next power of two (RML_U8_PADGEOM=0: never), which moves the cross-lane steps from ds_bpermute to the VALU
-    static const bool padgeom = [] { const char* e = getenv("RML_U8_PADGEOM"); return !e || atoi(e) != 0; }();
+    // next power of two, which moves the cross-lane steps from ds_bpermute to the VALU
     int G = (CPR == 8 || CPR == 16) ? CPR : 0;
-    if (padgeom && G == 0) {
+    if (G == 0) {
         const int g2 = CPR > 8 && CPR < 16 ? 16 : (CPR > 4 && CPR < 8 ? 8 : 0);
         if (g2 && (Y + 64 / g2 - 1) / (64 / g2) <= 8) G = g2;
     }

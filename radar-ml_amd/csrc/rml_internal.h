@@ -30,16 +30,8 @@ struct rml_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_proj[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};   // chunk pipeline of rml_project_svm (up to 3 workspaces)
+    hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm (two workspaces)
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
-    // third stream of rml_project_svm: the small kernels either side of a chunk's GEMM (tile decision and predicated second
-    // projection pass before it, k_svm_finish after it), so that the GEMM stream carries nothing but GEMMs back to back
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_flags[3] = {nullptr, nullptr, nullptr}, ev_gemm[3] = {nullptr, nullptr, nullptr};
-    // optional CU partition (RML_GEMM_CUS=g): aux_stream is restricted to g CUs of every XCD and proj_stream to
-    // the remaining 32-g, so the MFMA-bound GEMM and the HBM-bound projection stop fighting for wave slots/LDS
-    hipStream_t proj_stream = nullptr;
-    int gemm_cus_per_xcd = 0;
     // optional in-situ timing of the projection launches issued by rml_project_svm
     bool profiling = false;
     std::vector<hipEvent_t> prof_ev;    // start/stop pairs
@@ -172,7 +164,7 @@ struct ProjOut {
 inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
     const char* e = getenv("RML_CODE_RMW");
     if (e && *e) return atoi(e) != 0;
-    if (derive) return D * 16 <= frame_bytes;
+    if (derive) return 0;
     return u8 && D * 64 >= frame_bytes && D * 16 <= frame_bytes;
 }
 

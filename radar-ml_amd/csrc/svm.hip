@@ -1044,10 +1044,6 @@ inline bool use_dig_gemm(const rml_svm* m, int policy, int64_t n, int num_cu) {
     if (!m->dig_ok) return false;
     if (policy == RML_PATH_DIGITS) return true;
     if (policy != RML_PATH_AUTO) return false;
-    const char* env = getenv("RML_DIGITS");
-    const int knob = env ? atoi(env) : -1;
-    if (knob == 0) return false;
-    if (knob == 1) return true;
     const int64_t wgs = ((n + kBig - 1) / kBig) * ((m->Mpad + kBig - 1) / kBig);
     return wgs * 2 >= (int64_t)num_cu;
 }
@@ -1252,10 +1248,7 @@ template <typename T> int dev_upload(T** dst, const std::vector<T>& h) {
 
 template <int PATH, bool KM = false>
 int launch_gemm(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
-    // RML_GEMM_LDS_EXTRA pads the request (experiment knob: > 8 KB leaves one GEMM workgroup per CU, so that the
-    // HBM-bound projection of the next chunk keeps its wave slots while the two overlap)
-    static const size_t lds_extra = [] { const char* e = getenv("RML_GEMM_LDS_EXTRA"); long v = e ? atol(e) : 0; return (size_t)(v > 0 && v <= 64 * 1024 ? v : 0); }();
-    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + m->PT) * sizeof(double) + kExpTabBytes + lds_extra;
+    const size_t lds = 4 * kTileBytes + (size_t)kTile * (1 + m->PT) * sizeof(double) + kExpTabBytes;
     const int FT8 = (int)round_up(ga.FT, 8);
     dim3 grid((unsigned)(FT8 * ga.ST)), block(256);
 #define RML_GEMM_CASE(PTV)                                                                                         \
@@ -1417,8 +1410,7 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
     const bool gen_f32 = (policy == RML_PATH_F32);
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
-    // CUs the GEMM can use: all of them, or the aux stream's share of a CU partition (RML_GEMM_CUS)
-    const int gemm_cus = (ctx->gemm_cus_per_xcd > 0 && st == ctx->aux_stream) ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
+    const int gemm_cus = ctx->num_cu;
     const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, gemm_cus);
     // general tiles whose rows fit the model's fixed-point range go to the multi-digit int8 kernel (digit planes in w.dig)
     const bool run_dig = dig_ready && w.dig && run_gen && !gen_f32 && !kmat && m->dig_ok;
@@ -1781,30 +1773,24 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     if (B == 0) return RML_OK;
     hipStream_t caller = static_cast<hipStream_t>(stream);
     rml_ctx_guard guard(ctx, caller);       // shared workspaces, aux stream and chunk events (the caller's stream joins at the end)
-    // with a CU partition the projections run on the context's masked stream, forked from the caller's
-    hipStream_t st = ctx->proj_stream ? ctx->proj_stream : caller;
+    hipStream_t st = caller;                // the projections' stream
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
     // frames per chunk: see small_chunk below; RML_CHUNK overrides
     // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups
     // beside it overlap for real (GEMM hidden under the projection: 26.7 vs 28.0 ms per 262 144 frames), which the
     // 256x256 GEMM (205 VGPRs x 8 waves) cannot do -- it does not fit on a CU next to anything.
     // derive -> slice: the persistent k_derive_slice takes the same pairing (one 8-wave workgroup per CU beside 128x128 GEMM
-    // workgroups, 8 192-frame chunks); RML_DERIVE_PIPE=0: the ring GEMM in whole-round chunks, the two kernels taking turns
-    static const bool derive_pair = [] { const char* e = getenv("RML_DERIVE_PIPE"); return !e || atoi(e) != 0; }();
-    const bool wave_proj = derive ? derive_pair
+    // workgroups; the ring GEMM in whole-round chunks, the two kernels taking turns, measured 1-2 % slower: DESIGN.md 3.3)
+    const bool wave_proj = derive ? true
                                   : rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
     // Byte volumes (k_project_u8_max): the GEMM is a third of the step there, and since the projection's cross-lane steps left the
     // LDS pipe (round 3: 0.59 -> 0.71 of 8 TB/s alone) each kernel is worth more alone than beside the other: the 256x256 ring
     // kernel in whole-round chunks, the projection between its rounds (64x64x128 uint8, same box: 6.5-6.9 -> 7.4-7.5 M frames/s;
-    // Walabot grid 17.9-18.0 -> 18.4).  RML_PIPE_GEMM=0: the round-2 pairing (128x128 GEMM workgroups beside two projection
-    // workgroups per CU, 8 192-frame chunks).
-    // CU partition (RML_GEMM_CUS=g at context creation): the GEMM owns g CUs of every XCD (aux stream), the projection the other
-    // 32 - g (masked projection stream) -- nothing shares a CU, so the projection runs in its stand-alone configuration and the
-    // GEMM is the ring kernel, its chunks sized for whole rounds of ITS CUs
-    const bool part = ctx->gemm_cus_per_xcd > 0 && ctx->proj_stream != nullptr;
-    const int gemm_cus = part ? 8 * ctx->gemm_cus_per_xcd : ctx->num_cu;
-    const char* pge = getenv("RML_PIPE_GEMM");
-    const bool small_gemm = !part && (wave_proj || (vdtype == RML_VOL_U8 && pge && pge[0] == '0'));
+    // Walabot grid 17.9-18.0 -> 18.4).
+    // (A CU partition -- the GEMM on g CUs of every XCD, the projection on the other 32 - g, six splits -- was measured in rounds
+    // 2-3 and never won: DESIGN.md 3.3; the knob and its masked streams are gone since round 5.)
+    const int gemm_cus = ctx->num_cu;
+    const bool small_gemm = wave_proj;
     // 8192 frames per chunk; 16384 for small byte frames (same-box A/B: 22x31x176 float32 10.3 vs 9.6 M frames/s at 8192 vs 16384,
     // uint8 17.4 vs 17.7)
     // derive -> slice beside the 128x128 GEMM, frames of at most 1 MiB: 12 288 (six interleaved runs, session r4bk, Walabot grid:
@@ -1817,57 +1803,31 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // predicated launch -- a whole CU's LDS per workgroup even when it exits at once -- cannot start beside the resident projection
     // and GEMM workgroups: on the GEMM stream it waited for the end of the running projection launch, chunk after chunk
     // (profiles/r03_stats_walabot_f32.txt of session r3o: 224 launches of k_svm_gemm_ring<3,1>, up to 325 us each)
-    static const bool pipe_dig_always = [] { const char* e = getenv("RML_PIPE_DIGITS"); return e && atoi(e) == 1; }();      // A/B knob: round-3 state before r3o
-    const bool use_dig = (!grid_ok || pipe_dig_always) && vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
-    const int64_t CH = part ? std::min<int64_t>(round_up(B, kTile), pick_chunk_env(small_chunk))       // short chunks: the last chunk's GEMM is exposed
-                       : (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
+    const bool use_dig = !grid_ok && vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
+    const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
                        : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
                                                 : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
     const bool ws_ijk = derive && !ijk_out;             // the derived (i,j,k) stay in the chunk's workspace when the caller does not want them
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig, ws_ijk);
-    // workspaces in rotation: 2 (projection of chunk c+1 beside the GEMM of chunk c); RML_NBUF=3 lets the projection run two
-    // chunks ahead (experiment knob: loosens the lock-step of the two streams when their per-chunk times are equal)
-    const char* nbe = getenv("RML_NBUF");
-    const int NBUF = (nbe && atoi(nbe) == 3) ? 3 : 2;
+    // workspaces in rotation: 2 (projection of chunk c+1 beside the GEMM of chunk c; a third one -- the projection two chunks
+    // ahead -- changed nothing at 64x64x128 and cost 2 % at the Walabot grid: DESIGN.md 3.3)
+    constexpr int NBUF = 2;
     void* ws = nullptr;
     int rc = rml_ws_reserve(ctx, (size_t)NBUF * probe.bytes, &ws);
     if (rc) return rc;
-    ChunkWs w2[3];
+    ChunkWs w2[NBUF];
     for (int i = 0; i < NBUF; ++i) w2[i] = carve(m, CH, static_cast<unsigned char*>(ws) + (size_t)i * probe.bytes, grid_ok, true, use_dig, ws_ijk);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
     const int64_t frame_elems = (int64_t)X * Y * Z;
     hipStream_t aux = ctx->aux_stream;
     hipEvent_t* ev_proj = ctx->ev_proj;
     hipEvent_t* ev_done = ctx->ev_done;
-    // RML_PIPE_SPLIT=1 (experiment knob, off): three streams for a grid model on float volumes.  At the Walabot grid the second
-    // stream's chain -- tile decision, skipped second pass, GEMM, skipped float64 GEMM, finish and the launch gaps between them --
-    // is the period of the pipeline (profiles/r03_timeline_walabot.txt), so the small kernels move to a third stream: tile decision
-    // and second pass of chunk c as soon as its projection is done (under the GEMM of chunk c-1), k_svm_finish of chunk c under the
-    // GEMM of chunk c+1, the GEMM stream carries GEMMs back to back (use with RML_NBUF=3: with two workspaces the next projection
-    // waits for a finish that is queued behind this chunk's tile decision).  Measured over four boxes: Walabot +6.4 / +7.1 % on
-    // one, -1.6 / +4.8 % on another, +0.7 % over five interleaved rounds on a third (bimodal: 10.8 or 10.2 M frames/s, depending
-    // on which kernel's workgroups reach the CUs first); 64x64x128 -5 % (2.79 vs 2.93 M).  Not a default.
-    static const bool split_env = [] { const char* e = getenv("RML_PIPE_SPLIT"); return e && atoi(e) == 1; }();
-    const bool split = split_env && grid_ok && vdtype != RML_VOL_U8 && !part && ctx->side_stream != nullptr;
-    hipStream_t side = split ? ctx->side_stream : aux;
-    hipEvent_t* ev_flags = ctx->ev_flags;
-    hipEvent_t* ev_gemm = ctx->ev_gemm;
-    int64_t pend_c = -1, pend_r0 = 0, pend_n = 0;            // chunk whose k_svm_finish is still to be queued (split mode)
-    auto queue_finish = [&]() -> int {
-        if (pend_c < 0) return RML_OK;
-        const ChunkWs& pw = w2[pend_c % NBUF];
-        RML_HIP(hipStreamWaitEvent(side, ev_gemm[pend_c % NBUF], 0));
-        int frc = run_finish(m, pend_n, pw.flags, pw, out.at(pend_r0, m->C, m->P), side, false, false);
-        if (frc) return frc;
-        RML_HIP(hipEventRecord(ev_done[pend_c % NBUF], side));
-        pend_c = -1;
-        return RML_OK;
-    };
-    // aux (and the masked projection stream) must start after everything already queued by the caller
+    // (Three streams -- the small kernels either side of a chunk's GEMM on a third one, RML_PIPE_SPLIT in rounds 3-4 -- were
+    // bimodal at the Walabot grid and -5 % at 64x64x128: DESIGN.md 3.3; removed in round 5.)
+    hipStream_t side = aux;
+    // aux must start after everything already queued by the caller
     RML_HIP(hipEventRecord(ctx->ev_fork, caller));
     RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
-    if (split) RML_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
-    if (st != caller) RML_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
     int64_t c = 0;
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
         const int64_t n = std::min(CH, B - r0);
@@ -1885,8 +1845,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
-        o.share_cu = part ? 0 : 1;
-        if (derive && !small_gemm) o.share_cu = 0;       // taking turns with the ring GEMM: the stand-alone configuration
+        o.share_cu = 1;
         o.q_rmw = rml_code_rmw(m->D, frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4), derive, vdtype == RML_VOL_U8);
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
@@ -1968,41 +1927,18 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
             RML_HIP(hipEventRecord(ev_proj[c % NBUF], st));
             RML_HIP(hipStreamWaitEvent(aux, ev_proj[c % NBUF], 0));
         }
-        if (split) {
-            // the side stream: this chunk's tile decision and second pass are queued; the previous chunk's finish follows them (it
-            // waits for that chunk's GEMMs, which end later than this chunk's projection), then the GEMM stream takes this chunk
-            RML_HIP(hipEventRecord(ev_flags[c % NBUF], side));
-            rc = queue_finish();
-            if (rc) return rc;
-            RML_HIP(hipStreamWaitEvent(aux, ev_flags[c % NBUF], 0));
-        }
         rml_prof_mark_gemm(ctx, aux);
         rc = run_chunk(ctx, m, grid_ok ? RML_PATH_AUTO : RML_PATH_F64, n, grid_ok ? w.q : nullptr, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w,
                        out.at(r0, m->C, m->P), aux, /*tiles_done=*/grid_ok, nullptr, 0, false, /*allow_big=*/!small_gemm, /*dig_ready=*/use_dig,
-                       /*defer_finish=*/split);
+                       /*defer_finish=*/false);
         rml_prof_mark_gemm(ctx, aux);
         if (ctx->profiling) ctx->prof_ops_g += 2.0 * (double)n * (double)m->M * (double)m->D;
         if (rc) return rc;
-        if (split) {
-            RML_HIP(hipEventRecord(ev_gemm[c % NBUF], aux));
-            pend_c = c; pend_r0 = r0; pend_n = n;
-        } else {
-            RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
-        }
+        RML_HIP(hipEventRecord(ev_done[c % NBUF], aux));
     }
-    if (split) {
-        rc = queue_finish();
-        if (rc) return rc;
-        RML_HIP(hipEventRecord(ctx->ev_join, side));          // the last finish waited for the last GEMMs: side is the join
-    } else {
-        RML_HIP(hipEventRecord(ctx->ev_join, aux));
-    }
+    RML_HIP(hipEventRecord(ctx->ev_join, aux));
     // join: the caller's stream continues after the last GEMMs and their finish
     RML_HIP(hipStreamWaitEvent(caller, ctx->ev_join, 0));
-    if (st != caller) {
-        RML_HIP(hipEventRecord(ctx->ev_fork, st));
-        RML_HIP(hipStreamWaitEvent(caller, ctx->ev_fork, 0));
-    }
     return RML_OK;
 }
 }  // namespace

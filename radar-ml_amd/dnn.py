@@ -392,59 +392,94 @@ class Classifier(_module_base()):
         return out
 
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
-    def _guard(self, proba, eps, rescore, chunk=4096):
+    def _guard(self, proba, eps, rescore, chunk=512):
         """Replace the rows of ``proba`` (N, C) whose top-2 gap is below ``eps`` by what exact-input arithmetic gives:
-        ``rescore(row_indices, "float32")`` first (the plain float32 layers: MIOpen / hipBLASLt, error ~1e-6), and for the rows
-        whose float32 gap is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``."""
+        ``rescore(row_indices, "float32")`` first (float32 GEMMs on exact inputs, error ~1e-6), and for the rows whose float32 gap
+        is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``.  Rows are re-scored in chunks of EXACTLY ``chunk``
+        (64 for float64) rows -- a short chunk is padded by repeating its first row -- so that every GEMM has the same shape
+        whatever the count: a row's result does not depend on which rows were flagged with it (batching independence)."""
         import torch
         self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
         if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
             return proba
 
-        def close(p, gap):
+        def gaps(p):
             top2 = p.float().topk(2, dim=1).values
-            return ((top2[:, 0] - top2[:, 1]) < float(gap)).nonzero().squeeze(1)
+            return top2[:, 0] - top2[:, 1]
 
-        idx = close(proba, eps)                            # the call's first device -> host count
-        self.last_guard["rescored"] = int(idx.numel())
-        for s in range(0, int(idx.numel()), chunk):
-            sel = idx[s:s + chunk]
-            p32 = rescore(sel, "float32")
-            proba[sel] = p32.to(proba.dtype)
-            sel64 = sel[close(p32, LABEL_GUARD_F32)]
-            if sel64.numel():
-                self.last_guard["rescored_float64"] += int(sel64.numel())
-                proba[sel64] = rescore(sel64, "float64").to(proba.dtype)
+        def run(idx, prec, size):
+            outs = []
+            for s in range(0, int(idx.numel()), size):
+                sel = idx[s:s + size]
+                k = int(sel.numel())
+                if k < size:
+                    sel = torch.cat([sel, sel[:1].expand(size - k)])
+                outs.append(rescore(sel, prec)[:k])
+            return torch.cat(outs)
+
+        # Self-calibrating: the re-scored rows show what the bf16 chain's error on near-tie rows of THIS batch is; the gap must stay
+        # >= 4 x that (a gap moves by at most twice a probability's error, and twice again for margin), so a batch whose
+        # observed error asks for a wider gap gets its further rows re-scored too (at most three rounds).
+        g = gaps(proba)
+        gap = float(eps)
+        for _ in range(3):
+            idx = (g < gap).nonzero().squeeze(1)           # a device -> host count per round
+            if not idx.numel():
+                break
+            self.last_guard["rescored"] += int(idx.numel())
+            p32 = run(idx, "float32", chunk)
+            err = float((proba[idx].float() - p32).abs().max())
+            proba[idx] = p32.to(proba.dtype)
+            g[idx] = float("inf")                          # re-scored: never flagged again
+            idx64 = idx[(gaps(p32) < LABEL_GUARD_F32).nonzero().squeeze(1)]
+            self.last_guard["rescored_float64"] += int(idx64.numel())
+            if idx64.numel():
+                proba[idx64] = run(idx64, "float64", 64).to(proba.dtype)
+            self.last_guard["observed_error"] = max(err, self.last_guard.get("observed_error", 0.0))
+            if 4.0 * err <= gap:
+                break
+            gap = min(8.0 * err, 0.5)
+        self.last_guard["gap"] = gap
         return proba
 
-    def _f64_weights(self):
-        """float64 copies of every parameter, cached until one is written."""
-        import torch
+    def _exact_weights(self, dtype):
+        """float32 / float64 copies of every parameter in the layout of forward_exact, cached until one is written."""
         key = tuple((p._version, p.data_ptr()) for p in self.parameters())
-        if getattr(self, "_f64_key", None) != key:
-            self._f64_key = key
-            self._f64 = {"conv": [[(cv.conv.weight.detach().double(), cv.conv.bias.detach().double()) for cv in br] for br in self.branches],
-                         "fc": [(fc.weight.detach().double(), fc.bias.detach().double()) for fc in (self.fc1, self.fc2, self.fc3)]}
-        return self._f64
+        if getattr(self, "_exact_key", None) != key:
+            self._exact_key, self._exact = key, {}
+        if dtype not in self._exact:
+            self._exact[dtype] = {
+                "conv": [[(cv.conv.weight.detach().to(dtype).reshape(cv.conv.weight.shape[0], -1).contiguous(), cv.conv.bias.detach().to(dtype),
+                           int(cv.conv.weight.shape[2]), int(cv.conv.weight.shape[3])) for cv in br] for br in self.branches],
+                "fc": [(fc.weight.detach().to(dtype), fc.bias.detach().to(dtype)) for fc in (self.fc1, self.fc2, self.fc3)]}
+        return self._exact[dtype]
 
-    def forward_float64(self, xz, yz, xy):
-        """The layers of dnn.py:45-91 in float64 on the inputs' device: (N,H,W) or (N,1,H,W) planes -> (N, n_classes) float64
-        probabilities.  The guard's arithmetic (a few rows per batch), not a fast path."""
+    def forward_exact(self, xz, yz, xy, precision="float64"):
+        """The layers of dnn.py:45-91 in float32 or float64 on the inputs' device, as im2col + matrix products (rocBLAS /
+        hipBLASLt GEMMs in the operands' own precision: no half-precision operand anywhere): (N,H,W) or (N,1,H,W) planes ->
+        (N, n_classes) probabilities.  The margin guard's arithmetic -- a few hundred rows per batch -- not the fast path."""
         import torch
         import torch.nn.functional as F
-        w = self._f64_weights()
+        dt = torch.float64 if precision == "float64" else torch.float32
+        w = self._exact_weights(dt)
         outs = []
         for x, convs in zip((xz, yz, xy), w["conv"]):
-            x = x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).double()
-            for (k, b) in convs:
-                ph, pw = tf_same_pad(x.shape[-2], k.shape[-2], 2), tf_same_pad(x.shape[-1], k.shape[-1], 2)
-                x = F.relu(F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), k, b, stride=2))
+            x = x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).to(dt)
+            for (k2d, b, kh, kw) in convs:
+                ph, pw = tf_same_pad(x.shape[-2], kh, 2), tf_same_pad(x.shape[-1], kw, 2)
+                oh, ow = -(-x.shape[-2] // 2), -(-x.shape[-1] // 2)
+                cols = F.unfold(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), kernel_size=(kh, kw), stride=2)     # (N, Cin*kh*kw, oh*ow)
+                x = F.relu(torch.matmul(k2d, cols) + b[None, :, None]).reshape(x.shape[0], k2d.shape[0], oh, ow)
             outs.append(x)
         h = flatten_nhwc(torch.cat(outs, dim=1))
         (w1, b1), (w2, b2), (w3, b3) = w["fc"]
         h = F.relu(F.linear(h, w1, b1))
         h = F.relu(F.linear(h, w2, b2))
         return torch.softmax(F.linear(h, w3, b3), dim=-1)
+
+    def forward_float64(self, xz, yz, xy):
+        """:meth:`forward_exact` in float64: what the oracle's NumPy restatement computes, to ~1e-16."""
+        return self.forward_exact(xz, yz, xy, "float64")
 
     def rescore_exact(self, volumes, rescale=(80, 80), mode="max", precision="float64"):
         """(n,X,Y,Z) volumes -> (n, n_classes) probabilities through the reference's chain without a rounding the reference does
@@ -457,10 +492,8 @@ class Classifier(_module_base()):
         with torch.no_grad():
             feat = common.process_volumes(volumes, mode=mode, scale=False)
             xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="float32")
-            if precision == "float64":
-                return self.forward_float64(*xs)
             with torch.autocast("cuda", enabled=False):
-                return self(*[x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]) for x in xs])
+                return self.forward_exact(*xs, precision=precision)
 
     def _features_timed(self, xs, trunk_events, layout="nhwc"):
         import torch
@@ -494,8 +527,7 @@ class Classifier(_module_base()):
                 if dt is not None and dev.type == "cuda":
                     with torch.autocast("cuda", dtype=dt):
                         p = self(*xs)
-                    p = self._guard(p.float(), label_guard,
-                                    lambda idx, prec: self.forward_float64(*[x[idx] for x in xs]) if prec == "float64" else self(*[x[idx] for x in xs]))
+                    p = self._guard(p.float(), label_guard, lambda idx, prec: self.forward_exact(*[x[idx] for x in xs], precision=prec))
                 else:
                     p = self(*xs)
                 outs.append(p.float().cpu())

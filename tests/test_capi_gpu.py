@@ -309,10 +309,10 @@ def test_probe_stream_and_rmw_default(rml):
     assert 2600.0 < gbs.value < 8000.0
     old = os.environ.pop("RML_CODE_RMW", None)
     try:
-        # 64x64x128: uint8 volumes on, float32 max off, derive on; Walabot grid uint8 off (csrc/rml_internal.h)
+        # 64x64x128: uint8 volumes on, float32 max off, derive off (< 2 % on fresh frames); Walabot grid uint8 off (csrc/rml_internal.h)
         assert lib.rml_code_rmw_default(20480, 64 * 64 * 128, 0, 1) == 1
         assert lib.rml_code_rmw_default(20480, 4 * 64 * 64 * 128, 0, 0) == 0
-        assert lib.rml_code_rmw_default(20480, 4 * 64 * 64 * 128, 1, 0) == 1
+        assert lib.rml_code_rmw_default(20480, 4 * 64 * 64 * 128, 1, 0) == 0
         assert lib.rml_code_rmw_default(10010, 22 * 31 * 176, 0, 1) == 0
         os.environ["RML_CODE_RMW"] = "1"
         assert lib.rml_code_rmw_default(10010, 22 * 31 * 176, 0, 1) == 1

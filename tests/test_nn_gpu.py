@@ -175,7 +175,8 @@ def test_dnn_trained_model_labels_match_the_oracle_on_every_row(rml):
     np.testing.assert_array_equal(got.argmax(1), want.argmax(1))
     assert err <= DNN_BF16_PROBA_TOL
     print("margin guard: %d of %d rows re-scored in float64" % (gpu.last_guard["rescored"], gpu.last_guard["rows"]))
-    assert gpu.last_guard["rescored"] <= int((margin < 2 * dnn.LABEL_GUARD).sum())       # only rows near a tie pay for it
+    assert gpu.last_guard["rescored"] <= int((margin < 2 * gpu.last_guard["gap"]).sum())      # only rows near a tie pay for it
+    assert gpu.last_guard["gap"] >= 4 * gpu.last_guard["observed_error"]                    # the gap covers the error it saw, four times
     # host volumes stream through per batch (nothing but the slices crosses PCIe) and give the same answer
     got_h = gpu.predict_volumes(torch.from_numpy(vol), batch_size=128).cpu().numpy()
     np.testing.assert_array_equal(got_h, got)
@@ -206,8 +207,10 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     def same(a, b, what):
         # the dense tail runs on hipBLASLt, which picks its kernel (and with it the order of the K = 38 400 sum) by the batch's row
         # count: a batch of another size gives the same probabilities to bf16 round-off, not the same bits
+        # ... and a row near the guard's gap may be re-scored (exact inputs, float32) in one batching and not in the other: the two
+        # then differ by the bf16 chain's own error
         a, b = a.float(), b.float()
-        assert float((a - b).abs().max()) <= 2e-3, (what, float((a - b).abs().max()))
+        assert float((a - b).abs().max()) <= DNN_BF16_PROBA_TOL, (what, float((a - b).abs().max()))
         assert torch.equal(a.argmax(1), b.argmax(1)), what          # float64 labels either way (margin guard)
 
     cuts = [0, frames // 3 + 777, frames // 3 + 777 + 9999, frames]
