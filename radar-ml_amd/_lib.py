@@ -163,13 +163,14 @@ def context(device=None):
         device = torch.cuda.current_device()
     elif isinstance(device, torch.device):
         device = device.index if device.index is not None else torch.cuda.current_device()
+    index = int(device)
     lib = load()
     with _lock:
         h = _ctx.get(device)
     if h is None:
         # create outside the lock (a failing rml_ctx_create must raise, not dead-lock: check() calls load())
         new = c_void_p()
-        check(lib.rml_ctx_create(int(device), C.byref(new)), "rml_ctx_create")
+        check(lib.rml_ctx_create(index, C.byref(new)), "rml_ctx_create")
         with _lock:
             h = _ctx.setdefault(device, new)
         if h is not new:                    # another thread won the race

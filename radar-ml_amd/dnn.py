@@ -304,8 +304,9 @@ class Classifier(_module_base()):
         Keras layers, trained weights; 4.8e-4 on random-init ones), so a row whose two largest probabilities are more than ``label_guard`` apart
         has the label the float64 arithmetic gives; the rows closer than that -- and only those -- are scored again from their
         volumes on the GPU from exact inputs (exact projection, Pillow-bit-identical resize: :meth:`rescore_exact`), in float32 first
-        and, where the float32 gap is below LABEL_GUARD_F32, in float64; their probabilities are replaced.  A device->host count
-        per level; ``self.last_guard`` = {"rows", "rescored", "rescored_float64"}.
+        and, where the float32 gap is below LABEL_GUARD_F32, in float64; their probabilities are replaced.  The gap calibrates itself:
+        it is widened to four times the bf16 error seen on the re-scored rows.  ``self.last_guard`` = {"rows", "rescored",
+        "rescored_float64", "observed_error", "gap"}.
         """
         import torch
         from . import common, nn_common, _lib
@@ -340,6 +341,9 @@ class Classifier(_module_base()):
                         feat = common.process_volumes(vol(slice(s0, s1)), mode=mode, scale=False)
                         xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="bfloat16")
                     out[s0:s1] = self._forward_timed(xs, trunk_events)
+                # the margin guard once per call, behind the last pass.  (Per pass on a second stream beside the next pass, with a
+                # context of its own, was measured in session r5f: no overlap -- the chain's persistent kernels hold every CU and
+                # the guard's small launches start only at kernel boundaries -- and more padded chunks: 58 % against ~35 %.)
                 return self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(vol(idx), rescale, mode, prec))
             lib = _lib.load()
             ctx = _lib.context(dev)
@@ -392,14 +396,27 @@ class Classifier(_module_base()):
         return out
 
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
-    def _guard(self, proba, eps, rescore, chunk=512):
+    def _guard(self, proba, eps, rescore, chunk=512, merge=False):
         """Replace the rows of ``proba`` (N, C) whose top-2 gap is below ``eps`` by what exact-input arithmetic gives:
-        ``rescore(row_indices, "float32")`` first (float32 GEMMs on exact inputs, error ~1e-6), and for the rows whose float32 gap
+        ``rescore(row_indices, "float32")`` first (float32 layers on exact inputs, error ~1e-6), and for the rows whose float32 gap
         is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``.  Rows are re-scored in chunks of EXACTLY ``chunk``
-        (64 for float64) rows -- a short chunk is padded by repeating its first row -- so that every GEMM has the same shape
+        (32 for float64) rows -- a short chunk is padded by repeating its first row -- so that every GEMM has the same shape
         whatever the count: a row's result does not depend on which rows were flagged with it (batching independence)."""
         import torch
+        prev = getattr(self, "last_guard", None) if merge else None
         self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
+        try:
+            return self._guard_rows(proba, eps, rescore, chunk)
+        finally:
+            if prev:                                    # several passes of one call: sums, and the widest gap / largest error seen
+                for k in ("rows", "rescored", "rescored_float64"):
+                    self.last_guard[k] += prev.get(k, 0)
+                for k in ("observed_error", "gap"):
+                    if k in prev or k in self.last_guard:
+                        self.last_guard[k] = max(prev.get(k, 0.0), self.last_guard.get(k, 0.0))
+
+    def _guard_rows(self, proba, eps, rescore, chunk):
+        import torch
         if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
             return proba
 
@@ -434,7 +451,7 @@ class Classifier(_module_base()):
             idx64 = idx[(gaps(p32) < LABEL_GUARD_F32).nonzero().squeeze(1)]
             self.last_guard["rescored_float64"] += int(idx64.numel())
             if idx64.numel():
-                proba[idx64] = run(idx64, "float64", 64).to(proba.dtype)
+                proba[idx64] = run(idx64, "float64", 32).to(proba.dtype)
             self.last_guard["observed_error"] = max(err, self.last_guard.get("observed_error", 0.0))
             if 4.0 * err <= gap:
                 break
@@ -455,12 +472,17 @@ class Classifier(_module_base()):
         return self._exact[dtype]
 
     def forward_exact(self, xz, yz, xy, precision="float64"):
-        """The layers of dnn.py:45-91 in float32 or float64 on the inputs' device, as im2col + matrix products (rocBLAS /
-        hipBLASLt GEMMs in the operands' own precision: no half-precision operand anywhere): (N,H,W) or (N,1,H,W) planes ->
-        (N, n_classes) probabilities.  The margin guard's arithmetic -- a few hundred rows per batch -- not the fast path."""
+        """The layers of dnn.py:45-91 in float32 or float64 on the inputs' device, no half-precision operand anywhere:
+        (N,H,W) or (N,1,H,W) planes -> (N, n_classes) probabilities.  float32: the plain PyTorch layers (MIOpen float32
+        convolutions, hipBLASLt).  float64: im2col by nine strided slices + rocBLAS matrix products (MIOpen has no float64
+        convolution and PyTorch's fallback takes 10 ms for a handful of rows; F.unfold is as slow).  The margin guard's arithmetic
+        -- a few hundred rows per batch -- not the fast path."""
         import torch
         import torch.nn.functional as F
-        dt = torch.float64 if precision == "float64" else torch.float32
+        if precision != "float64":
+            with torch.autocast("cuda", enabled=False):
+                return self(*[x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).float() for x in (xz, yz, xy)])
+        dt = torch.float64
         w = self._exact_weights(dt)
         outs = []
         for x, convs in zip((xz, yz, xy), w["conv"]):
@@ -468,12 +490,20 @@ class Classifier(_module_base()):
             for (k2d, b, kh, kw) in convs:
                 ph, pw = tf_same_pad(x.shape[-2], kh, 2), tf_same_pad(x.shape[-1], kw, 2)
                 oh, ow = -(-x.shape[-2] // 2), -(-x.shape[-1] // 2)
-                cols = F.unfold(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), kernel_size=(kh, kw), stride=2)     # (N, Cin*kh*kw, oh*ow)
+                xp = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+                # (N, Cin, kh*kw, oh, ow) -> (N, Cin*kh*kw, oh*ow): the (cin, ky, kx) order of weight.reshape(Cout, -1)
+                cols = torch.stack([xp[:, :, ky:ky + 2 * oh - 1:2, kx:kx + 2 * ow - 1:2] for ky in range(kh) for kx in range(kw)], dim=2)
+                cols = cols.reshape(x.shape[0], -1, oh * ow)
                 x = F.relu(torch.matmul(k2d, cols) + b[None, :, None]).reshape(x.shape[0], k2d.shape[0], oh, ow)
             outs.append(x)
         h = flatten_nhwc(torch.cat(outs, dim=1))
         (w1, b1), (w2, b2), (w3, b3) = w["fc"]
-        h = F.relu(F.linear(h, w1, b1))
+        # the first dense layer as a batch of K-slices: rocBLAS' float64 GEMM with a few rows and K = 38 400 runs on a handful of
+        # workgroups (6 ms for 32 rows); 150 slices of 256 in one batched call and a sum take 0.1 ms
+        K = int(h.shape[1])
+        kc = 256 if K % 256 == 0 else K
+        part = torch.bmm(h.reshape(h.shape[0], K // kc, kc).transpose(0, 1), w1.reshape(w1.shape[0], K // kc, kc).permute(1, 2, 0))
+        h = F.relu(part.sum(dim=0) + b1)
         h = F.relu(F.linear(h, w2, b2))
         return torch.softmax(F.linear(h, w3, b3), dim=-1)
 
