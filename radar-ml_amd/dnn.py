@@ -396,7 +396,7 @@ class Classifier(_module_base()):
         return out
 
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
-    def _guard(self, proba, eps, rescore, chunk=512, merge=False):
+    def _guard(self, proba, eps, rescore, chunk=256, merge=False):
         """Replace the rows of ``proba`` (N, C) whose top-2 gap is below ``eps`` by what exact-input arithmetic gives:
         ``rescore(row_indices, "float32")`` first (float32 layers on exact inputs, error ~1e-6), and for the rows whose float32 gap
         is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``.  Rows are re-scored in chunks of EXACTLY ``chunk``
@@ -434,28 +434,46 @@ class Classifier(_module_base()):
                 outs.append(rescore(sel, prec)[:k])
             return torch.cat(outs)
 
-        # Self-calibrating: the re-scored rows show what the bf16 chain's error on near-tie rows of THIS batch is; the gap must stay
-        # >= 4 x that (a gap moves by at most twice a probability's error, and twice again for margin), so a batch whose
-        # observed error asks for a wider gap gets its further rows re-scored too (at most three rounds).
+        # Self-calibrating, closest ties first: the re-scored rows show what the bf16 chain's error on near-tie rows of THIS batch
+        # is, and a row is safe once its gap is >= 4 x that (a gap moves by at most twice a probability's error, and twice again
+        # for margin).  So the candidates (gap < eps) are taken in ascending order of their gap, a chunk at a time, and the pass
+        # stops at the first chunk boundary whose gap is already >= 4 x the largest error seen; a batch whose error asks for more
+        # than eps gets the next candidates (gap < 8 x error) the same way.
         g = gaps(proba)
-        gap = float(eps)
-        for _ in range(3):
-            idx = (g < gap).nonzero().squeeze(1)           # a device -> host count per round
-            if not idx.numel():
+        thr, reach, err = float(eps), 0.0, 0.0          # reach: every row with a gap below it is re-scored
+        done = []
+        for _ in range(4):
+            cand = (g < thr).nonzero().squeeze(1)                          # a device -> host count per round
+            if cand.numel():
+                cand = cand[torch.argsort(g[cand])]
+            stop = False
+            for s0 in range(0, int(cand.numel()), chunk):
+                idx = cand[s0:s0 + chunk]
+                p32 = run(idx, "float32", chunk)
+                err = max(err, float((proba[idx].float() - p32).abs().max()))
+                reach = float(g[idx[-1]])
+                proba[idx] = p32.to(proba.dtype)
+                g[idx] = float("inf")                                      # re-scored: never a candidate again
+                done.append((idx, p32))
+                self.last_guard["rescored"] += int(idx.numel())
+                if reach >= 4.0 * err:
+                    stop = True
+                    break
+            if stop:
                 break
-            self.last_guard["rescored"] += int(idx.numel())
-            p32 = run(idx, "float32", chunk)
-            err = float((proba[idx].float() - p32).abs().max())
-            proba[idx] = p32.to(proba.dtype)
-            g[idx] = float("inf")                          # re-scored: never flagged again
-            idx64 = idx[(gaps(p32) < LABEL_GUARD_F32).nonzero().squeeze(1)]
-            self.last_guard["rescored_float64"] += int(idx64.numel())
+            reach = thr                                                    # no candidate left below thr
+            if thr >= 4.0 * err:
+                break
+            thr = min(8.0 * err, 1.0)
+        gap = reach
+        if done:
+            idx_all = torch.cat([d[0] for d in done])
+            p_all = torch.cat([d[1] for d in done])
+            idx64 = idx_all[(gaps(p_all) < LABEL_GUARD_F32).nonzero().squeeze(1)]
+            self.last_guard["rescored_float64"] = int(idx64.numel())
             if idx64.numel():
                 proba[idx64] = run(idx64, "float64", 32).to(proba.dtype)
-            self.last_guard["observed_error"] = max(err, self.last_guard.get("observed_error", 0.0))
-            if 4.0 * err <= gap:
-                break
-            gap = min(8.0 * err, 0.5)
+        self.last_guard["observed_error"] = err
         self.last_guard["gap"] = gap
         return proba
 
