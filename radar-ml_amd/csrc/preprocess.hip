@@ -27,6 +27,9 @@
 #include "rml_internal.h"
 #include "resize_tables.h"
 #include <type_traits>
+#include <array>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -318,7 +321,24 @@ struct Plan {
     std::vector<float> hz_w, hy_w, vw;
 };
 
+Plan build_plan(int X, int Y, int Z, int OH, int OW);
+
+// the plan of a (grid, output size) pair is a pure function of the five numbers: built once per process, not once per call
+// (four Pillow coefficient tables and their window tables: ~10^4 double operations at the Walabot grid)
 Plan make_plan(int X, int Y, int Z, int OH, int OW) {
+    static std::mutex mu;
+    static std::map<std::array<int, 5>, Plan> cache;
+    const std::array<int, 5> key{X, Y, Z, OH, OW};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 64) cache.clear();          // a bound, not a policy: callers use a handful of shapes
+        it = cache.emplace(key, build_plan(X, Y, Z, OH, OW)).first;
+    }
+    return it->second;                                  // a copy, made under the lock (a few KB of tables)
+}
+
+Plan build_plan(int X, int Y, int Z, int OH, int OW) {
     Plan p;
     if (X <= 0 || Y <= 0 || Z <= 0 || OH <= 0 || OW <= 0) return p;
     const int64_t D = (int64_t)(X + Y) * Z + (int64_t)X * Y;
@@ -413,7 +433,8 @@ void launch_pre3_w(const Plan& p, const PreArgs& a, int num_cu, hipStream_t st) 
 }  // namespace
 
 extern "C" int rml_dnn_preprocess_supported(int X, int Y, int Z, int out_h, int out_w) {
-    return make_plan(X, Y, Z, out_h, out_w).ok ? 1 : 0;
+    const Plan p = make_plan(X, Y, Z, out_h, out_w);
+    return p.ok ? 1 : 0;
 }
 
 // skip_rows: device flag "every row is on the code grid" (the float-row launch exits at once when it is set), or nullptr

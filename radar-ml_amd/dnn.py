@@ -332,7 +332,9 @@ class Classifier(_module_base()):
         with torch.no_grad(), torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if not overlap:
-                fused = not exact_resize and nn_common.preprocess_supported((X, Y, Z), rescale)
+                # (mode "max_nan" can put NaN into the float rows: the fused float32 preprocessing multiplies out-of-window taps by
+                # zero weights, 0 * NaN, where Pillow never reads them -- those batches take the Pillow-exact resize)
+                fused = not exact_resize and mode != "max_nan" and nn_common.preprocess_supported((X, Y, Z), rescale)
                 for b in range(nb):
                     s0, s1 = b * bs, min(n, (b + 1) * bs)
                     if fused:

@@ -148,7 +148,9 @@ def preprocess_rows(grid, rescale, feat=None, codes=None, flags=None):
 def preprocess_volumes(volumes, rescale, mode="max", ijk=None):
     """(N, X, Y, Z) volumes (float32 or uint8, CUDA) -> the trunk's three bf16 inputs (N, H, W): projection into uint8 code rows
     (no float rows through HBM when the projections are integers 0..255 -- radar magnitudes, common.py:30-31; rows that are not
-    take a device-predicated float pass), then the fused scaling + bicubic resize (``rml_dnn_preprocess_volumes``)."""
+    take a device-predicated float pass), then the fused scaling + bicubic resize (``rml_dnn_preprocess_volumes``).  Finite
+    projections assumed on the float pass (its aligned windows touch neighbouring rows under zero weights: 0 * NaN is NaN where
+    Pillow would not have read): ``Classifier.predict_volumes`` sends mode "max_nan" through the Pillow-exact resize instead."""
     torch = _torch()
     from . import _lib, common
     lib = _lib.load()
@@ -428,9 +430,11 @@ class DeviceAdam:
     scaler's one-element kernels.  ``scale`` (a 1-element CUDA float32 tensor shared by the optimizers of a trainer, or None)
     multiplies the loss before ``backward``; ``step(grads)`` tests the gradients, skips the update and halves the scale on a
     non-finite one, doubles it after ``growth_interval`` clean steps in a row.  Exponential averages and the step count are this
-    object's; hyper-parameters follow ``param_groups`` of the torch optimizer it mirrors (sgan.py:206, 214)."""
+    object's.  ``mirror`` (the torch optimizer whose place this takes; optional): its ``param_groups[0]`` is read at every step, so
+    a learning-rate change made on the torch optimizer (a scheduler, a manual edit) takes effect here too (sgan.py:206, 214)."""
+    MAX_TABLES = 8          # device tables kept (one per set of gradient tensors: eager training re-allocates its gradients)
 
-    def __init__(self, params, lr, betas, eps, scale=None, scaler_state=None, growth=2.0, backoff=0.5, growth_interval=2000):
+    def __init__(self, params, lr, betas, eps, scale=None, scaler_state=None, growth=2.0, backoff=0.5, growth_interval=2000, mirror=None):
         torch = _torch()
         self.params = [p for p in params if p.requires_grad]
         if not self.params or any((not p.is_cuda) or p.dtype != torch.float32 for p in self.params):
@@ -448,6 +452,7 @@ class DeviceAdam:
         self.state = scaler_state if scaler_state is not None else torch.zeros((3,), dtype=torch.int32, device=dev)
         self.inv_scale = torch.ones((1,), dtype=torch.float32, device=dev)
         self._tables = {}
+        self.mirror = mirror
 
     def _table(self, grads):
         """device table for this set of gradient tensors (a HIP-graph head owns its own): built once per set"""
@@ -476,6 +481,8 @@ class DeviceAdam:
         host = np.array(rows, dtype=np.int64).reshape(-1)            # five 8-byte fields per record
         tab = torch.from_numpy(host).to(self.device)
         hit = (tab, n, start)
+        if len(self._tables) >= self.MAX_TABLES:            # oldest out (dicts keep insertion order): the cache cannot grow without bound
+            self._tables.pop(next(iter(self._tables)))
         self._tables[key] = hit
         return hit
 
@@ -486,6 +493,10 @@ class DeviceAdam:
         tab, n, total = self._table(grads)
         if n == 0:
             return
+        if self.mirror is not None:                         # hyper-parameters follow the torch optimizer this one mirrors
+            g0 = self.mirror.param_groups[0]
+            self.lr, self.eps = float(g0["lr"]), float(g0["eps"])
+            self.betas = (float(g0["betas"][0]), float(g0["betas"][1]))
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().rml_adam_step(
                 _lib.context(self.device), _lib.ptr(tab), n, total, self.lr, self.betas[0], self.betas[1], self.eps,

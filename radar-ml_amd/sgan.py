@@ -289,7 +289,7 @@ class DiscriminatorTrainer:
             from .nn_common import DeviceAdam
             self._scale_t = torch.full((1,), 65536.0, dtype=torch.float32, device=self.device) if self.amp_dtype == torch.float16 else None
             shared = torch.zeros((3,), dtype=torch.int32, device=self.device)
-            self._dev_adam = {id(o): DeviceAdam(self._params, lr, (beta1, 0.999), 1e-7, scale=self._scale_t, scaler_state=shared)
+            self._dev_adam = {id(o): DeviceAdam(self._params, lr, (beta1, 0.999), 1e-7, scale=self._scale_t, scaler_state=shared, mirror=o)
                               for o in (self.opt_c, self.opt_d)}
         self._graphs = {}           # head -> dict(graph, static inputs / targets, loss, logits, eager_calls)
 

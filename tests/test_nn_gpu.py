@@ -701,6 +701,23 @@ def test_device_adam_matches_torch_adam_and_grad_scaler(rml):
         p0.grad = gi.clone(); p1.grad = gi.clone()
         o0.step(); o1.step()
     assert (p0 - p1).abs().max() <= 1e-6
+    # a mirrored optimizer: a learning-rate change made on the torch optimizer is followed (it was frozen at
+    # construction); and the table cache stays bounded when every step brings freshly allocated gradients
+    p2 = p0.detach().clone().requires_grad_(True)
+    p3 = p2.detach().clone().requires_grad_(True)
+    o2 = torch.optim.Adam([p2], lr=1e-2, betas=(0.5, 0.999), eps=1e-7)
+    o3 = nc.DeviceAdam([p3], 1e-2, (0.5, 0.999), 1e-7, mirror=torch.optim.Adam([p3], lr=1e-2, betas=(0.5, 0.999), eps=1e-7))
+    keep = []
+    for it in range(3 * nc.DeviceAdam.MAX_TABLES):
+        if it == 5:
+            o2.param_groups[0]["lr"] = 3e-3
+            o3.mirror.param_groups[0]["lr"] = 3e-3
+        gi = torch.randn(1000, device="cuda")
+        p2.grad = gi.clone(); p3.grad = gi.clone()
+        keep.append(p3.grad)                                               # every step a NEW gradient tensor (distinct pointers)
+        o2.step(); o3.step()
+    assert (p2 - p3).abs().max() <= 2e-6
+    assert len(o3._tables) <= nc.DeviceAdam.MAX_TABLES
 
 
 def test_sgan_trainer_hip_graph_matches_eager(rml):
@@ -842,3 +859,22 @@ def test_sgan_whole_step_gradients_at_config4_size(rml, amp):
     for (k, a), (_, b) in zip(ref.named_buffers(), fus.named_buffers()):
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert float((a - b).abs().max()) < (2e-3 if amp == "float16" else 1e-2) * max(1.0, float(a.abs().max())), k
+
+
+def test_predict_volumes_nan_projections_take_the_exact_resize(rml):
+    """mode "max_nan" (NumPy's NaN policy, SURVEY 8 a-1') can put NaN into a projection; the fused float32 preprocessing would
+    spread it through zero-weight taps, so those batches run the Pillow-exact resize: the result is the
+    exact_resize=True chain's, bit for bit, and the frames without a NaN are untouched by the NaN next to them."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    import oracle_np as O
+    torch.manual_seed(4)
+    model = dnn.define_classifier(device="cuda").eval()
+    vol, _ = O.synth_volumes(13, 64, 22, 31, 176)
+    vol = vol.copy()
+    vol[5, 7, 11, 90] = np.nan
+    v = torch.from_numpy(vol).cuda()
+    a = model.predict_volumes(v, mode="max_nan", label_guard=None)
+    b = model.predict_volumes(v, mode="max_nan", exact_resize=True, label_guard=None)
+    assert torch.equal(a[torch.arange(64) != 5], b[torch.arange(64) != 5])
+    clean = model.predict_volumes(v[:5], mode="max", exact_resize=True, label_guard=None)
+    assert torch.equal(a[:5], clean)                      # a NaN frame does not leak into its neighbours

@@ -22,7 +22,10 @@ cd /tmp
 COMMON="--no-cpu --no-pmc --parity 512 --steps 5 --warmup 2"
 prof() {   # prof <name> <command...>
     local name=$1; shift
-    rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$name -o k -- "$@" > $R/gpurun_out/${TAG}_bench_$name.json 2> $R/gpurun_out/prof_$name.err
+    # bench.py prints two lines (verbose rows, contract line): its rows are read from the --doc-file JSON ({"doc": ..., "line": ...})
+    local doc=()
+    case "$*" in *bench.py*) doc=(--doc-file $R/gpurun_out/${TAG}_bench_$name.json);; esac
+    rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$name -o k -- "$@" "${doc[@]}" > $R/gpurun_out/${TAG}_bench_$name.log 2> $R/gpurun_out/prof_$name.err
     python $R/tools/prof_summary.py stats $R/gpurun_out/prof_$name/k_results.db > $R/gpurun_out/${TAG}_stats_$name.txt
     rm -rf $R/gpurun_out/prof_$name
 }
