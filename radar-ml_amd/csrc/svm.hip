@@ -1828,6 +1828,9 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // aux must start after everything already queued by the caller
     RML_HIP(hipEventRecord(ctx->ev_fork, caller));
     RML_HIP(hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    // (Round 5, session r5i: tapering the last chunk -- 8 192 -> 4 096, 2 048, 2 048, so that the GEMM left exposed behind the last
+    // projection is a quarter of a chunk's -- LOST: end to end / in-situ kernel 0.953 against 0.957-0.958 at 64x64x128 and
+    // 0.607 against 0.633 of 8 TB/s at the Walabot grid; a persistent launch over 2 048 frames is two frames per wave.)
     int64_t c = 0;
     for (int64_t r0 = 0; r0 < B; r0 += CH, ++c) {
         const int64_t n = std::min(CH, B - r0);
