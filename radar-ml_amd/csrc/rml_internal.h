@@ -164,6 +164,9 @@ struct ProjOut {
 inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
     const char* e = getenv("RML_CODE_RMW");
     if (e && *e) return atoi(e) != 0;
+    // round 5, FRESH frames (bench.py's sliding windows: no workspace row meets its own frame's old codes; sessions r5c / r5d):
+    // 64x64x128 uint8 +2.7 % (the +6-10 % above came with a batch re-run 20 times), derive -> slice +1.6 % / +1.3 % -- below the
+    // 2 % bar: the derive pipelines store plainly
     if (derive) return 0;
     return u8 && D * 64 >= frame_bytes && D * 16 <= frame_bytes;
 }

@@ -1824,6 +1824,13 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     hipEvent_t* ev_done = ctx->ev_done;
     // (Three streams -- the small kernels either side of a chunk's GEMM on a third one, RML_PIPE_SPLIT in rounds 3-4 -- were
     // bimodal at the Walabot grid and -5 % at 64x64x128: DESIGN.md 3.3; removed in round 5.)
+    // (Round 5, session r5j: the exact GEMM deciding its tiles from the row flags itself and starting the moment the projection is
+    // done, with the tile decision and the predicated general path -- second pass, float64 GEMM -- on a third stream beside it and
+    // the finish waiting for both: the chain WAS shorter, and the step slower -- 64x64x128 0.716-0.733 end to end against
+    // 0.752-0.759 on boxes of the same class, Walabot 0.593-0.598 against 0.633; k_project_lin in situ 0.66-0.68 against 0.745.
+    // A GEMM that starts WITH the next projection puts its workgroups on the CUs first, two per CU where the projection's
+    // persistent workgroup should go, and the projection pays for the imbalance.  The ~30 us of small kernels in front of the GEMM
+    // are what lets the projection settle first.)
     hipStream_t side = aux;
     // aux must start after everything already queued by the caller
     RML_HIP(hipEventRecord(ctx->ev_fork, caller));
