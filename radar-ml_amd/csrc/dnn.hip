@@ -22,7 +22,8 @@
 // The conv1 image uses a padded pixel stride (144 B) so that the ds_read_b128 fragment reads are bank-conflict
 // free.  Barriers are
 // LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) so that they do not drain the plane prefetch.
-// Numerics: bf16 operands (conv1 bias included), float32 accumulation (what torch.autocast(bf16) does), outputs bf16.
+// Numerics: bf16 operands, float32 accumulation (what torch.autocast(bf16) does), outputs bf16; the conv1 bias rides in the K
+// slots too: one bf16 slot in k_dnn_trunk, three (= float32 precision) in k_dnn_trunk_rf since round 5.
 // Measured (8192 samples of 3 x 80x80, MI355X): 0.68 ms = 12.1 M samples/s; the same layers through PyTorch/MIOpen
 // in bf16 channels_last take 13.9 ms.  Planes whose LDS layout fits go to k_dnn_trunk_rf further down (0.55-0.61 ms).
 #include "rml_internal.h"
@@ -460,7 +461,17 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
             const float bias = a.b1[br * C1 + ct * 32 + n];
             uint4 u;
             if (h == 0) u = make_uint4(pk_bf16(wr_[0], wr_[1]), pk_bf16(wr_[2], 0.f), pk_bf16(wr_[3], wr_[4]), pk_bf16(wr_[5], 0.f));
-            else u = make_uint4(pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[8], 0.f), pk_bf16(bias, 0.f), 0u);
+            else {
+                // the bias takes THREE of the four slots whose pixel side is 1.0 (0.0 on a padding pixel: all four at once): bf16(bias)
+                // + bf16 of what that left + bf16 of what that left = the float32 bias to 24 bits.  One bf16 slot (rounds 1-4) left an
+                // error of up to 2^-9 |bias| on EVERY conv1 pixel of a channel -- a coherent offset that conv2 and the 38 400-term
+                // dense layer add up instead of averaging out: it was most of the chain's probability error on trained weights
+                // (session r5l: 5.6e-3 with it against 2.0e-3 for a chain whose only roundings are the random ones)
+                const float bh = __uint_as_float(pk_bf16(bias, 0.f) << 16);
+                const float r1 = bias - bh;
+                const float bm = __uint_as_float(pk_bf16(r1, 0.f) << 16);
+                u = make_uint4(pk_bf16(wr_[6], wr_[7]), pk_bf16(wr_[8], 0.f), pk_bf16(bias, r1), pk_bf16(r1 - bm, 0.f));
+            }
             w1f[ct] = *reinterpret_cast<bf16x8*>(&u);
         }
         const unsigned char* wl = smem + L.off_w + lane * 16;
