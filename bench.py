@@ -365,6 +365,15 @@ def run_workload(a, env, grid, frames, primary):
         slice_rows["slice_mode"]["request_floor_bytes_per_frame"] = 4 * (X * Z + Y * Z) + 128 * X * Y + D + 16
         slice_rows["slice_mode"]["note"] = ("algorithmic = 4*D read + 28 B; every xy value lives in its own 128-byte memory request (rows are "
                                             ">= 512 B apart), so no kernel fetches less than request_floor_bytes_per_frame")
+        # what this row is bound by: not its projection (a gather of 4*D bytes per frame) but the int8 GEMM behind it -- quoted as such,
+        # with the projection's in-situ rate against the request floor (what the memory system must move) beside the algorithmic one
+        sm = slice_rows["slice_mode"]
+        floor_b = sm["request_floor_bytes_per_frame"]
+        rf_s = sm["roofline"]
+        ach_floor = floor_b * rf_s["frames_per_launch"] / (rf_s["avg_launch_ms"] * 1e-3) / 1e9 if rf_s["avg_launch_ms"] > 0 else 0.0
+        rf_s["frac_of_request_floor"] = round(ach_floor / HBM_PEAK_GBS, 4)
+        sm["bound"] = {"by": "mfma", "kernel": (sm.get("gemm_roofline") or {}).get("kernel"), "frac": (sm.get("gemm_roofline") or {}).get("frac"),
+                       "note": "the exact int8 GEMM of the rows is this row's time; the gather runs beside it at frac_of_request_floor of 8 TB/s"}
 
     if rank != 0:
         del V, Vall, out, svc
@@ -1155,6 +1164,9 @@ def main():
             for key, sr in (r.get("slice_rows") or {}).items():
                 gate(tag + "." + key, sr.get("parity"))
                 row[key] = compact(sr)
+                if key == "slice_mode" and sr.get("bound"):
+                    row[key]["bound"] = "gemm"
+                    row[key]["floor"] = sr["roofline"].get("frac_of_request_floor")
             summ[tag] = row
         if res["projection_only"]:
             summ["proj_only_configs1"] = {k: v["frac"] for k, v in res["projection_only"].items()}

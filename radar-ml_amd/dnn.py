@@ -398,27 +398,14 @@ class Classifier(_module_base()):
         return out
 
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
-    def _guard(self, proba, eps, rescore, chunk=256, merge=False):
-        """Replace the rows of ``proba`` (N, C) whose top-2 gap is below ``eps`` by what exact-input arithmetic gives:
+    def _guard(self, proba, eps, rescore, chunk=256):
+        """Replace the rows of ``proba`` (N, C) whose top-2 gap is too small for a bf16 chain by what exact-input arithmetic gives:
         ``rescore(row_indices, "float32")`` first (float32 layers on exact inputs, error ~1e-6), and for the rows whose float32 gap
         is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``.  Rows are re-scored in chunks of EXACTLY ``chunk``
-        (32 for float64) rows -- a short chunk is padded by repeating its first row -- so that every GEMM has the same shape
-        whatever the count: a row's result does not depend on which rows were flagged with it (batching independence)."""
+        (32 for float64) rows -- a short chunk is padded by repeating its first row -- so that every launch has the same shape
+        whatever the count.  ``self.last_guard`` = {"rows", "rescored", "rescored_float64", "observed_error", "gap"}."""
         import torch
-        prev = getattr(self, "last_guard", None) if merge else None
         self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
-        try:
-            return self._guard_rows(proba, eps, rescore, chunk)
-        finally:
-            if prev:                                    # several passes of one call: sums, and the widest gap / largest error seen
-                for k in ("rows", "rescored", "rescored_float64"):
-                    self.last_guard[k] += prev.get(k, 0)
-                for k in ("observed_error", "gap"):
-                    if k in prev or k in self.last_guard:
-                        self.last_guard[k] = max(prev.get(k, 0.0), self.last_guard.get(k, 0.0))
-
-    def _guard_rows(self, proba, eps, rescore, chunk):
-        import torch
         if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
             return proba
 
