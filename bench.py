@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--no-general", action="store_true", help="skip the general_rows row (non-integer data, float64 MFMA path)")
     ap.add_argument("--general-frames", type=int, default=16384, help="frames per GPU of the general_rows row")
     ap.add_argument("--dnn-parity", type=int, default=1024, help="frames of the CNN row checked against the NumPy restatement")
-    ap.add_argument("--dnn-train-steps", type=int, default=400, help="float32 Adam steps that give the CNN row's model real margins")
+    ap.add_argument("--dnn-train-steps", type=int, default=600, help="float32 Adam steps that give the CNN row's model real margins")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--doc-file", default=None, help="also write the verbose rows (and the contract line) to this JSON file")
     return ap.parse_args()
@@ -738,11 +738,18 @@ def run_dnn(a, env):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999), eps=1e-7)
     gtr = torch.Generator(device=dev).manual_seed(a.seed)
     model.train()
-    for _ in range(a.dnn_train_steps):
-        idx = torch.randint(0, 1024, (64,), device=dev, generator=gtr)
-        opt.zero_grad(set_to_none=True)
-        torch.nn.functional.cross_entropy(model.logits(*[t[idx] for t in txs]).float(), ty[idx]).backward()
-        opt.step()
+    # deterministic convolution algorithms while training: the same model in every run (MIOpen's default weight-gradient kernels
+    # accumulate with atomics: mean margin 0.45 ... 0.63 and 390 ... 1 280 guard rows from run to run of the same seed, session r5m)
+    det_was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for _ in range(a.dnn_train_steps):
+            idx = torch.randint(0, 1024, (64,), device=dev, generator=gtr)
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model.logits(*[t[idx] for t in txs]).float(), ty[idx]).backward()
+            opt.step()
+    finally:
+        torch.backends.cudnn.deterministic = det_was
     model.eval()
     del tv, tfeat, txs, opt
     V, Vcls = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 7, frame0=rank * B, device=dev)

@@ -425,29 +425,36 @@ class Classifier(_module_base()):
 
         # Self-calibrating, closest ties first: the re-scored rows show what the bf16 chain's error on near-tie rows of THIS batch
         # is, and a row is safe once its gap is >= 4 x that (a gap moves by at most twice a probability's error, and twice again
-        # for margin).  So the candidates (gap < eps) are taken in ascending order of their gap, a chunk at a time, and the pass
-        # stops at the first chunk boundary whose gap is already >= 4 x the largest error seen; a batch whose error asks for more
-        # than eps gets the next candidates (gap < 8 x error) the same way.
+        # for margin).  So the candidates (gap < eps) are sorted by their gap; the first ``chunk`` of them measure the error, the
+        # next launch takes every candidate still below 4 x that error at once (padded to a multiple of 64 rows, at most 1 024 per
+        # launch), and so on until the next candidate's gap is safe; a batch whose error asks for more than eps gets the next
+        # candidates (gap < 8 x error) the same way.
         g = gaps(proba)
         thr, reach, err = float(eps), 0.0, 0.0          # reach: every row with a gap below it is re-scored
         done = []
         for _ in range(4):
             cand = (g < thr).nonzero().squeeze(1)                          # a device -> host count per round
-            if cand.numel():
-                cand = cand[torch.argsort(g[cand])]
+            n = int(cand.numel())
             stop = False
-            for s0 in range(0, int(cand.numel()), chunk):
-                idx = cand[s0:s0 + chunk]
-                p32 = run(idx, "float32", chunk)
-                err = max(err, float((proba[idx].float() - p32).abs().max()))
-                reach = float(g[idx[-1]])
-                proba[idx] = p32.to(proba.dtype)
-                g[idx] = float("inf")                                      # re-scored: never a candidate again
-                done.append((idx, p32))
-                self.last_guard["rescored"] += int(idx.numel())
-                if reach >= 4.0 * err:
-                    stop = True
-                    break
+            if n:
+                cand = cand[torch.argsort(g[cand])]
+                gs = g[cand].cpu()                                         # the candidates' gaps, ascending, on the host
+                pos, size = 0, min(chunk, max(64, -(-n // 64) * 64))
+                while pos < n:
+                    idx = cand[pos:pos + size]
+                    p32 = run(idx, "float32", size)
+                    err = max(err, float((proba[idx].float() - p32).abs().max()))
+                    proba[idx] = p32.to(proba.dtype)
+                    g[idx] = float("inf")                                  # re-scored: never a candidate again
+                    done.append((idx, p32))
+                    pos += int(idx.numel())
+                    self.last_guard["rescored"] += int(idx.numel())
+                    need = int(torch.searchsorted(gs, torch.tensor(4.0 * err))) - pos      # candidates still below 4 x the error seen
+                    if need <= 0:
+                        reach = float(gs[pos]) if pos < n else thr
+                        stop = pos < n
+                        break
+                    size = min(-(-need // 64) * 64, 1024)
             if stop:
                 break
             reach = thr                                                    # no candidate left below thr
