@@ -218,6 +218,7 @@ extern "C" int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, in
                 "rml_probe_stream: needs a 16-byte aligned buffer of at least 1 MiB and reps >= 1");
     RML_HIP(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rml_ctx_guard guard(ctx, st);           // a workspace user like the others: serialised on the context
     void* sink = nullptr;
     int rc = rml_ws_reserve(ctx, (size_t)4 * 2 * ctx->num_cu, &sink);
     if (rc) return rc;
