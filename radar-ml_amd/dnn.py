@@ -400,38 +400,58 @@ class Classifier(_module_base()):
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
     def _guard(self, proba, eps, rescore, chunk=256):
         """Replace the rows of ``proba`` (N, C) whose top-2 gap is too small for a bf16 chain by what exact-input arithmetic gives:
-        ``rescore(row_indices, "float32")`` first (float32 layers on exact inputs, error ~1e-6), and for the rows whose float32 gap
-        is still below LABEL_GUARD_F32 ``rescore(row_indices, "float64")``.  Rows are re-scored in chunks of EXACTLY ``chunk``
-        (32 for float64) rows -- a short chunk is padded by repeating its first row -- so that every launch has the same shape
-        whatever the count.  ``self.last_guard`` = {"rows", "rescored", "rescored_float64", "observed_error", "gap"}."""
+        ``rescore(rows, "float32")`` first (float32 layers on exact inputs, error ~1e-6; :meth:`_guard_stage` picks the rows), and
+        for the rows whose float32 gap is still below LABEL_GUARD_F32 ``rescore(rows, "float64")``.  ``self.last_guard`` = {"rows",
+        "rescored", "rescored_float64", "observed_error" (of the bf16 chain on the re-scored rows), "gap"}.
+        (An fp16 stage in front -- the plain layers under fp16 autocast on exact inputs -- was measured in session r5o: MIOpen's /
+        hipBLASLt's fp16 path is 1.2e-2 away from float32 on these layers, worse than the bf16 chain it was meant to referee.)"""
         import torch
         self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
         if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
             return proba
+        idx, p32, err, reach = self._guard_stage(proba, float(eps), lambda rows: rescore(rows, "float32"), chunk)
+        self.last_guard.update(rescored=int(idx.numel()), observed_error=err, gap=reach)
+        if idx.numel():
+            sel = (self._gaps(p32) < LABEL_GUARD_F32).nonzero().squeeze(1)
+            self.last_guard["rescored_float64"] = int(sel.numel())
+            if sel.numel():
+                proba[idx[sel]] = self._run_padded(lambda rows: rescore(rows, "float64"), idx[sel], 32).to(proba.dtype)
+        return proba
 
-        def gaps(p):
-            top2 = p.float().topk(2, dim=1).values
-            return top2[:, 0] - top2[:, 1]
+    @staticmethod
+    def _gaps(p):
+        """top-2 gap per row; a row with a non-finite probability (an fp16 overflow) counts as a tie"""
+        import torch
+        top2 = torch.nan_to_num(p.float(), nan=0.0, posinf=0.0, neginf=0.0).topk(2, dim=1).values
+        g = top2[:, 0] - top2[:, 1]
+        return torch.where(torch.isfinite(p.float()).all(dim=1), g, torch.zeros_like(g))
 
-        def run(idx, prec, size):
-            outs = []
-            for s in range(0, int(idx.numel()), size):
-                sel = idx[s:s + size]
-                k = int(sel.numel())
-                if k < size:
-                    sel = torch.cat([sel, sel[:1].expand(size - k)])
-                outs.append(rescore(sel, prec)[:k])
-            return torch.cat(outs)
+    @staticmethod
+    def _run_padded(fn, idx, size):
+        """fn(rows) in launches of EXACTLY ``size`` rows (a short one padded by repeating its first row): every launch of a size has
+        the same shape whatever the count"""
+        import torch
+        outs = []
+        for s in range(0, int(idx.numel()), size):
+            sel = idx[s:s + size]
+            k = int(sel.numel())
+            if k < size:
+                sel = torch.cat([sel, sel[:1].expand(size - k)])
+            outs.append(fn(sel)[:k])
+        return torch.cat(outs)
 
-        # Self-calibrating, closest ties first: the re-scored rows show what the bf16 chain's error on near-tie rows of THIS batch
-        # is, and a row is safe once its gap is >= 4 x that (a gap moves by at most twice a probability's error, and twice again
-        # for margin).  So the candidates (gap < eps) are sorted by their gap; the first ``chunk`` of them measure the error, the
-        # next launch takes every candidate still below 4 x that error at once (padded to a multiple of 64 rows, at most 1 024 per
-        # launch), and so on until the next candidate's gap is safe; a batch whose error asks for more than eps gets the next
-        # candidates (gap < 8 x error) the same way.
-        g = gaps(proba)
-        thr, reach, err = float(eps), 0.0, 0.0          # reach: every row with a gap below it is re-scored
-        done = []
+    def _guard_stage(self, proba, eps, fn, chunk):
+        """Closest ties first.  The rows of ``proba`` with a top-2 gap below ``eps`` are sorted by their gap;
+        the first ``chunk`` of them measure the error of ``proba`` against ``fn(rows)``; the next launch takes every candidate still
+        below 4 x that error at once (padded to a multiple of 64 rows, at most 1 024 per launch), and so on until the next
+        candidate's gap is safe -- a gap moves by at most twice a probability's error, and twice again for margin; a batch whose
+        error asks for more than ``eps`` gets the next candidates (gap < 8 x error) the same way.  Re-scored rows are written into
+        ``proba``.  Returns (rows re-scored, their new probabilities, largest error seen, the gap below which every row was
+        re-scored)."""
+        import torch
+        g = self._gaps(proba)
+        thr, reach, err = float(eps), 0.0, 0.0
+        done_i, done_p = [], []
         for _ in range(4):
             cand = (g < thr).nonzero().squeeze(1)                          # a device -> host count per round
             n = int(cand.numel())
@@ -442,13 +462,13 @@ class Classifier(_module_base()):
                 pos, size = 0, min(chunk, max(64, -(-n // 64) * 64))
                 while pos < n:
                     idx = cand[pos:pos + size]
-                    p32 = run(idx, "float32", size)
-                    err = max(err, float((proba[idx].float() - p32).abs().max()))
-                    proba[idx] = p32.to(proba.dtype)
+                    pn = self._run_padded(fn, idx, size).float()
+                    d = torch.nan_to_num((proba[idx].float() - pn).abs(), nan=1.0, posinf=1.0)
+                    err = max(err, float(d.max()))
+                    proba[idx] = pn.to(proba.dtype)
                     g[idx] = float("inf")                                  # re-scored: never a candidate again
-                    done.append((idx, p32))
+                    done_i.append(idx); done_p.append(pn)
                     pos += int(idx.numel())
-                    self.last_guard["rescored"] += int(idx.numel())
                     need = int(torch.searchsorted(gs, torch.tensor(4.0 * err))) - pos      # candidates still below 4 x the error seen
                     if need <= 0:
                         reach = float(gs[pos]) if pos < n else thr
@@ -461,17 +481,9 @@ class Classifier(_module_base()):
             if thr >= 4.0 * err:
                 break
             thr = min(8.0 * err, 1.0)
-        gap = reach
-        if done:
-            idx_all = torch.cat([d[0] for d in done])
-            p_all = torch.cat([d[1] for d in done])
-            idx64 = idx_all[(gaps(p_all) < LABEL_GUARD_F32).nonzero().squeeze(1)]
-            self.last_guard["rescored_float64"] = int(idx64.numel())
-            if idx64.numel():
-                proba[idx64] = run(idx64, "float64", 32).to(proba.dtype)
-        self.last_guard["observed_error"] = err
-        self.last_guard["gap"] = gap
-        return proba
+        if not done_i:
+            return proba.new_zeros((0,), dtype=torch.long), proba.new_zeros((0, proba.shape[1])), err, reach
+        return torch.cat(done_i), torch.cat(done_p), err, reach
 
     def _exact_weights(self, dtype):
         """float32 / float64 copies of every parameter in the layout of forward_exact, cached until one is written."""
@@ -536,8 +548,7 @@ class Classifier(_module_base()):
         with torch.no_grad():
             feat = common.process_volumes(volumes, mode=mode, scale=False)
             xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="float32")
-            with torch.autocast("cuda", enabled=False):
-                return self.forward_exact(*xs, precision=precision)
+            return self.forward_exact(*xs, precision=precision)
 
     def _features_timed(self, xs, trunk_events, layout="nhwc"):
         import torch
