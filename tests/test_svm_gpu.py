@@ -689,3 +689,36 @@ def test_nan_row_through_the_svm_is_finite_and_documented(rml):
     keep = [r for r in range(9) if r != 4]
     # (the tile holding the NaN row runs on the float64 kernel as a whole: its other rows agree with the exact path to rounding)
     np.testing.assert_allclose(ovr.cpu().numpy()[keep], clean[keep], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("grid", [(64, 31, 176), (40, 24, 192)])
+def test_pipeline_on_wide_linear_plane_grids_matches_the_oracle(rml, grid):
+    """a codes-only launch of k_project_lin with a large code stage -- 64 x 31 x 176 float32 asks for 67.5 KB of wave
+    images + 4 x 12.9 KB of stage = 117.8 KB of dynamic LDS, past the 112 KB the kernel's attribute allowed (the launch failed with
+    'invalid argument': the runtime does enforce it).  The attribute is the CU's 160 KB now, with a direct-store fallback beyond
+    it.  The fused pipeline on such grids (one more of the linear-plane family: 48-quad rows) against the float64 oracle."""
+    import oracle_np as O
+    X, Y, Z = grid
+    D = X * Z + Y * Z + X * Y
+    rng = np.random.default_rng(5)
+    M = 192
+    sv_codes = (rng.random((M, D)) < 0.15) * rng.integers(13, 256, (M, D))
+    sv = (sv_codes.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    dual = rng.uniform(-3, 3, (2, M))
+    icpt = rng.uniform(-0.5, 0.5, 3)
+    nsup = np.array([64, 64, 64], dtype=np.int32)
+    svc = rml.GpuSVC(sv, dual, icpt, nsup, 0.01, np.arange(3), calib_a=np.array([-1.5, -1.2, -1.8]), calib_b=np.array([0.1, 0.0, -0.1]))
+    assert svc.exact
+    vol, _ = O.synth_volumes(17, 640, X, Y, Z)                       # >= 2 * 256 frames: the persistent wave-per-frame kernels take it
+    out = svc.decide_volumes(torch.from_numpy(vol).cuda(), mode="max", scale=True, want_proba=True)
+    import oracle_c as OC
+    xz, yz, xy = OC.project_max(vol, threads=8)
+    ref = OC.svm(OC.features(xz, yz, xy, scale=True), sv, dual, icpt, nsup, 0.01, "rbf", np.array([-1.5, -1.2, -1.8]), np.array([0.1, 0.0, -0.1]),
+                 threads=8)
+    assert np.abs(out["dec_ovo"].cpu().numpy() - ref["dec_ovo"]).max() <= TOL
+    np.testing.assert_array_equal(out["label_vote"].cpu().numpy(), ref["label_vote"])
+    np.testing.assert_array_equal(out["label_calib"].cpu().numpy(), ref["label_calib"])
+    # and the two-step route (code rows, then the GEMM) gives the same bits
+    _, q, isum, isq, flags = rml.process_volumes(torch.from_numpy(vol).cuda(), mode="max", scale=True, codes=True)
+    ovo_c, _, vote_c, _, lab_c = svc.decide_codes(q, isum, isq, flags, want_proba=True)
+    assert torch.equal(ovo_c, out["dec_ovo"]) and torch.equal(vote_c, out["label_vote"]) and torch.equal(lab_c, out["label_calib"])
