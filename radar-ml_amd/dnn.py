@@ -463,8 +463,10 @@ class Classifier(_module_base()):
                 while pos < n:
                     idx = cand[pos:pos + size]
                     pn = self._run_padded(fn, idx, size).float()
-                    d = torch.nan_to_num((proba[idx].float() - pn).abs(), nan=1.0, posinf=1.0)
-                    err = max(err, float(d.max()))
+                    d = (proba[idx].float() - pn).abs()
+                    ok = torch.isfinite(d).all(dim=1)                      # a NaN row (mode "max_nan") says nothing about the chain's error
+                    if bool(ok.any()):
+                        err = max(err, float(d[ok].max()))
                     proba[idx] = pn.to(proba.dtype)
                     g[idx] = float("inf")                                  # re-scored: never a candidate again
                     done_i.append(idx); done_p.append(pn)

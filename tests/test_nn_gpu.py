@@ -878,3 +878,8 @@ def test_predict_volumes_nan_projections_take_the_exact_resize(rml):
     assert torch.equal(a[torch.arange(64) != 5], b[torch.arange(64) != 5])
     clean = model.predict_volumes(v[:5], mode="max", exact_resize=True, label_guard=None)
     assert torch.equal(a[:5], clean)                      # a NaN frame does not leak into its neighbours
+    # with the margin guard: whatever the NaN frame's own row turns into (a packed-bf16 relu may swallow the NaN or not), it must
+    # not count as chain error -- a NaN difference would widen the gap to everything and re-score the whole batch
+    g = model.predict_volumes(v, mode="max_nan")
+    assert model.last_guard["observed_error"] < 1e-2
+    assert torch.equal(g[torch.arange(64) != 5].argmax(1), b[torch.arange(64) != 5].argmax(1))
