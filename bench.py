@@ -710,6 +710,40 @@ def _top2_margin(p):
     return srt[:, -1] - srt[:, -2]
 
 
+def dnn_bench_model(rml, dev, seed, train_steps, grid=(22, 31, 176)):
+    """The CNN row's model: the reference's architecture (dnn.py:45-91) with trained weights -- plumbing: float32 Adam steps with
+    plain PyTorch layers, dnn.py:89-90 optimizer, on synthetic 3-class frames through the reference's preprocessing; random-init
+    outputs sit at ~1/3 each and say nothing about labels.  Every rank trains the same model from the same seed."""
+    import importlib
+    import torch
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    nn_common = importlib.import_module("radar_ml_amd.nn_common")
+    X, Y, Z = grid
+    torch.manual_seed(seed)
+    model = dnn.define_classifier(device=dev)
+    tv, tcls = rml.synth_volumes(1024, X, Y, Z, seed=seed + 5, frame0=1 << 41, device=dev)
+    tfeat = rml.process_volumes(tv, mode="max", scale=False)
+    txs = [t.reshape(-1, 1, 80, 80) for t in nn_common.preprocess_features(tfeat, (X, Y, Z), (80, 80), out_dtype="float32")]
+    ty = tcls.to(dev).long()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999), eps=1e-7)
+    gtr = torch.Generator(device=dev).manual_seed(seed)
+    model.train()
+    # deterministic convolution algorithms while training: the same model in every run (MIOpen's default weight-gradient kernels
+    # accumulate with atomics: mean margin 0.45 ... 0.63 and 390 ... 1 280 guard rows from run to run of the same seed, session r5m)
+    det_was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for _ in range(train_steps):
+            idx = torch.randint(0, 1024, (64,), device=dev, generator=gtr)
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model.logits(*[t[idx] for t in txs]).float(), ty[idx]).backward()
+            opt.step()
+    finally:
+        torch.backends.cudnn.deterministic = det_was
+    model.eval()
+    return model
+
+
 def run_dnn(a, env):
     """BASELINE configs[3]: multi-view CNN inference at the Walabot arena grid -- projection into uint8 code rows (csrc/project_lin.hip;
     a device-predicated float pass for frames off the code grid) -> [-1,1] scaling + bicubic resize to 80x80 of the three projections
@@ -725,33 +759,7 @@ def run_dnn(a, env):
     dnn = importlib.import_module("radar_ml_amd.dnn")
     X, Y, Z = 22, 31, 176
     B = a.dnn_frames
-    torch.manual_seed(a.seed)
-    model = dnn.define_classifier(device=dev)
-    # trained weights (plumbing: a few hundred float32 Adam steps with plain PyTorch layers, dnn.py:89-90 optimizer, on synthetic
-    # 3-class frames through the reference's preprocessing): random-init outputs sit at ~1/3 each and say nothing about labels.
-    # Every rank trains the same model from the same seed.
-    nn_common = importlib.import_module("radar_ml_amd.nn_common")
-    tv, tcls = rml.synth_volumes(1024, X, Y, Z, seed=a.seed + 5, frame0=1 << 41, device=dev)
-    tfeat = rml.process_volumes(tv, mode="max", scale=False)
-    txs = [t.reshape(-1, 1, 80, 80) for t in nn_common.preprocess_features(tfeat, (X, Y, Z), (80, 80), out_dtype="float32")]
-    ty = tcls.to(dev).long()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999), eps=1e-7)
-    gtr = torch.Generator(device=dev).manual_seed(a.seed)
-    model.train()
-    # deterministic convolution algorithms while training: the same model in every run (MIOpen's default weight-gradient kernels
-    # accumulate with atomics: mean margin 0.45 ... 0.63 and 390 ... 1 280 guard rows from run to run of the same seed, session r5m)
-    det_was = torch.backends.cudnn.deterministic
-    torch.backends.cudnn.deterministic = True
-    try:
-        for _ in range(a.dnn_train_steps):
-            idx = torch.randint(0, 1024, (64,), device=dev, generator=gtr)
-            opt.zero_grad(set_to_none=True)
-            torch.nn.functional.cross_entropy(model.logits(*[t[idx] for t in txs]).float(), ty[idx]).backward()
-            opt.step()
-    finally:
-        torch.backends.cudnn.deterministic = det_was
-    model.eval()
-    del tv, tfeat, txs, opt
+    model = dnn_bench_model(rml, dev, a.seed, a.dnn_train_steps, (X, Y, Z))
     V, Vcls = rml.synth_volumes(B, X, Y, Z, seed=a.seed + 7, frame0=rank * B, device=dev)
     from radar_ml_amd import dist as rdist
 

@@ -372,6 +372,40 @@ int rml_dnn_trunk_kblock(rml_ctx* ctx, const void* xz, const void* yz, const voi
                          const float* w1, const float* b1, const uint16_t* w2t, const float* b2,
                          uint16_t* feat, void* stream);
 
+/* The same two convolutions at float32-class accuracy (csrc/dnn_x3.hip, round 6) -- the reference's model.predict is float32 Keras
+ * (dnn.py:373-381): every operand is carried as `parts` bf16 numbers and every product as the matrix-core products of the part
+ * pairs (i, j) with i + j < parts, float32 accumulation.  parts = 2 ("x3": 16 significant bits, three products, ~2^-16 relative
+ * per product where rml_dnn_trunk has bf16's 2^-9; about 3.5 x the time of rml_dnn_trunk per sample) or 3 ("x6": 24 bits, six
+ * products, what is dropped is the size of float32's own rounding; about twice x3).  Planes float32 (rml_resize_bicubic's
+ * Pillow-bit-identical output), weights float32: w1 [3][64][9], b1 [3][64], w2 [3][32][576] (k = (ky*3+kx)*64 + cin; NOT transposed
+ * to bf16), b2 [3][32]; feat[b][(h*(W/4)+w)*96 + branch*32 + n] float32 (Keras' Flatten order).  Planes, w2 and feat 16-byte aligned.
+ * The second opinion of the margin guard (radar-ml_amd/dnn.py), not the fast path.
+ * rml_dnn_trunk_x3_supported: H, W multiples of 4 and three float32 planes + 72 KB of weight fragments (one plane + 108 KB for
+ * parts = 3) within the 160 KB LDS -- the 80 x 80 of dnn.py:33 does; otherwise RML_ERR_UNSUPPORTED. */
+int rml_dnn_trunk_x3_supported(int H, int W);
+int rml_dnn_trunk_x3(rml_ctx* ctx, const float* xz, const float* yz, const float* xy, int64_t B, int H, int W,
+                     const float* w1, const float* b1, const float* w2, const float* b2, int parts, float* feat, void* stream);
+
+/* Volumes -> float32-class features in one call (the re-scoring front of the margin guard): frames rows[0..n) of V (rows = NULL: the
+ * first n frames) gathered into scratch, projected exactly (rml_project, float32 rows, mode MAX / SUM / MAX_NAN), scaled to [-1, 1]
+ * and resized with rml_resize_bicubic (Pillow-bit-identical float32 planes), then rml_dnn_trunk_x3 with `parts`.  scratch:
+ * rml_dnn_exact_features_scratch_bytes(vdtype, n, X, Y, Z, out_h, out_w, rows != NULL) bytes, 256-byte aligned. */
+int64_t rml_dnn_exact_features_scratch_bytes(int vdtype, int64_t n, int X, int Y, int Z, int out_h, int out_w, int gathered);
+int rml_dnn_exact_features(rml_ctx* ctx, const void* V, int vdtype, const int64_t* rows, int64_t n, int X, int Y, int Z, int mode,
+                           int out_h, int out_w, const float* w1, const float* b1, const float* w2, const float* b2, int parts,
+                           void* scratch, int64_t scratch_bytes, float* feat, void* stream);
+
+/* ---- the margin guard's device side (radar-ml_amd/dnn.py Classifier._guard; labels of model.predict, dnn.py:373-381) --------------
+ * rml_dnn_top2_gap: gap[r] = largest - second largest of proba[r][0..C) (rows ld floats apart, 2 <= C <= 16); 0 for a row that
+ * holds a non-finite value (it counts as a tie).
+ * rml_dnn_guard_apply: one re-scoring round's bookkeeping in one launch -- proba[rows[i]] <- fresh[i] (fresh: n x C contiguous),
+ * stats[0] = atomic max over the rows where both are finite of |old - new| as float32 BITS (non-negative floats order like unsigned
+ * integers; zero stats before the call), stats[1] += rows whose new top-2 gap is below thr_close, close[i] = that test,
+ * gap[rows[i]] = +inf when gap is given (re-scored: never a candidate again). */
+int rml_dnn_top2_gap(rml_ctx* ctx, const float* proba, int64_t ld, int64_t N, int C, float* gap, void* stream);
+int rml_dnn_guard_apply(rml_ctx* ctx, float* proba, int64_t ld, int C, const int64_t* rows, int64_t n, const float* fresh,
+                        float thr_close, float* gap, uint32_t* stats, uint8_t* close, void* stream);
+
 /* ---- dnn.py dense tail (dnn.py:78-88), fused -----------------------------------------------------------------
  * Dense 64 relu -> Dense 64 relu -> Dense n_classes softmax on the bf16 feature rows of rml_dnn_trunk (Dropout is inactive at
  * inference): proba[b][c] float32.  The first layer runs on the bf16 matrix cores (float32 accumulation, split-K with the partial

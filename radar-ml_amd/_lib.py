@@ -82,6 +82,15 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p]),
     "rml_dnn_trunk_kblock": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "rml_dnn_trunk_x3_supported": (c_int, [c_int, c_int]),
+    "rml_dnn_trunk_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_void_p, c_void_p]),
+    "rml_dnn_exact_features_scratch_bytes": (c_int64, [c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rml_dnn_exact_features": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rml_dnn_top2_gap": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "rml_dnn_guard_apply": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "rml_dnn_dense_workspace_bytes": (c_int64, [c_void_p, c_int64, c_int64]),
     "rml_dnn_dense_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -17,9 +17,13 @@ RESCALE = (80, 80)          # dnn.py:33
 # chain moves a probability by <= 3.4e-3 on trained weights (larger logits) and <= 4.8e-4 on random-init ones (measured against
 # the float64 restatement, tests/test_nn_gpu.py DNN_BF16_PROBA_TOL / _RANDOM_INIT_TOL), i.e. a gap by <= 6.8e-3: 3 x that.
 LABEL_GUARD = 2e-2
-# Second level: the float32 layers on exact inputs are within ~1e-6 of float64 (measured 7e-8 .. 1e-6); rows whose float32 gap is
-# below this go to float64.
-LABEL_GUARD_F32 = 1e-4
+# Second level: the float32-class trunk (csrc/dnn_x3.hip) + float32 dense layers on exact inputs; rows whose gap there is below this
+# go to float64.  Measured against float64 (tests/test_nn_gpu.py::test_x3_trunk_*): see DNN_X3_PROBA_TOL there; 8 x that.
+LABEL_GUARD_X3 = 1e-4
+# Third level: the same kernel with three bf16 parts per operand ("x6": float32-class in the strict sense) on the rows whose x3 gap is
+# below LABEL_GUARD_X3; rows whose gap there is below this go to float64.
+LABEL_GUARD_X6 = 1e-5
+LABEL_GUARD_F32 = LABEL_GUARD_X3        # (the name of rounds 1-5, when this stage ran PyTorch's float32 layers)
 
 
 def define_classifier(xz_shape=(80, 80, 1), yz_shape=(80, 80, 1), xy_shape=(80, 80, 1), n_classes=3,
@@ -299,13 +303,16 @@ class Classifier(_module_base()):
         4.6-4.7 against 4.7-4.8 M frames/s.  Kept as a knob.  ``trunk_events``: a list that receives one (start, stop, frames)
         torch.cuda.Event triple per trunk launch (bench.py's in-situ roofline of k_dnn_trunk_rf).
 
-        ``label_guard`` (default LABEL_GUARD = 2e-2; None or 0 turns it off): the margin guard that makes ``argmax`` of the result
-        the float64 label.  The bf16 chain moves a probability by at most 3.4e-3 (measured against the float64 restatement of the
-        Keras layers, trained weights; 4.8e-4 on random-init ones), so a row whose two largest probabilities are more than ``label_guard`` apart
-        has the label the float64 arithmetic gives; the rows closer than that -- and only those -- are scored again from their
-        volumes on the GPU from exact inputs (exact projection, Pillow-bit-identical resize: :meth:`rescore_exact`), in float32 first
-        and, where the float32 gap is below LABEL_GUARD_F32, in float64; their probabilities are replaced.  The gap calibrates itself:
-        it is widened to four times the bf16 error seen on the re-scored rows.  ``self.last_guard`` = {"rows", "rescored",
+        ``label_guard`` (default LABEL_GUARD = 2e-2; None or 0 turns it off): the margin guard (:meth:`_guard`).  The bf16 chain moves a
+        probability by up to 3.4e-3 (measured against the float64 restatement of the Keras layers, trained weights; 4.8e-4 on random-init
+        ones), so rows whose two largest probabilities are closer than ``label_guard`` -- and only those -- are scored again from
+        their volumes from exact inputs (exact projection, Pillow-bit-identical resize: :meth:`rescore_exact`): all of them at once
+        through the float32-class trunk (csrc/dnn_x3.hip, bf16 operand pairs: ~1e-5 from float64, 0.2-0.3 us per row) and, where that
+        gap is below LABEL_GUARD_X3, in float64; their probabilities are replaced.  The gap calibrates itself: it is widened to four
+        times the bf16 error seen on the re-scored rows -- an EMPIRICAL bound: ``argmax`` is the float64 label on every row inside the
+        covered gap and on every row outside it whose bf16 error is below twice the largest error seen.  Guarded outputs are not
+        batching-invariant bit for bit (a row near the gap may be re-scored under one batching and not under another; both values
+        are within the bf16 tolerance); ``label_guard=None`` results are.  ``self.last_guard`` = {"rows", "rescored",
         "rescored_float64", "observed_error", "gap"}.
         """
         import torch
@@ -346,7 +353,7 @@ class Classifier(_module_base()):
                 # the margin guard once per call, behind the last pass.  (Per pass on a second stream beside the next pass, with a
                 # context of its own, was measured in session r5f: no overlap -- the chain's persistent kernels hold every CU and
                 # the guard's small launches start only at kernel boundaries -- and more padded chunks: 58 % against ~35 %.)
-                return self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(vol(idx), rescale, mode, prec))
+                return self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(volumes, rescale, mode, prec, rows=idx))
             lib = _lib.load()
             ctx = _lib.context(dev)
             sp = getattr(self, "_proj_stream", None)
@@ -394,33 +401,109 @@ class Classifier(_module_base()):
             finally:
                 _lib.check(lib.rml_ctx_set_option(ctx, _lib.OPT_PROJECT_SHARE_CU, 0), "rml_ctx_set_option")
             cur.wait_stream(sp)
-            out = self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(volumes[idx], rescale, mode, prec))
+            out = self._guard(out, label_guard, lambda idx, prec: self.rescore_exact(volumes, rescale, mode, prec, rows=idx))
         return out
 
     # ---- margin guard: float64 labels from a bf16 chain -------------------------------------------------
-    def _guard(self, proba, eps, rescore, chunk=256):
-        """Replace the rows of ``proba`` (N, C) whose top-2 gap is too small for a bf16 chain by what exact-input arithmetic gives:
-        ``rescore(rows, "float32")`` first (float32 layers on exact inputs, error ~1e-6; :meth:`_guard_stage` picks the rows), and
-        for the rows whose float32 gap is still below LABEL_GUARD_F32 ``rescore(rows, "float64")``.  ``self.last_guard`` = {"rows",
-        "rescored", "rescored_float64", "observed_error" (of the bf16 chain on the re-scored rows), "gap"}.
-        (An fp16 stage in front -- the plain layers under fp16 autocast on exact inputs -- was measured in session r5o: MIOpen's /
-        hipBLASLt's fp16 path is 1.2e-2 away from float32 on these layers, worse than the bf16 chain it was meant to referee.)"""
+    def _guard(self, proba, eps, rescore):
+        """Replace the rows of ``proba`` (N, C) whose top-2 gap is too small for a bf16 chain by what exact-input arithmetic gives.
+        Stage 1, ``rescore(rows, "x3")``: the float32-class trunk (csrc/dnn_x3.hip: every operand as a bf16 pair, three matrix-core
+        products per product) + float32 dense layers on exact inputs, ~1e-5 from float64, ALL candidates of a round in one pass --
+        0.2-0.3 us per row, no host round trip but the candidate count and one (error, count) read-back.  The gap calibrates itself:
+        a round's candidates are the rows below ``eps``; their re-scoring measures the bf16 chain's error; if four times that error
+        (a gap moves by at most twice a probability's error, twice again for margin) reaches past the gap covered so far, the rows in
+        between are the next round.  Stage 2: rows whose x3 gap is still below LABEL_GUARD_X3 go through ``rescore(rows, "x6")``
+        (three bf16 parts per operand: float32-class in the strict sense); stage 3: rows whose x6 gap is below LABEL_GUARD_X6
+        through ``rescore(rows, "float64")``.  The bound is EMPIRICAL: a row outside the covered gap whose bf16 error exceeds twice the largest error seen
+        on the re-scored rows keeps its bf16 label (``last_guard["covered"]`` is False when the loop gave up before the gap covered
+        four times the error).  The gap a call ends with is where the next call on the same weights starts (the same
+        rows, the same bits when the call is repeated).  ``self.last_guard`` = {"rows", "rescored", "rescored_float64", "observed_error", "gap", "rounds",
+        "covered"}."""
         import torch
-        self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0}
+        from . import _lib
+        self.last_guard = {"rows": int(proba.shape[0]), "rescored": 0, "rescored_float64": 0, "rounds": 0, "covered": True}
         if not eps or proba.shape[0] == 0 or proba.shape[1] < 2:
             return proba
-        idx, p32, err, reach = self._guard_stage(proba, float(eps), lambda rows: rescore(rows, "float32"), chunk)
-        self.last_guard.update(rescored=int(idx.numel()), observed_error=err, gap=reach)
-        if idx.numel():
-            sel = (self._gaps(p32) < LABEL_GUARD_F32).nonzero().squeeze(1)
-            self.last_guard["rescored_float64"] = int(sel.numel())
-            if sel.numel():
-                proba[idx[sel]] = self._run_padded(lambda rows: rescore(rows, "float64"), idx[sel], 32).to(proba.dtype)
+        if not (proba.is_cuda and proba.dtype == torch.float32 and proba.stride(1) == 1 and proba.shape[1] <= 16):
+            raise ValueError("_guard: a CUDA float32 (N, C <= 16) probability tensor expected")
+        lib, dev = _lib.load(), proba.device
+        N, C, ld = int(proba.shape[0]), int(proba.shape[1]), int(proba.stride(0))
+        thr, err, err3, err6, n3, n6, n64, rounds = float(eps), 0.0, 0.0, 0.0, 0, 0, 0, 0
+        # the gap the last call on these weights ended with is where this one starts: one round instead of two in the steady state
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        if getattr(self, "_guard_gap_key", None) == key:
+            thr = max(thr, self._guard_gap)
+        with torch.cuda.device(dev):
+            ctx, st = _lib.context(dev), _lib.stream_ptr(dev)
+            g = torch.empty((N,), dtype=torch.float32, device=dev)
+            _lib.check(lib.rml_dnn_top2_gap(ctx, _lib.ptr(proba), ld, N, C, _lib.ptr(g), st), "rml_dnn_top2_gap")
+            stats = torch.zeros((2,), dtype=torch.int32, device=dev)
+            while True:
+                cand = (g < thr).nonzero().squeeze(1)                       # device -> host: the candidate count
+                n = int(cand.numel())
+                if n:
+                    rounds += 1
+                    p3 = rescore(cand, "x3").float().contiguous()
+                    close = torch.empty((n,), dtype=torch.uint8, device=dev)
+                    stats.zero_()
+                    # rows replaced, largest |bf16 - x3| on them, the rows still near a tie, g[rows] = inf: one launch
+                    _lib.check(lib.rml_dnn_guard_apply(ctx, _lib.ptr(proba), ld, C, _lib.ptr(cand), n, _lib.ptr(p3), float(LABEL_GUARD_X3),
+                                                       _lib.ptr(g), _lib.ptr(stats), _lib.ptr(close), st), "rml_dnn_guard_apply")
+                    sh = stats.cpu()                                        # device -> host: the error seen, rows for float64
+                    err = max(err, float(sh[:1].view(torch.float32)[0]))
+                    n3 += n
+                    if int(sh[1]):
+                        # second stage: the rows still near a tie through the three-part trunk ("x6"), the same bookkeeping launch
+                        rows6 = cand[close.nonzero().squeeze(1)]
+                        p6 = rescore(rows6, "x6").float().contiguous()
+                        k6 = int(rows6.numel())
+                        close6 = torch.empty((k6,), dtype=torch.uint8, device=dev)
+                        stats.zero_()
+                        _lib.check(lib.rml_dnn_guard_apply(ctx, _lib.ptr(proba), ld, C, _lib.ptr(rows6), k6, _lib.ptr(p6), float(LABEL_GUARD_X6),
+                                                           None, _lib.ptr(stats), _lib.ptr(close6), st), "rml_dnn_guard_apply")
+                        sh = stats.cpu()
+                        err3 = max(err3, float(sh[:1].view(torch.float32)[0]))
+                        n6 += k6
+                        if int(sh[1]):
+                            sel = close6.nonzero().squeeze(1)
+                            k64, e6 = self._guard_float64(proba, rows6[sel], p6[sel], rescore)
+                            n64 += k64
+                            err6 = max(err6, e6)
+                if thr >= min(4.0 * err, 1.0):
+                    break
+                if rounds >= 4:
+                    self.last_guard["covered"] = False
+                    break
+                thr = min(8.0 * err, 1.0)
+        self.last_guard.update(rescored=n3, rescored_x6=n6, rescored_float64=n64, observed_error=err, observed_error_x3=err3,
+                               observed_error_x6=err6, gap=thr, rounds=rounds)
+        if rounds:
+            self._guard_gap_key, self._guard_gap = key, thr
         return proba
+
+    def _guard_float64(self, proba, rows, p3, rescore, chunk=32):
+        """Last stage: ``rows`` (their x6 probabilities ``p3`` have a top-2 gap below LABEL_GUARD_X6), closest ties first, ``chunk``
+        at a time through ``rescore(rows, "float64")``; the pass stops at the first chunk boundary whose gap is at least eight times
+        the largest |x6 - float64| seen (at least 1e-6).  Returns (rows re-scored, largest error of the x6 stage seen)."""
+        import torch
+        g3 = self._gaps(p3)
+        order = torch.argsort(g3)
+        gs = g3[order].cpu()                                                 # ascending, on the host
+        rows, p3 = rows[order], p3[order]
+        n, pos, e3 = int(rows.numel()), 0, 0.0
+        while pos < n:
+            idx = rows[pos:pos + chunk]
+            p64 = self._run_padded(lambda r: rescore(r, "float64"), idx, chunk)
+            e3 = max(e3, float((p3[pos:pos + chunk].double() - p64.double()).abs().max()))
+            proba[idx] = p64.to(proba.dtype)
+            pos += int(idx.numel())
+            if pos < n and float(gs[pos]) >= max(8.0 * e3, 1e-6):
+                break
+        return pos, e3
 
     @staticmethod
     def _gaps(p):
-        """top-2 gap per row; a row with a non-finite probability (an fp16 overflow) counts as a tie"""
+        """top-2 gap per row; a row with a non-finite probability counts as a tie"""
         import torch
         top2 = torch.nan_to_num(p.float(), nan=0.0, posinf=0.0, neginf=0.0).topk(2, dim=1).values
         g = top2[:, 0] - top2[:, 1]
@@ -440,53 +523,6 @@ class Classifier(_module_base()):
             outs.append(fn(sel)[:k])
         return torch.cat(outs)
 
-    def _guard_stage(self, proba, eps, fn, chunk):
-        """Closest ties first.  The rows of ``proba`` with a top-2 gap below ``eps`` are sorted by their gap;
-        the first ``chunk`` of them measure the error of ``proba`` against ``fn(rows)``; the next launch takes every candidate still
-        below 4 x that error at once (padded to a multiple of 64 rows, at most 1 024 per launch), and so on until the next
-        candidate's gap is safe -- a gap moves by at most twice a probability's error, and twice again for margin; a batch whose
-        error asks for more than ``eps`` gets the next candidates (gap < 8 x error) the same way.  Re-scored rows are written into
-        ``proba``.  Returns (rows re-scored, their new probabilities, largest error seen, the gap below which every row was
-        re-scored)."""
-        import torch
-        g = self._gaps(proba)
-        thr, reach, err = float(eps), 0.0, 0.0
-        done_i, done_p = [], []
-        for _ in range(4):
-            cand = (g < thr).nonzero().squeeze(1)                          # a device -> host count per round
-            n = int(cand.numel())
-            stop = False
-            if n:
-                cand = cand[torch.argsort(g[cand])]
-                gs = g[cand].cpu()                                         # the candidates' gaps, ascending, on the host
-                pos, size = 0, min(chunk, max(64, -(-n // 64) * 64))
-                while pos < n:
-                    idx = cand[pos:pos + size]
-                    pn = self._run_padded(fn, idx, size).float()
-                    d = (proba[idx].float() - pn).abs()
-                    ok = torch.isfinite(d).all(dim=1)                      # a NaN row (mode "max_nan") says nothing about the chain's error
-                    if bool(ok.any()):
-                        err = max(err, float(d[ok].max()))
-                    proba[idx] = pn.to(proba.dtype)
-                    g[idx] = float("inf")                                  # re-scored: never a candidate again
-                    done_i.append(idx); done_p.append(pn)
-                    pos += int(idx.numel())
-                    need = int(torch.searchsorted(gs, torch.tensor(4.0 * err))) - pos      # candidates still below 4 x the error seen
-                    if need <= 0:
-                        reach = float(gs[pos]) if pos < n else thr
-                        stop = pos < n
-                        break
-                    size = min(-(-need // 64) * 64, 1024)
-            if stop:
-                break
-            reach = thr                                                    # no candidate left below thr
-            if thr >= 4.0 * err:
-                break
-            thr = min(8.0 * err, 1.0)
-        if not done_i:
-            return proba.new_zeros((0,), dtype=torch.long), proba.new_zeros((0, proba.shape[1])), err, reach
-        return torch.cat(done_i), torch.cat(done_p), err, reach
-
     def _exact_weights(self, dtype):
         """float32 / float64 copies of every parameter in the layout of forward_exact, cached until one is written."""
         key = tuple((p._version, p.data_ptr()) for p in self.parameters())
@@ -499,17 +535,63 @@ class Classifier(_module_base()):
                 "fc": [(fc.weight.detach().to(dtype), fc.bias.detach().to(dtype)) for fc in (self.fc1, self.fc2, self.fc3)]}
         return self._exact[dtype]
 
+    def _x3_weights(self):
+        """float32 conv weights in the layout of rml_dnn_trunk_x3 (w1 [3][64][9], b1 [3][64], w2 [3][32][576] with k = (ky*3+kx)*64 +
+        cin, b2 [3][32]), cached until a convolution parameter is written."""
+        import torch
+        key = tuple((p._version, p.data_ptr()) for br in self.branches for cv in (br[0].conv, br[1].conv) for p in (cv.weight, cv.bias))
+        if getattr(self, "_x3_key", None) != key:
+            self._x3_key = key
+            self._x3_pack = (
+                torch.stack([br[0].conv.weight.detach().float().reshape(64, 9) for br in self.branches]).contiguous(),
+                torch.stack([br[0].conv.bias.detach().float() for br in self.branches]).contiguous(),
+                torch.stack([br[1].conv.weight.detach().float().permute(0, 2, 3, 1).reshape(32, 576) for br in self.branches]).contiguous(),
+                torch.stack([br[1].conv.bias.detach().float() for br in self.branches]).contiguous())
+        return self._x3_pack
+
+    def x3_supported(self, H, W):
+        """True when csrc/dnn_x3.hip takes (H, W) planes of this model: three branches of Conv2D(1->64) -> Conv2D(64->32), 3x3."""
+        from . import _lib
+        return (len(self.branches) == 3 and all(tuple(br[0].conv.weight.shape) == (64, 1, 3, 3) and tuple(br[1].conv.weight.shape) == (32, 64, 3, 3)
+                                                for br in self.branches)
+                and bool(_lib.load().rml_dnn_trunk_x3_supported(int(H), int(W))))
+
+    def features_x3(self, xz, yz, xy, parts=2):
+        """The conv features in float32 from the float32-class trunk (csrc/dnn_x3.hip): (N,H,W) or (N,1,H,W) CUDA float32 planes ->
+        (N, 38 400) rows in Keras' Flatten order.  ``parts`` = 2: ~2^-16 relative per product (bf16 pairs, three matrix-core
+        products each, "x3"); 3: ~2^-24 (bf16 triples, six products, "x6")."""
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        xs = [x.reshape(x.shape[0], x.shape[-2], x.shape[-1]).float().contiguous() for x in (xz, yz, xy)]
+        n, H, W = xs[0].shape
+        dev = xs[0].device
+        w1, b1, w2, b2 = self._x3_weights()
+        feat = torch.empty((n, (H // 4) * (W // 4) * 96), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_dnn_trunk_x3(_lib.context(dev), _lib.ptr(xs[0]), _lib.ptr(xs[1]), _lib.ptr(xs[2]), n, H, W, _lib.ptr(w1),
+                                            _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), int(parts), _lib.ptr(feat), _lib.stream_ptr(dev)), "rml_dnn_trunk_x3")
+        return feat
+
     def forward_exact(self, xz, yz, xy, precision="float64"):
-        """The layers of dnn.py:45-91 in float32 or float64 on the inputs' device, no half-precision operand anywhere:
-        (N,H,W) or (N,1,H,W) planes -> (N, n_classes) probabilities.  float32: the plain PyTorch layers (MIOpen float32
-        convolutions, hipBLASLt).  float64: im2col by nine strided slices + rocBLAS matrix products (MIOpen has no float64
-        convolution and PyTorch's fallback takes 10 ms for a handful of rows; F.unfold is as slow).  The margin guard's arithmetic
-        -- a few hundred rows per batch -- not the fast path."""
+        """The layers of dnn.py:45-91 on the inputs' device with no single-bf16 operand anywhere, dropout inactive whatever the
+        module's mode: (N,H,W) or (N,1,H,W) planes -> (N, n_classes) probabilities.
+        "x3" / "x6": the float32-class HIP trunk (:meth:`features_x3`, two / three bf16 parts per operand) + the dense layers in
+        float32 (hipBLASLt) -- the margin guard's first two stages; planes it does not take fall to "float32".  "float32": the plain PyTorch layers (MIOpen float32 convolutions,
+        hipBLASLt), the reference's own arithmetic.  "float64": im2col by nine strided slices + rocBLAS matrix products (MIOpen
+        has no float64 convolution and PyTorch's fallback takes 10 ms for a handful of rows; F.unfold is as slow)."""
         import torch
         import torch.nn.functional as F
+        if precision not in ("x3", "x6", "float32", "float64"):
+            raise ValueError("precision must be 'x3', 'x6', 'float32' or 'float64'")
         if precision != "float64":
             with torch.autocast("cuda", enabled=False):
-                return self(*[x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).float() for x in (xz, yz, xy)])
+                xs = [x.reshape(x.shape[0], 1, x.shape[-2], x.shape[-1]).float() for x in (xz, yz, xy)]
+                if precision in ("x3", "x6") and xs[0].is_cuda and self.x3_supported(xs[0].shape[-2], xs[0].shape[-1]):
+                    fv = self.features_x3(*xs, parts=3 if precision == "x6" else 2)
+                else:
+                    fv = self.features(*xs)
+                return self._tail_float32(fv)
         dt = torch.float64
         w = self._exact_weights(dt)
         outs = []
@@ -535,22 +617,102 @@ class Classifier(_module_base()):
         h = F.relu(F.linear(h, w2, b2))
         return torch.softmax(F.linear(h, w3, b3), dim=-1)
 
+    def _tail_float32(self, fv):
+        """Dense 64 relu, Dense 64 relu, Dense n softmax in float32 on float32 feature rows (no dropout: inference)."""
+        import torch
+        import torch.nn.functional as F
+        (w1, b1), (w2, b2), (w3, b3) = self._exact_weights(torch.float32)["fc"]
+        h = F.relu(F.linear(fv, w1, b1))
+        h = F.relu(F.linear(h, w2, b2))
+        return torch.softmax(F.linear(h, w3, b3), dim=-1)
+
+    def exact_features(self, volumes, rows=None, rescale=(80, 80), mode="max", parts=2):
+        """CUDA volumes (float32 or uint8) -> float32-class conv features of frames ``rows`` (an int64 CUDA index tensor; None:
+        all) in ONE library call (rml_dnn_exact_features: gather, exact projection, Pillow-bit-identical resize, x3 / x6 trunk)."""
+        import torch
+        from . import _lib, common
+        lib = _lib.load()
+        v, vdt = common._as_device_volumes(volumes)
+        dev = v.device
+        X, Y, Z = (int(t) for t in v.shape[1:])
+        n = int(rows.numel()) if rows is not None else int(v.shape[0])
+        oh, ow = int(rescale[1]), int(rescale[0])
+        w1, b1, w2, b2 = self._x3_weights()
+        feat = torch.empty((n, (oh // 4) * (ow // 4) * 96), dtype=torch.float32, device=dev)
+        if n == 0:
+            return feat
+        if rows is not None:
+            rows = rows.to(device=dev, dtype=torch.int64).contiguous()
+        nbytes = int(lib.rml_dnn_exact_features_scratch_bytes(vdt, n, X, Y, Z, oh, ow, 1 if rows is not None else 0))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rml_dnn_exact_features(_lib.context(dev), _lib.ptr(v), vdt, _lib.ptr(rows), n, X, Y, Z, _lib.MODES[mode], oh, ow,
+                                                  _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), int(parts), _lib.ptr(scratch), nbytes,
+                                                  _lib.ptr(feat), _lib.stream_ptr(dev)), "rml_dnn_exact_features")
+        return feat
+
     def forward_float64(self, xz, yz, xy):
         """:meth:`forward_exact` in float64: what the oracle's NumPy restatement computes, to ~1e-16."""
         return self.forward_exact(xz, yz, xy, "float64")
 
-    def rescore_exact(self, volumes, rescale=(80, 80), mode="max", precision="float64"):
+    # frames per pass of rescore_exact: the gathered volumes, their float rows, three float32 planes and 150 KB of float32 features each
+    RESCORE_BYTES = 2 << 30
+
+    def rescore_exact(self, volumes, rescale=(80, 80), mode="max", precision="float64", rows=None):
         """(n,X,Y,Z) volumes -> (n, n_classes) probabilities through the reference's chain without a rounding the reference does
         not have: projection (exact), (p - 127.5) / 127.5 and Pillow's bicubic resize in float64 rounded to float32 planes as
-        Pillow stores them (csrc/resize.hip, bit-identical), then the layers in ``precision``: "float32" (the reference's own
-        arithmetic, dnn.py runs Keras in float32) or "float64" (the oracle's)."""
+        Pillow stores them (csrc/resize.hip, bit-identical), then the layers in ``precision`` (:meth:`forward_exact`: "x3",
+        "float32" -- the reference's own arithmetic, dnn.py runs Keras in float32 -- or "float64", the oracle's).  ``rows``: an index
+        tensor -- score ``volumes[rows]`` (in that order), a pass of at most RESCORE_BYTES of volumes at a time.  A sparse ``rows``
+        gathers its frames; when at least half of the frames are wanted the passes project whole contiguous blocks of frames
+        instead (no 480 KB-per-frame gather) and pick the 40 KB feature rows."""
         import torch
         from . import common, nn_common
+        N = int(volumes.shape[0])
         X, Y, Z = (int(v) for v in volumes.shape[1:])
-        with torch.no_grad():
-            feat = common.process_volumes(volumes, mode=mode, scale=False)
+        per = max(1, X * Y * Z * volumes.element_size())
+        step = max(64, min(16384, self.RESCORE_BYTES // per))
+        host = not volumes.is_cuda
+        dev = next(self.parameters()).device
+
+        def score(v, pick=None):
+            if host:
+                v = v.to(dev)
+            feat = common.process_volumes(v, mode=mode, scale=False)
+            if pick is not None:
+                feat = feat[pick]
             xs = nn_common.preprocess_features(feat, (X, Y, Z), rescale, out_dtype="float32")
             return self.forward_exact(*xs, precision=precision)
+
+        with torch.no_grad():
+            fused = (precision in ("x3", "x6") and not host and mode != "slice" and self.x3_supported(int(rescale[1]), int(rescale[0]))
+                     and volumes.dtype in (torch.float32, torch.uint8) and volumes.is_contiguous())
+            if fused and rows is not None and 2 * int(rows.numel()) < N:
+                # the sparse case on the device: one library call per pass (gather, projection, resize, trunk) + the float32 tail
+                n = int(rows.numel())
+                outs = [self._tail_float32(self.exact_features(volumes, rows[s:s + step], rescale, mode, 3 if precision == "x6" else 2))
+                        for s in range(0, n, step)]
+            elif rows is None:
+                outs = [score(volumes[s:s + step]) for s in range(0, N, step)]
+            elif 2 * int(rows.numel()) >= N:
+                # (nothing is gathered here: a pass is bounded by its intermediates -- 270 KB per frame -- not by RESCORE_BYTES of volumes)
+                srt, order = torch.sort(rows)
+                dstep = 16384
+                cuts = torch.searchsorted(srt, torch.arange(0, N + dstep, dstep, device=srt.device, dtype=srt.dtype)).cpu().tolist()
+                outs = []
+                for i, s in enumerate(range(0, N, dstep)):
+                    if cuts[i + 1] > cuts[i]:
+                        outs.append(score(volumes[s:s + dstep], (srt[cuts[i]:cuts[i + 1]] - s).to(dev)))
+                res = torch.empty_like(torch.cat(outs))
+                res[order.to(dev)] = torch.cat(outs)
+                return res
+            else:
+                n = int(rows.numel())
+                outs = []
+                for s in range(0, n, step):
+                    sel = rows[s:s + step]
+                    outs.append(score(volumes[sel.cpu() if host else sel]))
+        return torch.cat(outs) if len(outs) != 1 else outs[0]
 
     def _features_timed(self, xs, trunk_events, layout="nhwc"):
         import torch

@@ -182,6 +182,114 @@ def test_dnn_trained_model_labels_match_the_oracle_on_every_row(rml):
     np.testing.assert_array_equal(got_h, got)
 
 
+def test_x3_trunk_is_float32_class(rml):
+    """csrc/dnn_x3.hip (every operand a bf16 pair, three matrix-core products per product) against float64 layers on the same
+    float32 planes and weights: features to ~1e-5 relative of the row's scale, class probabilities within DNN_X3_PROBA_TOL --
+    random-init and trained weights, batch sizes that leave waves idle (1, 2, 7), planes other than 80 x 80."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    torch.manual_seed(5)
+    rng = np.random.default_rng(6)
+    cpu_t, _, _ = _train_classifier_with_margins(dnn, steps=60)
+    worst, worst6 = {}, {}
+    for name, cpu in (("random-init", dnn.define_classifier(device="cpu").eval()), ("trained", cpu_t)):
+        with torch.no_grad():
+            for br in cpu.branches:                    # non-zero biases on the random-init model too (Keras starts them at 0)
+                for cv in br:
+                    if name == "random-init":
+                        cv.conv.bias.uniform_(-0.3, 0.3)
+        gpu = copy.deepcopy(cpu).to("cuda").eval()
+        ref = copy.deepcopy(cpu).double().eval()
+        for n in (1, 2, 7, 200):
+            x = [torch.from_numpy(rng.uniform(-1, 1, (n, 1, 80, 80)).astype(np.float32)) for _ in range(3)]
+            with torch.no_grad():
+                f64 = ref.features(*[t.double() for t in x])
+                p64 = ref(*[t.double() for t in x])
+            xg = [t.cuda() for t in x]
+            f3 = gpu.features_x3(*xg).double().cpu()
+            assert f3.shape == f64.shape
+            scale = f64.abs().max(dim=1, keepdim=True).values.clamp_min(1e-30)
+            ferr = float(((f3 - f64).abs() / scale).max())
+            p3 = gpu.forward_exact(*xg, precision="x3").double().cpu()
+            perr = float((p3 - p64).abs().max())
+            p32 = gpu.forward_exact(*xg, precision="float32").double().cpu()
+            worst[name] = max(worst.get(name, 0.0), perr)
+            # three bf16 parts per operand, six products: float32-class in the strict sense
+            f6 = gpu.features_x3(*xg, parts=3).double().cpu()
+            ferr6 = float(((f6 - f64).abs() / scale).max())
+            perr6 = float((gpu.forward_exact(*xg, precision="x6").double().cpu() - p64).abs().max())
+            worst6[name] = max(worst6.get(name, 0.0), perr6)
+            print("x3 trunk, %s weights, %d rows: features %.2e of the row maximum (x6: %.2e), |dp| x3 vs float64 = %.2e, x6 %.2e (MIOpen float32: %.2e)"
+                  % (name, n, ferr, ferr6, perr, perr6, float((p32.detach() - p64).abs().max())))
+            assert ferr < 3e-5 and ferr6 < 2e-6          # x6 sits on the float32 accumulation's own noise (576- and 16-term sums)
+            assert perr < DNN_X3_PROBA_TOL and perr6 < DNN_X6_PROBA_TOL
+            assert (f3 >= 0).all() and (f6 >= 0).all()                             # relu
+    # other planes: H, W multiples of 4 that fit the LDS; zero rows / columns at the edges ('same' padding on the bottom / right)
+    for (H, W) in ((64, 64), (40, 48), (84, 80), (8, 8)):
+        torch.manual_seed(H * 100 + W)
+        cpu = dnn.Classifier([(H, W, 1)] * 3, 3).eval()
+        assert cpu.x3_supported(H, W)
+        gpu = copy.deepcopy(cpu).to("cuda").eval()
+        ref = copy.deepcopy(cpu).double().eval()
+        x = [torch.from_numpy(rng.uniform(-1, 1, (5, 1, H, W)).astype(np.float32)) for _ in range(3)]
+        with torch.no_grad():
+            f64 = ref.features(*[t.double() for t in x])
+        f3 = gpu.features_x3(*[t.cuda() for t in x]).double().cpu()
+        scale = f64.abs().max(dim=1, keepdim=True).values.clamp_min(1e-30)
+        assert float(((f3 - f64).abs() / scale).max()) < 3e-5, (H, W)
+    assert not dnn.Classifier([(128, 128, 1)] * 3, 3).x3_supported(128, 128)       # three float32 planes of that size do not fit
+    assert dnn.LABEL_GUARD_X3 >= 4 * max(worst.values())                              # the next stage's gap covers this stage's error
+    assert dnn.LABEL_GUARD_X6 >= 4 * max(worst6.values())
+
+
+def test_exact_features_in_one_call(rml):
+    """rml_dnn_exact_features (gather + exact projection + Pillow-exact resize + x3 / x6 trunk in one library call) against the same
+    steps one by one: the same bits; float32 and uint8 volumes, a row list with repeats and out of order, no row list."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    nc = importlib.import_module("radar_ml_amd.nn_common")
+    torch.manual_seed(12)
+    model = dnn.define_classifier(device="cuda").eval()
+    for grid in ((22, 31, 176), (16, 16, 32)):
+        V, _ = rml.synth_volumes(96, *grid, seed=23)
+        rows = torch.tensor([5, 0, 95, 5, 17, 64, 33], device="cuda")
+        for vol in (V, V.to(torch.uint8)):
+            for parts in (2, 3):
+                feat = rml.process_volumes(vol[rows], mode="max", scale=False)
+                xs = nc.preprocess_features(feat, grid, (80, 80), out_dtype="float32")
+                want = model.features_x3(*xs, parts=parts)
+                got = model.exact_features(vol, rows, parts=parts)
+                assert torch.equal(got, want), (grid, vol.dtype, parts)
+        feat = rml.process_volumes(V, mode="max", scale=False)
+        want = model.features_x3(*nc.preprocess_features(feat, grid, (80, 80), out_dtype="float32"))
+        assert torch.equal(model.exact_features(V), want)
+    # rescore_exact: sparse rows (the fused call), dense rows (whole blocks projected, rows picked) and all rows agree -- the features
+    # bit for bit (above), the probabilities to float32 round-off (hipBLASLt picks the dense layers' kernel by the row count)
+    V, _ = rml.synth_volumes(300, 22, 31, 176, seed=29)
+    allp = model.rescore_exact(V, precision="x3")
+    sparse = torch.tensor([299, 3, 150, 7], device="cuda")
+    assert float((model.rescore_exact(V, precision="x3", rows=sparse) - allp[sparse]).abs().max()) < 2e-6
+    dense = torch.randperm(300, device="cuda")[:200]
+    assert float((model.rescore_exact(V, precision="x3", rows=dense) - allp[dense]).abs().max()) < 2e-6
+    assert model.exact_features(V, rows=torch.zeros((0,), dtype=torch.int64, device="cuda")).shape == (0, 38400)
+
+
+def test_margin_guard_ignores_the_training_flag(rml):
+    """define_classifier returns a module in train mode (as nn.Module does); predict_volumes must not depend on it: the fused
+    chain has no dropout, and the guard's re-scoring applies none either (round 5's float32 stage went through self.drop)."""
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    torch.manual_seed(9)
+    model = dnn.define_classifier(device="cuda")
+    assert model.training
+    V, _ = rml.synth_volumes(512, 22, 31, 176, seed=17)
+    a = model.predict_volumes(V)
+    ga = dict(model.last_guard)
+    b = model.predict_volumes(V)                       # deterministic: no dropout mask anywhere
+    assert torch.equal(a, b)
+    model.eval()
+    c = model.predict_volumes(V)
+    assert torch.equal(a, c) and model.last_guard["rescored"] >= ga["rescored"]
+    assert ga["rescored"] > 0 and ga["observed_error"] < DNN_BF16_RANDOM_INIT_TOL   # an error, not a dropout mask's 1e-1
+
+
 def test_dnn_full_size_batch_size_independent_properties(rml):
     """BASELINE configs[3] at its stated per-GPU size -- 32 768 frames of the Walabot arena grid through
     Classifier.predict_volumes (projection -> [-1,1] scaling + bicubic resize -> fused bf16 trunk -> dense tail) -- by
@@ -246,6 +354,8 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
 # init and 3.4e-3 on the trained model; the tolerances are ~2x the measured worst, not the 3e-2 of round 2
 DNN_BF16_PROBA_TOL = 8e-3            # trained model (outputs away from 1/3): measured 3.4e-3
 DNN_BF16_RANDOM_INIT_TOL = 1e-3      # random-init weights: measured 1.6e-4 ... 4.8e-4 over the three chains
+DNN_X3_PROBA_TOL = 1e-5              # csrc/dnn_x3.hip + float32 dense layers against float64 (test_x3_trunk_is_float32_class prints it)
+DNN_X6_PROBA_TOL = 2e-6              # the same with three bf16 parts per operand
 
 
 def test_sgan_step_fp16_tracks_fp32(rml):
