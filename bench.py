@@ -177,16 +177,9 @@ def run_workload(a, env, grid, frames, primary):
     V = Vall[:B]
 
     def with_rmw(flag, fn):
-        """fn() with RML_CODE_RMW forced (the library reads it per call) -- the with / without pair of a read-compare-write row"""
-        old = os.environ.get("RML_CODE_RMW")
-        os.environ["RML_CODE_RMW"] = flag
-        try:
+        """fn() with RML_OPT_CODE_RMW forced on this rank's context -- the with / without pair of a read-compare-write row"""
+        with _lib.options(dev, code_rmw=int(flag)):
             return fn()
-        finally:
-            if old is None:
-                os.environ.pop("RML_CODE_RMW", None)
-            else:
-                os.environ["RML_CODE_RMW"] = old
     lib = _lib.load()
     ctx = _lib.context(dev)
     from radar_ml_amd import dist as rdist
@@ -281,7 +274,7 @@ def run_workload(a, env, grid, frames, primary):
               "read_compare_write": {"on_by_default": bool(lib.rml_code_rmw_default(D, X * Y * Z, 0, 1)),
                                      "value_with_plain_stores": round(world * B * a.steps / dt8_plain, 1),
                                      "gain": round(dt8_plain / dt8 - 1.0, 4),
-                                     "note": "same steps with RML_CODE_RMW=0; sliding windows: no row meets its own frame's old codes"},
+                                     "note": "same steps with RML_OPT_CODE_RMW = 0; sliding windows: no row meets its own frame's old codes"},
               "identical_to_f32_ingest": same, "labels_identical": lab_same, "dec_ovo_max_abs_diff_vs_f32_ingest": dec_diff,
               "hbm_frac_end_to_end": round(B * a.steps / dt8 * (X * Y * Z + 16) / 1e9 / HBM_PEAK_GBS, 4),
               "roofline": {"bound": "hbm", "kernel": "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>",
@@ -358,7 +351,7 @@ def run_workload(a, env, grid, frames, primary):
                 slice_rows[key]["read_compare_write"] = {"on_by_default": bool(lib.rml_code_rmw_default(D, frame_bytes, 1, 0)),
                                                          "value_with_plain_stores": round(world * B * a.steps / plain, 1),
                                                          "gain": round(plain / dt_s - 1.0, 4),
-                                                         "note": "same steps with RML_CODE_RMW=0; every step takes a window %d frames further on" % SLIDE}
+                                                         "note": "same steps with RML_OPT_CODE_RMW = 0; every step takes a window %d frames further on" % SLIDE}
         if "ijk" in slice_rows["derive_slice_svm"]["_out"]:
             slice_rows["derive_slice_svm"]["ijk_equal_rml_derive_targets"] = bool(
                 torch.equal(slice_rows["derive_slice_svm"]["_out"]["ijk"], ijk_dev))
@@ -390,9 +383,9 @@ def run_workload(a, env, grid, frames, primary):
     traffic = None          # filled in by main() from this run's own PMC passes (tools/bench_support.measure_traffic)
     zq = Z // 4
     rpl = 1 if 32 < zq <= 64 else (64 // zq if zq in (16, 32) and Y % (64 // zq) == 0 else 0)
-    wave = os.environ.get("RML_WAVEFRAME", "1") != "0" and rpl > 0 and Y // rpl <= 32      # wave_kernel_wanted(share_cu) of csrc/project.hip
+    wave = _lib.get_option("waveframe", dev) != 0 and rpl > 0 and Y // rpl <= 32      # wave_kernel_wanted(share_cu) of csrc/project.hip
     kname = "k_project_wave" if wave else ("k_project_fast" if zq & (zq - 1) == 0 else "k_project_rowgroup")
-    if wave and ((zq == 44 and 16 < Y <= 32) or (zq in (40, 48, 56) and 8 < Y <= 32)) and os.environ.get("RML_LINPLANE", "1") != "0":
+    if wave and ((zq == 44 and 16 < Y <= 32) or (zq in (40, 48, 56) and 8 < Y <= 32)) and _lib.get_option("linplane", dev) != 0:
         kname = "k_project_lin"                          # try_launch_lin of csrc/project_lin.hip
     if a.ingest == "u8":
         kname = "k_project_u8_max" if Z % 16 == 0 else "k_project_fast<uint8>"
@@ -810,6 +803,21 @@ def run_dnn(a, env):
     torch.cuda.synchronize(dev)
     exact_dt = time.perf_counter() - t0
     exact_dp = float((pe - res["f32_noguard"][1]).abs().max())
+    # the guard's worst case: untrained weights of the same architecture -- outputs ~1/3 each, nearly every row inside the gap, so
+    # nearly every row is scored twice (bf16 chain, then the float32-class trunk on exact inputs)
+    torch.manual_seed(a.seed + 3)
+    rmodel = dnn.define_classifier(device=dev).eval()
+    for _ in range(2):
+        rp = rmodel.predict_volumes(V)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rp = rmodel.predict_volumes(V)
+    torch.cuda.synchronize(dev)
+    rdt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rdt, op=dist.ReduceOp.MAX)
+    rguard = dict(rmodel.last_guard)
     if rank != 0:
         return None
     # parity on a few frames: NumPy restatement of the whole chain (oracle projections, Pillow restatement, Keras layers)
@@ -824,6 +832,9 @@ def run_dnn(a, env):
     convs, dense = model.keras_weights()
     want = O.dnn_forward(np.stack(planes[0]), np.stack(planes[1]), np.stack(planes[2]), convs, dense)
     got = res["f32"][1][:npar].float().cpu().numpy()
+    nrp = int(min(256, npar))
+    rwant = O.dnn_forward(np.stack(planes[0][:nrp]), np.stack(planes[1][:nrp]), np.stack(planes[2][:nrp]), *rmodel.keras_weights())
+    rgot = rp[:nrp].float().cpu().numpy()
     # roofline of the dominant kernel of this row, k_dnn_trunk_rf (bf16 MFMA): the event pairs recorded around EVERY trunk launch of
     # the timed steps above, on the stream it runs on (round 3 timed 13 launches after seconds of host-only oracle work: the chip
     # had clocked down, and the line disagreed with the rocprofv3 summary by 30 %); full batches only
@@ -849,11 +860,20 @@ def run_dnn(a, env):
                         "algorithmic_flop_per_frame": conv_flop, "traffic": None},
            # the margin guard (Classifier.predict_volumes: rows whose top-2 gap is below dnn.LABEL_GUARD are scored again in float64)
            "margin_guard": {"gap_initial": dnn.LABEL_GUARD, "gap_used": guard["f32"].get("gap"), "observed_bf16_error": guard["f32"].get("observed_error"),
-                            "gap_float32": dnn.LABEL_GUARD_F32, "rows": guard["f32"]["rows"], "rescored": guard["f32"]["rescored"],
-                            "rescored_float64": guard["f32"]["rescored_float64"],
+                            "stages": "bf16 chain -> x3 (bf16 operand pairs, csrc/dnn_x3.hip) below the gap -> x6 (triples) below %g -> float64 below %g"
+                                      % (dnn.LABEL_GUARD_X3, dnn.LABEL_GUARD_X6),
+                            "rows": guard["f32"]["rows"], "rescored": guard["f32"]["rescored"], "rescored_x6": guard["f32"].get("rescored_x6"),
+                            "rescored_float64": guard["f32"]["rescored_float64"], "observed_x3_error": guard["f32"].get("observed_error_x3"),
+                            "rounds": guard["f32"].get("rounds"), "covered": guard["f32"].get("covered"),
                             "value_without_guard": round(world * B * a.steps / res["f32_noguard"][0], 1),
                             "cost_frac": round(res["f32"][0] / res["f32_noguard"][0] - 1.0, 4),
                             "label_mismatch_without_guard": int((res["f32_noguard"][1][:npar].float().cpu().numpy().argmax(1) != want.argmax(1)).sum())},
+           "random_init": {"value": round(world * B * a.steps / float(rdt.item()), 1), "unit": "frames/s",
+                           "note": "untrained weights (outputs ~1/3 each): the guard's worst case, nearly every row scored twice",
+                           "rescored": rguard["rescored"], "rescored_x6": rguard.get("rescored_x6"), "rescored_float64": rguard["rescored_float64"],
+                           "rows": rguard["rows"], "observed_bf16_error": rguard.get("observed_error"),
+                           "parity": {"frames": nrp, "label_mismatch": int((rgot.argmax(1) != rwant.argmax(1)).sum()),
+                                      "proba_max_abs_err_vs_float64_oracle": float(np.abs(rgot - rwant).max())}},
            "parity": {"frames": npar, "proba_max_abs_err_vs_float64_oracle": float(np.abs(got - want).max()),
                       "label_mismatch": int((got.argmax(1) != want.argmax(1)).sum()),
                       "rows_inside_the_guard_gap": int((_top2_margin(want) <= dnn.LABEL_GUARD).sum()),
@@ -1197,7 +1217,11 @@ def main():
             dp = dnn_row["parity"]
             if dp["label_mismatch"] != 0:
                 fails.append("dnn.label_mismatch=%d" % dp["label_mismatch"])
+            ri = dnn_row["random_init"]
+            if ri["parity"]["label_mismatch"] != 0:
+                fails.append("dnn.random_init.label_mismatch=%d" % ri["parity"]["label_mismatch"])
             summ["dnn_configs3"] = {"v": dnn_row["value"], "v_u8": dnn_row["value_uint8_volumes"], "mfma": dnn_row["roofline"]["frac"],
+                                    "random_init_v": ri["value"], "random_init_rescored": ri["rescored"],
                                     "par": [dp["frames"], dp["label_mismatch"], float("%.2g" % dp["proba_max_abs_err_vs_float64_oracle"])],
                                     "guard": [dnn_row["margin_guard"]["rescored"], dnn_row["margin_guard"]["rescored_float64"], dnn_row["margin_guard"]["rows"],
                                               dnn_row["margin_guard"]["cost_frac"]]}

@@ -102,12 +102,42 @@ int rml_ctx_create(int device, rml_ctx** out);
 int rml_ctx_destroy(rml_ctx* ctx);
 int rml_ctx_device(const rml_ctx* ctx);
 
-/* Context options.  RML_OPT_PROJECT_SHARE_CU (0 / 1, default 0): the stand-alone projection entry points (rml_project,
- * rml_project_planes, rml_project_slices) launch their persistent kernels the way the fused pipeline does beside its GEMM --
- * one workgroup per CU with a padded LDS request -- so that a kernel the caller runs on ANOTHER stream (the CNN path runs the
- * bicubic resize of batch b beside the projection of batch b+1: radar-ml_amd/dnn.py) finds room on every CU.  Same results. */
+/* Context options (rml_ctx_set_option / rml_ctx_get_option).  The defaults are the tuned configuration and give the documented
+ * results; every other value gives THE SAME RESULTS through another kernel family or schedule -- they exist for A/B measurements and
+ * for the tests that pin one family against another.  (Until round 5 these were environment variables read inside the launch paths.)
+ *   RML_OPT_PROJECT_SHARE_CU (0 / 1, default 0): the stand-alone projection entry points launch their persistent kernels the way
+ *     the fused pipeline does beside its GEMM -- one workgroup per CU with a padded LDS request -- so that a kernel the caller runs on
+ *     ANOTHER stream finds room on every CU.
+ *   RML_OPT_WAVEFRAME (default 1): wave-per-frame projection kernels; 0 off, 2 quarter-plane buffers everywhere, 3 also for short rows
+ *     stand-alone.          RML_OPT_LINPLANE (default 1): the linear-plane kernel for rows of 40 / 44 / 48 / 56 quads.
+ *   RML_OPT_STAGE_CODES (default 1): per-wave LDS stage of the code rows.   RML_OPT_SLICE_WAVE (default 1): wave-per-row slice kernel.
+ *   RML_OPT_DERIVE_FUSED (default 1): one-pass derive -> slice kernel (0: rml_derive_slice runs sum planes + top-k + slices, and
+ *     rml_derive_project_svm returns RML_ERR_UNSUPPORTED).
+ *   RML_OPT_CODE_RMW (default -1 = the measured rule, rml_code_rmw_default; 0 / 1 forced): read-compare-write code-row stores.
+ *   RML_OPT_GEMM_BIG (default -1 = the whole-round rule; 0 never, 1 for every chunk of >= 256 rows): 256 x 256 ring GEMM.
+ *   RML_OPT_CHUNK (default 0 = chosen per batch): rows per chunk of the chunked front doors (>= 128; rounded up to 128).
+ *   RML_OPT_C1_PK (default 1): packed first-layer kernels of the SGAN branches. */
 #define RML_OPT_PROJECT_SHARE_CU 1
+#define RML_OPT_WAVEFRAME 2
+#define RML_OPT_LINPLANE 3
+#define RML_OPT_STAGE_CODES 4
+#define RML_OPT_SLICE_WAVE 5
+#define RML_OPT_DERIVE_FUSED 6
+#define RML_OPT_CODE_RMW 7
+#define RML_OPT_GEMM_BIG 8
+#define RML_OPT_CHUNK 9
+#define RML_OPT_C1_PK 10
 int rml_ctx_set_option(rml_ctx* ctx, int option, int value);
+int rml_ctx_get_option(const rml_ctx* ctx, int option, int* value);
+
+/* The context's workspace (the chunk buffers of rml_project_svm / rml_svm_decision / rml_derive_targets ...) grows on demand: the
+ * first call that needs more than any call before it allocates a bigger block with hipMalloc (the outgrown one is released once the
+ * work queued before is done) -- a host-side allocation, not capturable into a HIP graph and possibly synchronising.  Every other
+ * call is asynchronous on the caller's stream.  rml_ctx_reserve_workspace(ctx, bytes) does the growth up front (and releases
+ * outgrown blocks; it synchronises the device); a warm-up call of the same shape does the same.  A call that would have to grow
+ * the workspace while its stream is being captured fails with RML_ERR_INVALID and says so. */
+int rml_ctx_reserve_workspace(rml_ctx* ctx, int64_t bytes);
+int64_t rml_ctx_workspace_bytes(const rml_ctx* ctx);
 
 /* In-situ timing of the projection launches issued by rml_project_svm (bench.py's roofline line):
  * while enabled, a hipEvent pair is recorded around every projection launch on the stream it is
@@ -127,7 +157,7 @@ int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, int reps, dou
 
 /* 1 when the fused pipelines store a frame's code row read-compare-write (read the old words, store what changed) for frames of
  * frame_bytes volume bytes and D codes, 0 for plain stores (the rule and its measurements: csrc/rml_internal.h rml_code_rmw;
- * RML_CODE_RMW=0/1 in the environment overrides it).  Reporting only: bench.py prints it beside the with/without pair. */
+ * RML_OPT_CODE_RMW overrides it per context).  Reporting only: bench.py prints it beside the with/without pair. */
 int rml_code_rmw_default(int64_t D, int64_t frame_bytes, int derive, int u8);
 
 /* Feature-row length for a grid and mask: X*Z + Y*Z + X*Y over the selected planes
@@ -195,13 +225,13 @@ int rml_derive_targets(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
  *   feat, feat_q, row_*   B*num_targets rows, as rml_project
  * Shapes without the fused kernel (rows that are not whole 16-byte quads, Z > 256, odd part of Z/4 above 15, a misaligned V)
  * run rml_derive_targets + rml_project_slices internally.  rml_derive_slice_supported: 1 when the one-pass kernel takes the
- * shape (V may be NULL: alignment not checked). */
+ * shape on this context (ctx may be NULL: default options; V may be NULL: alignment not checked). */
 int rml_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,
                      int32_t* ijk, float* profiles, float scale_div, uint32_t mask,
                      float* feat, int64_t ld_feat,
                      uint8_t* feat_q, int64_t ld_q, int32_t* row_isum, int64_t* row_isq, int32_t* row_flags,
                      void* stream);
-int rml_derive_slice_supported(const void* V, int vdtype, int X, int Y, int Z, int num_targets);
+int rml_derive_slice_supported(const rml_ctx* ctx, const void* V, int vdtype, int X, int Y, int Z, int num_targets);
 
 /* Assemble feature rows from already separate projection planes (the list-of-tuples
  * input of common.process_samples, common.py:123-149, stacked per plane), zoom 1.
@@ -306,7 +336,7 @@ int rml_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, i
 /* The same front door for the reference-faithful projection with DERIVED targets: per frame the strongest derived target
  * (common.py:49-80, num_targets = 1), the three slices through it (predict.py:98-107) and the SVM outputs, the frame read once
  * (+ 4*D bytes for the slices).  ijk_out: B*3 int32 or NULL (the derived indices).  RML_ERR_UNSUPPORTED when
- * rml_derive_slice_supported(V, ...) is 0: call rml_derive_targets and rml_project_svm(RML_MODE_SLICE, ijk) then. */
+ * rml_derive_slice_supported(ctx, V, ...) is 0: call rml_derive_targets and rml_project_svm(RML_MODE_SLICE, ijk) then. */
 int rml_derive_project_svm(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, int64_t B, int X, int Y, int Z,
                            float scale_div, uint32_t mask, int32_t* ijk_out,
                            double* dec_ovo, double* dec_ovr, double* proba,

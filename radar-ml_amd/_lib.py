@@ -32,6 +32,9 @@ SIGNATURES = {
     "rml_ctx_destroy": (c_int, [c_void_p]),
     "rml_ctx_device": (c_int, [c_void_p]),
     "rml_ctx_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "rml_ctx_get_option": (c_int, [c_void_p, c_int, C.POINTER(c_int)]),
+    "rml_ctx_reserve_workspace": (c_int, [c_void_p, c_int64]),
+    "rml_ctx_workspace_bytes": (c_int64, [c_void_p]),
     "rml_profile_enable": (c_int, [c_void_p, c_int]),
     "rml_profile_read": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_int64)]),
     "rml_profile_read_gemm": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_double)]),
@@ -45,7 +48,7 @@ SIGNATURES = {
     "rml_derive_targets": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rml_derive_slice": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_uint32,
                                  c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rml_derive_slice_supported": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "rml_derive_slice_supported": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "rml_assemble_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                       c_uint32, c_void_p, c_int64, c_void_p]),
     "rml_zoom_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_float,
@@ -116,7 +119,16 @@ SIGNATURES = {
 }
 
 MODE_MAX, MODE_SLICE, MODE_SUM, MODE_MAX_NAN = 0, 1, 2, 3
-OPT_PROJECT_SHARE_CU = 1
+# rml_ctx_set_option ids (include/radarml.h RML_OPT_*)
+OPT_PROJECT_SHARE_CU, OPT_WAVEFRAME, OPT_LINPLANE, OPT_STAGE_CODES, OPT_SLICE_WAVE, OPT_DERIVE_FUSED, OPT_CODE_RMW, OPT_GEMM_BIG, OPT_CHUNK, OPT_C1_PK = range(1, 11)
+OPTIONS = {"project_share_cu": OPT_PROJECT_SHARE_CU, "waveframe": OPT_WAVEFRAME, "linplane": OPT_LINPLANE, "stage_codes": OPT_STAGE_CODES,
+           "slice_wave": OPT_SLICE_WAVE, "derive_fused": OPT_DERIVE_FUSED, "code_rmw": OPT_CODE_RMW, "gemm_big": OPT_GEMM_BIG,
+           "chunk": OPT_CHUNK, "c1_pk": OPT_C1_PK}
+# A/B runs from a shell (tools/profile_round.sh, tools/kbench.py under rocprofv3): these environment variables are read ONCE, here in
+# Python, when a context is created, and applied as options -- the library itself never reads the environment
+ENV_OPTIONS = {"RML_WAVE_SHARE": "project_share_cu", "RML_WAVEFRAME": "waveframe", "RML_LINPLANE": "linplane", "RML_STAGE_CODES": "stage_codes",
+               "RML_SLICE_WAVE": "slice_wave", "RML_DERIVE_FUSED": "derive_fused", "RML_CODE_RMW": "code_rmw", "RML_GEMM_BIG": "gemm_big",
+               "RML_CHUNK": "chunk", "RML_C1_PK": "c1_pk"}
 AUG_ROTATE, AUG_ZOOM, AUG_NOISE = 0, 1, 2
 VOL_F32, VOL_U8 = 0, 1
 MODES = {"max": MODE_MAX, "slice": MODE_SLICE, "sum": MODE_SUM, "max_nan": MODE_MAX_NAN}
@@ -180,11 +192,47 @@ def context(device=None):
         # create outside the lock (a failing rml_ctx_create must raise, not dead-lock: check() calls load())
         new = c_void_p()
         check(lib.rml_ctx_create(index, C.byref(new)), "rml_ctx_create")
+        for var, name in ENV_OPTIONS.items():
+            val = os.environ.get(var)
+            if val not in (None, ""):
+                check(lib.rml_ctx_set_option(new, OPTIONS[name], int(val)), "rml_ctx_set_option(%s from $%s)" % (name, var))
         with _lock:
             h = _ctx.setdefault(device, new)
         if h is not new:                    # another thread won the race
             lib.rml_ctx_destroy(new)
     return h
+
+
+def set_option(name, value, device=None):
+    """rml_ctx_set_option on the device's context; returns the previous value.  ``name``: a key of OPTIONS."""
+    lib, ctx = load(), context(device)
+    old = C.c_int()
+    check(lib.rml_ctx_get_option(ctx, OPTIONS[name], C.byref(old)), "rml_ctx_get_option")
+    check(lib.rml_ctx_set_option(ctx, OPTIONS[name], int(value)), "rml_ctx_set_option")
+    return old.value
+
+
+def get_option(name, device=None):
+    v = C.c_int()
+    check(load().rml_ctx_get_option(context(device), OPTIONS[name], C.byref(v)), "rml_ctx_get_option")
+    return v.value
+
+
+class options:
+    """``with _lib.options(gemm_big=0, chunk=4096): ...`` -- context options set for the block and restored after it."""
+
+    def __init__(self, device=None, **kv):
+        self.device, self.kv, self.old = device, kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = set_option(k, v, self.device)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v, self.device)
+        return False
 
 
 def device_of(device=None):

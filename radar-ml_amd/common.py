@@ -228,7 +228,7 @@ def process_volumes(volumes, mode="max", ijk=None, proj_mask=ProjMask(xz=True, y
             # over the volumes where the shape has the fused kernel (rml_derive_slice), two launches otherwise
             derived = True
             T = int(num_targets)
-            fused_derive = bool(lib.rml_derive_slice_supported(_lib.ptr(v), vdt, X, Y, Z, T))
+            fused_derive = bool(lib.rml_derive_slice_supported(_lib.context(v.device), _lib.ptr(v), vdt, X, Y, Z, T))
             if not fused_derive:
                 ijk = derive_targets(v, num_targets)
         if not fused_derive:

@@ -855,8 +855,7 @@ extern "C" int rml_conv1_bn_lrelu_pad_forward(rml_ctx* ctx, const void* image, c
                        save_mean, save_rstd, running_mean, running_var);
     const unsigned rows = (unsigned)(N * (H + pad_h));
     const unsigned ga = rows < (unsigned)(ctx->num_cu * 8) ? rows : (unsigned)(ctx->num_cu * 8);
-    const char* pke = getenv("RML_C1_PK");             // read per call: the tests flip it (0: the general kernels)
-    if ((!pke || atoi(pke) != 0) && C == 128 && (W == 16 || W == 32 || W == 64)) {
+    if (ctx->opt.c1_pk && C == 128 && (W == 16 || W == 32 || W == 64)) {
         auto go = [&](auto bf, auto nb) {
             constexpr bool BFV = decltype(bf)::value;
             constexpr int NBV = decltype(nb)::value;
@@ -895,9 +894,8 @@ extern "C" int rml_conv1_bn_lrelu_pad_backward(rml_ctx* ctx, const void* image, 
     const float* img = img_stats;
     // four channels per thread where the channel groups divide the workgroup (C = 128: 32 groups x 8 pixels)
     const bool four = C % 4 == 0 && kT % (C / 4) == 0 && C / 4 <= kT;
-    // C = 128 and rows of 16 / 32 / 64 pixels: the packed kernel (RML_C1_PK=0: the general one)
-    const char* pke = getenv("RML_C1_PK");             // read per call: the tests flip it
-    const bool pk_on = !pke || atoi(pke) != 0;
+    // C = 128 and rows of 16 / 32 / 64 pixels: the packed kernel (RML_OPT_C1_PK = 0: the general one)
+    const bool pk_on = ctx->opt.c1_pk != 0;
     const bool pk = pk_on && C == 128 && (W == 16 || W == 32 || W == 64);
     if (pk) {
         // one round of resident workgroups (166 registers at W = 64: three per CU), rows strided over them

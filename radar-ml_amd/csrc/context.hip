@@ -21,32 +21,90 @@ int rml_hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return RML_ERR_HIP;
 }
 
-int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out) {
+// outgrown workspace blocks whose retirement point has passed (all of them when `all`: the caller has synchronised)
+static void ws_release_retired(rml_ctx* ctx, bool all) {
+    size_t k = 0;
+    for (size_t i = 0; i < ctx->ws_retired.size(); ++i) {
+        rml_ws_retired& r = ctx->ws_retired[i];
+        if (all || hipEventQuery(r.ev) == hipSuccess) {
+            (void)hipFree(r.p);
+            (void)hipEventDestroy(r.ev);
+        } else {
+            ctx->ws_retired[k++] = r;
+        }
+    }
+    (void)hipGetLastError();            // hipErrorNotReady of a pending event is not an error
+    ctx->ws_retired.resize(k);
+}
+
+static int ws_grow(rml_ctx* ctx, size_t bytes, hipStream_t st, bool retire_on_stream) {
+    void* nw = nullptr;
+    size_t want = bytes + (bytes >> 3);
+    hipError_t e = hipMalloc(&nw, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ws_release_retired(ctx, false);
+        want = bytes;
+        e = hipMalloc(&nw, want);
+    }
+    if (e != hipSuccess) {
+        rml_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return RML_ERR_NOMEM;
+    }
+    if (ctx->ws) {
+        // The old block may still be in use by work queued before this call.  Every user ran under rml_ctx_guard and this call's
+        // stream already waits for the last of them (ev_last), so an event recorded on it NOW completes after all of them: the block
+        // is parked behind that event and freed when a later growth (or rml_ctx_reserve_workspace / rml_ctx_destroy) finds it done.
+        // No hipDeviceSynchronize, no hipFree on this path (round 5 did both here, inside "asynchronous" entry points).
+        rml_ws_retired r{ctx->ws, nullptr};
+        if (retire_on_stream && hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(r.ev, st) == hipSuccess) {
+            ctx->ws_retired.push_back(r);
+        } else {
+            (void)hipGetLastError();
+            if (r.ev) (void)hipEventDestroy(r.ev);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ctx->ws);
+        }
+    }
+    ctx->ws = nw;
+    ctx->ws_bytes = want;
+    return RML_OK;
+}
+
+int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out, hipStream_t st) {
     if (bytes > ctx->ws_bytes) {
-        if (ctx->ws) {
-            // the old block may still be in use by queued work on any stream
-            RML_HIP(hipDeviceSynchronize());
-            RML_HIP(hipFree(ctx->ws));
-            ctx->ws = nullptr;
-            ctx->ws_bytes = 0;
-        }
-        size_t want = bytes + (bytes >> 3);
-        hipError_t e = hipMalloc(&ctx->ws, want);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            want = bytes;
-            e = hipMalloc(&ctx->ws, want);
-        }
-        if (e != hipSuccess) {
-            rml_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-            (void)hipGetLastError();
-            return RML_ERR_NOMEM;
-        }
-        ctx->ws_bytes = want;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        RML_REQUIRE(cs == hipStreamCaptureStatusNone, RML_ERR_INVALID,
+                    "the context's workspace would have to grow from %zu to %zu bytes inside a stream capture: call rml_ctx_reserve_workspace "
+                    "(or run the same call once) before capturing", ctx->ws_bytes, bytes);
+        ws_release_retired(ctx, false);
+        const int rc = ws_grow(ctx, bytes, st, true);
+        if (rc) return rc;
     }
     *out = ctx->ws;
     return RML_OK;
 }
+
+extern "C" int rml_ctx_reserve_workspace(rml_ctx* ctx, int64_t bytes) {
+    RML_REQUIRE(ctx != nullptr && bytes >= 0, RML_ERR_INVALID, "rml_ctx_reserve_workspace: bad arguments");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    int prev = -1;
+    RML_HIP(hipGetDevice(&prev));
+    RML_HIP(hipSetDevice(ctx->device));
+    RML_HIP(hipDeviceSynchronize());
+    ws_release_retired(ctx, true);
+    int rc = RML_OK;
+    if ((size_t)bytes > ctx->ws_bytes) {
+        if (ctx->ws) { (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+        rc = ws_grow(ctx, (size_t)bytes, nullptr, false);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int64_t rml_ctx_workspace_bytes(const rml_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes : 0; }
 
 extern "C" const char* rml_version(void) { return "radarml-hip 0.1 (gfx950)"; }
 extern "C" const char* rml_last_error(void) { return g_err; }
@@ -57,6 +115,12 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
     int n = 0;
     RML_HIP(hipGetDeviceCount(&n));
     RML_REQUIRE(device >= 0 && device < n, RML_ERR_INVALID, "rml_ctx_create: device %d out of range (%d devices)", device, n);
+    // the caller's current device is the caller's: streams and events are created on `device` and the previous one is restored
+    struct restore_device {
+        int prev = -1;
+        restore_device() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+        ~restore_device() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } restore;
     RML_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     RML_HIP(hipGetDeviceProperties(&prop, device));
@@ -84,8 +148,11 @@ extern "C" int rml_ctx_create(int device, rml_ctx** out) {
 
 extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     if (!ctx) return RML_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    ws_release_retired(ctx, true);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -100,11 +167,19 @@ extern "C" int rml_ctx_destroy(rml_ctx* ctx) {
     for (const rml_pre_tab& t : ctx->pre_tabs) (void)hipFree(t.dev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
+    if (prev >= 0) (void)hipSetDevice(prev);
     return RML_OK;
 }
 
+// (timing events are not recorded into a stream capture: they could not be read back)
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+    return cs != hipStreamCaptureStatusNone;
+}
+
 void rml_prof_mark(rml_ctx* ctx, hipStream_t st) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || stream_is_capturing(st)) return;
     if (ctx->prof_used == ctx->prof_ev.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -114,7 +189,7 @@ void rml_prof_mark(rml_ctx* ctx, hipStream_t st) {
 }
 
 void rml_prof_mark_gemm(rml_ctx* ctx, hipStream_t st) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || stream_is_capturing(st)) return;
     if (ctx->prof_used_g == ctx->prof_ev_g.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -125,6 +200,7 @@ void rml_prof_mark_gemm(rml_ctx* ctx, hipStream_t st) {
 
 extern "C" int rml_profile_read_gemm(rml_ctx* ctx, int64_t* launches, double* total_ms, double* ops) {
     RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_read_gemm: ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);          // the marks are recorded by guarded entry points: the same lock
     RML_HIP(hipSetDevice(ctx->device));
     double tot = 0.0;
     int64_t n = 0;
@@ -145,6 +221,7 @@ extern "C" int rml_profile_read_gemm(rml_ctx* ctx, int64_t* launches, double* to
 
 extern "C" int rml_profile_enable(rml_ctx* ctx, int on) {
     RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_enable: ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->profiling = on != 0;
     ctx->prof_used = 0;
     ctx->prof_frames = 0;
@@ -155,6 +232,7 @@ extern "C" int rml_profile_enable(rml_ctx* ctx, int on) {
 
 extern "C" int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_ms, int64_t* frames) {
     RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_profile_read: ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RML_HIP(hipSetDevice(ctx->device));
     double tot = 0.0;
     int64_t n = 0;
@@ -175,13 +253,48 @@ extern "C" int rml_profile_read(rml_ctx* ctx, int64_t* launches, double* total_m
 
 extern "C" int rml_ctx_device(const rml_ctx* ctx) { return ctx ? ctx->device : RML_ERR_INVALID; }
 
+static int* opt_slot(rml_opts& o, int option) {
+    switch (option) {
+        case RML_OPT_PROJECT_SHARE_CU: return &o.project_share_cu;
+        case RML_OPT_WAVEFRAME: return &o.waveframe;
+        case RML_OPT_LINPLANE: return &o.linplane;
+        case RML_OPT_STAGE_CODES: return &o.stage_codes;
+        case RML_OPT_SLICE_WAVE: return &o.slice_wave;
+        case RML_OPT_DERIVE_FUSED: return &o.derive_fused;
+        case RML_OPT_CODE_RMW: return &o.code_rmw;
+        case RML_OPT_GEMM_BIG: return &o.gemm_big;
+        case RML_OPT_C1_PK: return &o.c1_pk;
+        default: return nullptr;
+    }
+}
+
 extern "C" int rml_ctx_set_option(rml_ctx* ctx, int option, int value) {
     RML_REQUIRE(ctx != nullptr, RML_ERR_INVALID, "rml_ctx_set_option: ctx is NULL");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    switch (option) {
-        case RML_OPT_PROJECT_SHARE_CU: ctx->opt_project_share_cu = value ? 1 : 0; return RML_OK;
-        default: RML_REQUIRE(false, RML_ERR_INVALID, "rml_ctx_set_option: unknown option %d", option);
+    if (option == RML_OPT_CHUNK) {
+        RML_REQUIRE(value == 0 || value >= 128, RML_ERR_INVALID, "rml_ctx_set_option: RML_OPT_CHUNK is 0 (automatic) or >= 128 rows");
+        ctx->opt.chunk = value;
+        return RML_OK;
     }
+    int* slot = opt_slot(ctx->opt, option);
+    RML_REQUIRE(slot != nullptr, RML_ERR_INVALID, "rml_ctx_set_option: unknown option %d", option);
+    switch (option) {
+        case RML_OPT_WAVEFRAME: RML_REQUIRE(value >= 0 && value <= 3, RML_ERR_INVALID, "rml_ctx_set_option: RML_OPT_WAVEFRAME is 0..3"); *slot = value; break;
+        case RML_OPT_CODE_RMW: case RML_OPT_GEMM_BIG: *slot = value < 0 ? -1 : (value ? 1 : 0); break;
+        default: *slot = value ? 1 : 0;
+    }
+    return RML_OK;
+}
+
+extern "C" int rml_ctx_get_option(const rml_ctx* ctx, int option, int* value) {
+    RML_REQUIRE(ctx != nullptr && value != nullptr, RML_ERR_INVALID, "rml_ctx_get_option: NULL argument");
+    rml_ctx* c = const_cast<rml_ctx*>(ctx);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (option == RML_OPT_CHUNK) { *value = (int)c->opt.chunk; return RML_OK; }
+    const int* slot = opt_slot(c->opt, option);
+    RML_REQUIRE(slot != nullptr, RML_ERR_INVALID, "rml_ctx_get_option: unknown option %d", option);
+    *value = *slot;
+    return RML_OK;
 }
 
 // ---- rml_probe_stream: what a pure streaming READ reaches on this device ------------------------------------------------------------
@@ -220,20 +333,25 @@ extern "C" int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     rml_ctx_guard guard(ctx, st);           // a workspace user like the others: serialised on the context
     void* sink = nullptr;
-    int rc = rml_ws_reserve(ctx, (size_t)4 * 2 * ctx->num_cu, &sink);
+    int rc = rml_ws_reserve(ctx, (size_t)4 * 2 * ctx->num_cu, &sink, st);
     if (rc) return rc;
     const int64_t n16 = bytes / 16;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     RML_HIP(hipEventCreate(&e0));
-    RML_HIP(hipEventCreate(&e1));
+    {
+        const hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) { (void)hipEventDestroy(e0); RML_HIP(ec); }
+    }
     const dim3 grid((unsigned)(2 * ctx->num_cu)), block(256);
     for (int i = 0; i < 2; ++i)
         hipLaunchKernelGGL(k_probe_stream, grid, block, 0, st, static_cast<const probe_v4*>(buf), n16, static_cast<float*>(sink));
-    (void)hipEventRecord(e0, st);
-    for (int i = 0; i < reps; ++i)
+    hipError_t e = hipGetLastError();                       // a failed warm-up launch shows here, before anything is timed
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int i = 0; i < reps && e == hipSuccess; ++i)
         hipLaunchKernelGGL(k_probe_stream, grid, block, 0, st, static_cast<const probe_v4*>(buf), n16, static_cast<float*>(sink));
-    (void)hipEventRecord(e1, st);
-    hipError_t e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0);
@@ -244,7 +362,7 @@ extern "C" int rml_probe_stream(rml_ctx* ctx, const void* buf, int64_t bytes, in
     return RML_OK;
 }
 
-// the pipelines' default for read-compare-write code stores (rml_internal.h rml_code_rmw; honours RML_CODE_RMW): bench.py reports it
+// the pipelines' default for read-compare-write code stores (rml_internal.h rml_code_rmw; RML_OPT_CODE_RMW overrides it per context): bench.py reports it
 extern "C" int rml_code_rmw_default(int64_t D, int64_t frame_bytes, int derive, int u8) {
     return rml_code_rmw(D, frame_bytes, derive != 0, u8 != 0);
 }

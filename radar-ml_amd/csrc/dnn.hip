@@ -104,9 +104,6 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
     const int br = blockIdx.y;
     const TrunkLayout L(H, W, SR, MT);
     const int RS = L.RS;
-#ifdef RML_DNN_TIMING
-    const unsigned long long tentry = __builtin_readcyclecounter();
-#endif
 
     uint16_t* in_s = reinterpret_cast<uint16_t*>(smem);          // [H+5][W+2] bf16: plane + zero pad
     unsigned char* c1_s = smem + L.off_c1;                       // [R1][OW1+1] pixels x 144 B (+ 1 dummy pixel)
@@ -210,10 +207,6 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
     }
     const int NT1 = L.nt1;
 
-#ifdef RML_DNN_TIMING
-    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0_, t1_, t2_, t3_, t4_;
-    const unsigned long long tstart = __builtin_readcyclecounter();
-#endif
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     // 1. the plane as bf16 into LDS (every wave is past the conv1 of the previous sample: barriers in between)
     if (prefetch) {
@@ -232,9 +225,6 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
     }
     for (int r0 = 0; r0 < OH2; r0 += SR) {
         lds_barrier();                      // previous strip stored, the plane is in place
-#ifdef RML_DNN_TIMING
-        t0_ = __builtin_readcyclecounter();
-#endif
         // 2. conv1 + bias + relu -> bf16 image.  conv1 rows past the bottom edge are 'same' zeros: their pixels go to
         //    the dummy slot and the rows are cleared here (only ever in the last strip).
         const int live = OH1 - 2 * r0;      // conv1 rows of this strip that exist
@@ -282,13 +272,7 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
                 }
             }
         }
-#ifdef RML_DNN_TIMING
-        t1_ = __builtin_readcyclecounter();
-#endif
         lds_barrier();
-#ifdef RML_DNN_TIMING
-        t2_ = __builtin_readcyclecounter();
-#endif
         // 3. conv2 as implicit GEMM: wave = (K half kh, channel tile nt), all MT pixel tiles (tiles past the strip
         //    recompute its last pixel and are dropped in the epilogue: no divergent loads in the MFMA loop)
         f32x4 acc[MT];
@@ -320,9 +304,6 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
-#ifdef RML_DNN_TIMING
-        t3_ = __builtin_readcyclecounter();
-#endif
         // K-split reduction, both halves busy: the kh=0 wave finishes pixel tiles 0..MS-1, the kh=1 wave the rest;
         // each hands the other its partials of the tiles it does not finish
         if (kh == 0) {
@@ -349,17 +330,8 @@ __global__ __launch_bounds__(256, WPC) void k_dnn_trunk(TrunkArgs a) {
                     *reinterpret_cast<uint2*>(dst0 + q * 96) = make_uint2(pk_relu(pk_bf16(s4[0], s4[1])), pk_relu(pk_bf16(s4[2], s4[3])));
             }
         }
-#ifdef RML_DNN_TIMING
-        t4_ = __builtin_readcyclecounter();
-        tA += t1_ - t0_; tB += t2_ - t1_; tC += t3_ - t2_; tD += t4_ - t3_;
-#endif
     }
     }
-#ifdef RML_DNN_TIMING
-    if (blockIdx.x == 100 && br == 0 && lane == 0)
-        printf("[dnn timing] wave %d: prologue %llu  conv1 %llu  barrier %llu  conv2 %llu  epilogue %llu  total %llu\n", wave,
-               (unsigned long long)(tstart - tentry), tA, tB, tC, tD, (unsigned long long)(__builtin_readcyclecounter() - tentry));
-#endif
 }
 
 template <int SR, bool INBF, int MT, bool PF, int WPC>
@@ -416,9 +388,6 @@ struct RfLayout {
     }
 };
 
-#ifndef RML_RF_ABL
-#define RML_RF_ABL 0        // experiment builds only: 2 = no convert/relu, 3 = no stores
-#endif
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 template <bool INBF>
@@ -540,12 +509,6 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
                     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct], w, z, 0, 0, 0);
                 };
                 auto cvt = [&](const f32x16& c, bf16x8& p0, bf16x8& p1) {
-#if RML_RF_ABL == 2
-                    uint4 v0 = make_uint4(__float_as_uint(c[0]), __float_as_uint(c[2]), __float_as_uint(c[4]), __float_as_uint(c[6]));
-                    uint4 v1 = make_uint4(__float_as_uint(c[8]), __float_as_uint(c[10]), __float_as_uint(c[12]), __float_as_uint(c[14]));
-                    p0 = *reinterpret_cast<bf16x8*>(&v0); p1 = *reinterpret_cast<bf16x8*>(&v1);
-                    return;
-#endif
                     uint4 u0 = make_uint4(pk_relu(pk_bf16(c[0], c[1])), pk_relu(pk_bf16(c[2], c[3])), pk_relu(pk_bf16(c[4], c[5])), pk_relu(pk_bf16(c[6], c[7])));
                     uint4 u1 = make_uint4(pk_relu(pk_bf16(c[8], c[9])), pk_relu(pk_bf16(c[10], c[11])), pk_relu(pk_bf16(c[12], c[13])), pk_relu(pk_bf16(c[14], c[15])));
                     p0 = *reinterpret_cast<bf16x8*>(&u0);
@@ -622,11 +585,7 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
                 const auto s01 = __builtin_amdgcn_permlane32_swap(d[1], d[5], false, false);
                 const auto s10 = __builtin_amdgcn_permlane32_swap(d[2], d[6], false, false);     // channels 8-11 | 24-27 <-> 12-15 | 28-31
                 const auto s11 = __builtin_amdgcn_permlane32_swap(d[3], d[7], false, false);
-#if RML_RF_ABL == 3
-                if (live && d[0] == 0x12345u) {
-#else
                 if (live) {
-#endif
                     *reinterpret_cast<uint4*>(dst) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
                     *reinterpret_cast<uint4*>(dst + 8) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
                 }

@@ -224,10 +224,7 @@ __global__ __launch_bounds__(256) void k_pre3(PreArgs a) {
         if (!mine) continue;
         lds_barrier();
 
-#ifndef RML_PRE3_ABL
-#define RML_PRE3_ABL 0      // experiment builds (timing only): 1 = no horizontal pass, 2 = no vertical pass arithmetic, 3 = no output stores
-#endif
-        if (hact && RML_PRE3_ABL != 1) {
+        if (hact) {
             // rows of [xz | yz] (length Z) and of xy (length Y) -> column hx of the intermediate, scaled to [-1, 1]
             float* tc = tmp + hx;
             int y = hg;
@@ -251,10 +248,6 @@ __global__ __launch_bounds__(256) void k_pre3(PreArgs a) {
             uint2* o8 = reinterpret_cast<uint2*>(a.out[p] + b * opl);
             int yy = tid / OW4, c4 = tid - yy * OW4;
             for (int r = tid; r < per; r += 256) {
-#if RML_PRE3_ABL == 2
-                o8[r] = make_uint2((uint32_t)r, (uint32_t)yy);
-                continue;
-#endif
                 const float4 w = *reinterpret_cast<const float4*>(wv + yy * VT);
                 const float* s = tp + fv[yy] * TW + 4 * c4;
                 const float4 v0 = *reinterpret_cast<const float4*>(s);
@@ -267,11 +260,7 @@ __global__ __launch_bounds__(256) void k_pre3(PreArgs a) {
                 lo = __builtin_elementwise_fma(f32x2{v1.x, v1.y}, w1, lo); hi = __builtin_elementwise_fma(f32x2{v1.z, v1.w}, w1, hi);
                 lo = __builtin_elementwise_fma(f32x2{v2.x, v2.y}, w2, lo); hi = __builtin_elementwise_fma(f32x2{v2.z, v2.w}, w2, hi);
                 lo = __builtin_elementwise_fma(f32x2{v3.x, v3.y}, w3, lo); hi = __builtin_elementwise_fma(f32x2{v3.z, v3.w}, w3, hi);
-#if RML_PRE3_ABL == 3
-                if (lo.x == 12345.678f) o8[r] = make_uint2(pk_bf16(lo.x, lo.y), pk_bf16(hi.x, hi.y));
-#else
                 o8[r] = make_uint2(pk_bf16(lo.x, lo.y), pk_bf16(hi.x, hi.y));
-#endif
                 yy += vdq; c4 += vdr;
                 if (c4 >= OW4) { c4 -= OW4; ++yy; }
             }

@@ -248,9 +248,6 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
 // ------------------------------------------------------------------------------------------
 template <typename VT, int MODE, int NY, int G, bool PRED>
 __global__ __launch_bounds__(256, (NY + 2 * G) * 4 + 40 > 256 ? 1 : 2) void k_project_wave(ProjParams a) {
-#ifdef RML_PRIO_PROJ
-    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
-#endif
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     constexpr int NG = (NY + G - 1) / G;                // row groups per plane
     static_assert(NG == 1 || NG % 2 == 0, "the two row buffers must alternate statically");
@@ -432,14 +429,12 @@ int wave_kernel_rpl(int ZQ, int Y) {
     return 0;
 }
 
-// RML_WAVEFRAME: 0 = off, 1 = on (default; long rows always, short rows -- where k_project_fast is as fast stand-alone --
+// knob (RML_OPT_WAVEFRAME): 0 = off, 1 = on (default; long rows always, short rows -- where k_project_fast is as fast stand-alone --
 // only beside a GEMM), 2 = quarter-plane buffers everywhere, 3 = also short rows stand-alone
 // Small batches stay on the workgroup-per-frame kernels: a single wave streams a 480 KB frame in ~50 us, which is what a
 // B = 1 call would wait for (single-observation latency 167 -> 210 us when this kernel took every batch size).
-bool wave_kernel_wanted(int ZQ, int Y, bool share_cu, int64_t B, int num_cu) {
+bool wave_kernel_wanted(int ZQ, int Y, bool share_cu, int64_t B, int num_cu, int knob) {
     if (B < 2 * (int64_t)num_cu) return false;
-    const char* env = getenv("RML_WAVEFRAME");          // read per call (tests flip it): a getenv is noise next to a launch
-    const int knob = env ? atoi(env) : 1;
     const int rpl = wave_kernel_rpl(ZQ, Y);
     if (knob == 0 || rpl == 0) return false;
     return rpl == 1 || share_cu || knob == 3;
@@ -448,11 +443,10 @@ bool wave_kernel_wanted(int ZQ, int Y, bool share_cu, int64_t B, int num_cu) {
 // returns true when the wave-per-frame kernel took the launch
 template <typename VT, int MODE>
 bool try_launch_wave(const ProjParams& pp_in, int num_cu, hipStream_t st) {
-    if (!wave_kernel_wanted(pp_in.ZQ, pp_in.Y, pp_in.o.share_cu != 0, pp_in.B, num_cu)) return false;
+    const int knob = pp_in.k_waveframe;
+    if (!wave_kernel_wanted(pp_in.ZQ, pp_in.Y, pp_in.o.share_cu != 0, pp_in.B, num_cu, knob)) return false;
     ProjParams pp = pp_in;
     pp.rpl = wave_kernel_rpl(pp.ZQ, pp.Y);
-    const char* env = getenv("RML_WAVEFRAME");
-    const int knob = env ? atoi(env) : 1;
     const int Y = pp.Y / wave_kernel_rpl(pp.ZQ, pp.Y);  // rows of the view
     // whole-plane buffers need an even number of planes; beside a GEMM the quarter-plane variant (206 VGPRs) leaves it room
     // (half-plane buffers, 267 registers and twice the bytes in flight per wave, were measured beside the GEMM in round 3:
@@ -651,7 +645,7 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
     // rows of 44 quads (the Walabot arena grid): the linear-plane wave-per-frame kernel (project_lin.hip), one workgroup per CU
     // beside a GEMM like k_project_wave; the wave kernel keeps every other long-row shape (and this one with RML_LINPLANE=0)
     if constexpr (sizeof(VT) == 4) {
-        if (fast_ok && wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0, pp.B, num_cu) && try_launch_lin(pp, MODE, num_cu, st)) {
+        if (fast_ok && wave_kernel_wanted(pp.ZQ, pp.Y, pp.o.share_cu != 0, pp.B, num_cu, pp.k_waveframe) && try_launch_lin(pp, MODE, num_cu, st)) {
             *used_fast = true;
             return 0;
         }
@@ -684,9 +678,14 @@ int launch_mode(const ProjParams& pp, int num_cu, hipStream_t st, bool* used_fas
     return 0;
 }
 
-void fill_params(ProjParams& pp, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
+void fill_params(ProjParams& pp, const rml_ctx* ctx, const void* V, int64_t B, int X, int Y, int Z, const int32_t* ijk, const ProjOut& o) {
     pp.V = V; pp.B = B; pp.X = X; pp.Y = Y; pp.Z = Z; pp.ZQ = Z / 4; pp.ijk = ijk; pp.tpf = 1; pp.rpl = 1; pp.o = o;
     pp.ntgt = 1; pp.ijk_out = nullptr; pp.profiles = nullptr; pp.wave_lds = 0; pp.stage_bytes = 0;
+    const rml_opts def;
+    const rml_opts& op = ctx ? ctx->opt : def;
+    pp.k_waveframe = op.waveframe; pp.k_linplane = op.linplane; pp.k_stage_codes = op.stage_codes; pp.k_slice_wave = op.slice_wave;
+    pp.k_derive_fused = op.derive_fused;
+    if (op.project_share_cu) pp.o.share_cu = 1;       // RML_OPT_PROJECT_SHARE_CU: the pipeline's kernel configuration in a stand-alone launch
     for (int pl = 0; pl < 3; ++pl)
         pp.vec_ok[pl] = o.p[pl] && ((reinterpret_cast<uintptr_t>(o.p[pl]) & 15) == 0) && (o.stride[pl] % 4 == 0);
 }
@@ -715,11 +714,12 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
 }
 }  // namespace
 
-bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B, int num_cu) {
+bool rml_project_uses_wave_kernel(const rml_ctx* ctx, int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B) {
     (void)X;
+    const int num_cu = ctx ? ctx->num_cu : 256, knob = ctx ? ctx->opt.waveframe : 1;
     if (mode != RML_MODE_MAX && mode != RML_MODE_SUM) return false;
     if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX && Z % 16 == 0) return false;      // the byte-native kernel takes those
-    return Z % 4 == 0 && wave_kernel_wanted(Z / 4, Y, share_cu, B, num_cu);
+    return Z % 4 == 0 && wave_kernel_wanted(Z / 4, Y, share_cu, B, num_cu, knob);
 }
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
@@ -729,10 +729,8 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
     RML_REQUIRE(targets_per_frame == 1 || mode == RML_MODE_SLICE, RML_ERR_INVALID, "rml_project: several targets per frame only in mode SLICE");
     ProjParams pp;
-    fill_params(pp, V, B, X, Y, Z, ijk, o);       // B counts output rows
+    fill_params(pp, ctx, V, B, X, Y, Z, ijk, o);       // B counts output rows
     pp.tpf = targets_per_frame;
-    if (getenv("RML_WAVE_SHARE")) pp.o.share_cu = 1;    // measurement knob: the pipeline's kernel configuration in a stand-alone launch
-    if (ctx && ctx->opt_project_share_cu) pp.o.share_cu = 1;      // rml_ctx_set_option(RML_OPT_PROJECT_SHARE_CU)
     const int num_cu = !ctx ? 256 : ctx->num_cu;
     const int rc = vdtype == RML_VOL_U8 ? launch_project_t<uint8_t>(pp, mode, num_cu, st) : launch_project_t<float>(pp, mode, num_cu, st);
     if (rc) return rc;
@@ -746,7 +744,7 @@ int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, 
                             int32_t* ijk_out, float* profiles, const ProjOut& o, hipStream_t st) {
     if (B == 0) return RML_OK;
     ProjParams pp;
-    fill_params(pp, V, B, X, Y, Z, nullptr, o);
+    fill_params(pp, ctx, V, B, X, Y, Z, nullptr, o);
     pp.ntgt = num_targets; pp.ijk_out = ijk_out; pp.profiles = profiles;
     const int num_cu = !ctx ? 256 : ctx->num_cu;
     if (!try_launch_derive_slice(pp, vdtype == RML_VOL_U8 ? 1 : 4, num_cu, st)) return RML_ERR_UNSUPPORTED;
@@ -808,8 +806,9 @@ static void rows_out(ProjOut& o, int X, int Y, int Z, uint32_t mask, float scale
 static int derive_two_kernels(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets, int32_t* ijk,
                               float* profiles, hipStream_t st);
 
-extern "C" int rml_derive_slice_supported(const void* V, int vdtype, int X, int Y, int Z, int num_targets) {
+extern "C" int rml_derive_slice_supported(const rml_ctx* ctx, const void* V, int vdtype, int X, int Y, int Z, int num_targets) {
     if (X <= 0 || Y <= 0 || Z <= 0 || (vdtype != RML_VOL_F32 && vdtype != RML_VOL_U8)) return 0;
+    if (ctx && !ctx->opt.derive_fused) return 0;
     const size_t quad = vdtype == RML_VOL_U8 ? 4 : 16;
     if (V && (reinterpret_cast<uintptr_t>(V) & (quad - 1))) return 0;
     return derive_slice_shape_ok(X, Y, Z, num_targets) ? 1 : 0;
@@ -845,7 +844,7 @@ extern "C" int rml_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t
         // behind the sum planes of derive_two_kernels in the shared workspace
         const size_t planes = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
         void* ws = nullptr;
-        rc = rml_ws_reserve(ctx, planes + (size_t)B * num_targets * 3 * sizeof(int32_t), &ws);
+        rc = rml_ws_reserve(ctx, planes + (size_t)B * num_targets * 3 * sizeof(int32_t), &ws, st);
         if (rc) return rc;
         ijk_w = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(ws) + planes);
     }
@@ -926,7 +925,7 @@ static int derive_two_kernels(rml_ctx* ctx, const void* V, int vdtype, int64_t B
     // workspace: sum planes xz (B,X,Z) and yz (B,Y,Z)
     size_t need = (size_t)B * ((size_t)X * Z + (size_t)Y * Z) * sizeof(float);
     void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, need, &ws);
+    int rc = rml_ws_reserve(ctx, need, &ws, st);
     if (rc) return rc;
     float* xzs = static_cast<float*>(ws);
     float* yzs = xzs + (size_t)B * X * Z;
@@ -964,7 +963,7 @@ extern "C" int rml_assemble_features(rml_ctx* ctx, const float* xz, const float*
     o.sel = mask & RML_MASK_ALL;
     o.scale_div = scale_div;
     ProjParams pp;
-    fill_params(pp, nullptr, B, X, Y, Z, nullptr, o);
+    fill_params(pp, ctx, nullptr, B, X, Y, Z, nullptr, o);
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)B), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        (mask & 1u) ? xz : nullptr, (mask & 2u) ? yz : nullptr, (mask & 4u) ? xy : nullptr, pp);
     RML_HIP(hipGetLastError());
@@ -984,7 +983,7 @@ extern "C" int rml_quantize_rows(rml_ctx* ctx, const float* feat, int64_t N, int
     o.row_isum = row_isum; o.row_isq = row_isq; o.row_flags = row_flags;
     o.scale_div = 0.0f;
     ProjParams pp;
-    fill_params(pp, nullptr, N, 1, 1, 1, nullptr, o);
+    fill_params(pp, ctx, nullptr, N, 1, 1, 1, nullptr, o);
     hipLaunchKernelGGL(k_quantize_rows, dim3((unsigned)N), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        feat, D, ld_feat, scale_div, pp);
     RML_HIP(hipGetLastError());

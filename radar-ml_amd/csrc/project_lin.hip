@@ -23,9 +23,6 @@ using namespace rmlproj;
 // 2 when the plane may end inside the second to last group (the last one is then empty)
 template <int MODE, int ZQ4, int NI, int RG, int NGRP, int NMASK, bool PRED>
 __global__ __launch_bounds__(256, 2) void k_project_lin(ProjParams a) {
-#ifdef RML_PRIO_PROJ
-    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
-#endif
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     static_assert(NGRP % 2 == 0 && RG % 8 == 0 && NMASK >= 1 && NMASK <= NGRP,
                   "an even number of groups per plane (the row buffers alternate statically); xz folds 8 rows per wait");
@@ -200,12 +197,11 @@ namespace rmlproj {
 // Rows that do not fill a load instruction, loaded as the linear array of quads a plane is.  44 quads (the Walabot arena grid) in
 // groups of 16 rows (11 whole instructions), two groups: 17..32 rows, modes MAX and SUM; 40 / 48 / 56 quads (Z = 160 / 192 / 224:
 // other arenas the reference resizes to, predict.py:34-54) in groups of 8 rows, 9..32 rows, mode MAX.  float32 volumes.
-// RML_LINPLANE=0 turns it off (k_project_wave takes the shape then).
+// RML_OPT_LINPLANE = 0 turns it off (k_project_wave takes the shape then).
 bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st) {
     if (pp.Z != 4 * pp.ZQ) return false;
     if (pp.B < 2 * (int64_t)num_cu) return false;       // small batches stay on the workgroup-per-frame kernels (latency)
-    const char* env = getenv("RML_LINPLANE");
-    if (env && atoi(env) == 0) return false;
+    if (!pp.k_linplane) return false;
     if (pp.ZQ == 44) {
         if (pp.Y <= 16 || pp.Y > 32) return false;
         if (mode == RML_MODE_MAX) launch_lin<RML_MODE_MAX, 11, 11, 16, 2, 1>(pp, num_cu, st);

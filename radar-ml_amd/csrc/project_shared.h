@@ -27,6 +27,8 @@ struct ProjParams {
     // wave-per-frame kernels, codes-only launches: bytes of wave-private LDS in which the codes of the per-plane outputs (xz, xy) wait
     // for the frame's end (Emitter::stage); 0 = every plane's codes go to memory as they are finished
     int stage_bytes;
+    // host side only: the context's kernel-family options (rml_opts; fill_params copies them) for the launchers below
+    int k_waveframe, k_linplane, k_stage_codes, k_slice_wave, k_derive_fused;
 };
 
 template <int MODE> struct Op;
@@ -61,16 +63,10 @@ __device__ __forceinline__ float4 bytes_to_float4(uint32_t w) {
 
 // Per-thread sink for finished projection values: scaled float store, uint8 code store and
 // the row statistics of the exact-integer SVM path.
-#ifndef RML_CODE_NT
-#define RML_CODE_NT 0       // experiment builds: 1 = the code rows leave with non-temporal stores
-#endif
-#ifndef RML_EMIT_ABL
-#define RML_EMIT_ABL 0      // experiment builds (timing only): 1 = no code stores, 2 = code rows of all frames land on 64 rows (L2-resident)
-#endif
 struct Emitter {
     const ProjParams& a;
     int64_t b;
-    __device__ __forceinline__ int64_t qb() const { return RML_EMIT_ABL == 2 ? (b & 63) : b; }
+    __device__ __forceinline__ int64_t qb() const { return b; }
     int32_t isum = 0;
     uint32_t isq = 0;       // per THREAD: < 66 000 codes of <= 255^2 each (the launchers keep a thread's share far below that)
     int ok = 1;
@@ -150,15 +146,11 @@ struct Emitter {
         if (want_stats) {
             isum += (int32_t)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
             isq = __builtin_amdgcn_udot4(w, w, isq, false);
-#if RML_EMIT_ABL == 1
-            asm volatile("" :: "v"(w));
-#else
             if (a.o.q[pl]) {
                 uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
                 const uint32_t nv = w ^ 0x80808080u;
                 if (!rmw || (have_old ? old : *dq) != nv) *dq = nv;
             }
-#endif
         }
     }
     // idx is a multiple of 4
@@ -185,16 +177,10 @@ struct Emitter {
             if (a.o.q[pl]) {
                 uint32_t packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
                 if (staged && pl != 1) *(lds_u32*)(stage + (pl == 2 ? stage_xy : 0) + idx) = packed;
-#if RML_EMIT_ABL == 1
-                else asm volatile("" :: "v"(packed));
-#elif RML_CODE_NT
-                else __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx));
-#else
                 else {
                     uint32_t* dq = reinterpret_cast<uint32_t*>(a.o.q[pl] + qb() * a.o.qstride + idx);
                     if (!rmw || (have_old ? old : *dq) != packed) *dq = packed;
                 }
-#endif
             }
         }
     }
@@ -208,19 +194,12 @@ struct Emitter {
         const int len[2] = {a.X * a.Z, a.X * a.Y};
         lds_u8* src[2] = {stage, stage + stage_xy};
         uint8_t* dst[2] = {a.o.q[0] + qb() * a.o.qstride, a.o.q[2] + qb() * a.o.qstride};
-#if RML_EMIT_ABL == 1
-        return;
-#endif
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int done = 0;
             if ((reinterpret_cast<uintptr_t>(dst[r]) & 15) == 0) {
                 for (int i = lane; i < (len[r] >> 4); i += 64) {
-#if RML_CODE_NT
-                    __builtin_nontemporal_store(((lds_u128*)src[r])[i], reinterpret_cast<u32x4*>(dst[r]) + i);
-#else
                     reinterpret_cast<u32x4*>(dst[r])[i] = ((lds_u128*)src[r])[i];
-#endif
                 }
                 done = len[r] & ~15;
             }
@@ -295,23 +274,15 @@ struct Emitter {
 // streaming load: every volume byte is read exactly once, so it is marked non-temporal (keeps the
 // support-vector tiles of the concurrently running SVM GEMM resident in L2 / Infinity Cache)
 __device__ __forceinline__ float4 ld_stream(const float4* p) {
-#ifdef RML_NO_NT
-    return *p;
-#else
     typedef float v4f_t __attribute__((ext_vector_type(4)));
     v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
-#endif
 }
 
 // uint8 volumes (the radar's native 0..255 magnitudes, 4x fewer HBM bytes): a lane's quad is one dword,
 // widened with v_cvt_f32_ubyte0..3; everything downstream is the float path, so the results are identical
 __device__ __forceinline__ float4 ld_stream(const uint32_t* p) {
-#ifdef RML_NO_NT
-    const uint32_t w = *p;
-#else
     const uint32_t w = __builtin_nontemporal_load(p);
-#endif
     return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
 }
 template <typename VT> struct Quad;
@@ -359,13 +330,11 @@ template <int J> __device__ __forceinline__ float park_lane(float acc, float uni
 // would quiet a signalling NaN; v_max_f32 itself already returns the other operand for ANY NaN, which is the documented NaN
 // policy of the max-projection).  4 VALU less per row of the streaming loop.
 template <int MODE> __device__ __forceinline__ float op_raw(float a, float b) {
-#ifndef RML_NO_RAWMAX
     if constexpr (MODE == RML_MODE_MAX) {
         float r;
         asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
         return r;
     } else
-#endif
     {
         return Op<MODE>::f(a, b);
     }
@@ -374,12 +343,11 @@ template <int MODE> __device__ __forceinline__ float4 op4_raw(float4 a, float4 b
     return make_float4(op_raw<MODE>(a.x, b.x), op_raw<MODE>(a.y, b.y), op_raw<MODE>(a.z, b.z), op_raw<MODE>(a.w, b.w));
 }
 
-// bytes of per-wave LDS code stage for a launch of a wave-per-frame kernel (0: not a codes-only launch, or RML_STAGE_CODES=0)
+// bytes of per-wave LDS code stage for a launch of a wave-per-frame kernel (0: not a codes-only launch, or RML_OPT_STAGE_CODES = 0)
 inline int code_stage_bytes(const ProjParams& pp, size_t voxel_bytes) {
     const ProjOut& o = pp.o;
     if (voxel_bytes != 4 || o.p[0] || o.p[1] || o.p[2] || o.row_nsq || !o.q[0] || !o.q[2] || o.skip_if_set) return 0;
-    const char* env = getenv("RML_STAGE_CODES");
-    if (env && atoi(env) == 0) return 0;
+    if (!pp.k_stage_codes) return 0;
     const int bytes = ((pp.X * pp.Z + 15) & ~15) + ((pp.X * pp.Y + 15) & ~15);
     return bytes <= 16 * 1024 ? bytes : 0;
 }
@@ -392,7 +360,7 @@ bool try_launch_lin(const ProjParams& pp, int mode, int num_cu, hipStream_t st);
 // frame; pp.ntgt / ijk_out / profiles set by the caller); true when they took the launch
 bool try_launch_slice(const ProjParams& pp, int vbytes, hipStream_t st);
 bool try_launch_derive_slice(const ProjParams& pp, int vbytes, int num_cu, hipStream_t st);
-bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt);
+bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt);        // the shape alone (RML_OPT_DERIVE_FUSED is the caller's)
 
 // project_u8.hip: the byte-native max-projection of uint8 volumes (rows of whole 16-byte chunks); true when it took the launch
 bool try_launch_u8_max(const ProjParams& pp, hipStream_t st);

@@ -31,12 +31,7 @@
 // are bit-exact against NumPy; on other data the float32 rounding follows this kernel's (fixed) order.
 #include "project_shared.h"
 
-#ifndef RML_DERIVE_UB
-#define RML_DERIVE_UB 8     // quads per gather batch of k_derive_slice (variant builds: 4, 16)
-#endif
-#ifndef RML_DS_ABL
-#define RML_DS_ABL 0      // ablation switches of k_derive_slice (variant builds only)
-#endif
+constexpr int RML_DERIVE_UB = 8;     // quads per gather batch of k_derive_slice (4 and 16 were measured: tools/exp/README.md)
 
 namespace {
 
@@ -454,11 +449,10 @@ bool quads_ok(const ProjParams& pp, int vbytes) {
 
 namespace rmlproj {
 
-// mode SLICE, (i,j,k) given.  RML_SLICE_WAVE=0 keeps the round-1 workgroup-per-row kernel (A/B knob).
+// mode SLICE, (i,j,k) given.  RML_OPT_SLICE_WAVE = 0 keeps the round-1 workgroup-per-row kernel (A/B knob).
 bool try_launch_slice(const ProjParams& pp, int vbytes, hipStream_t st) {
     if (!quads_ok(pp, vbytes) || pp.B <= 0) return false;
-    const char* env = getenv("RML_SLICE_WAVE");
-    if (env && atoi(env) == 0) return false;
+    if (!pp.k_slice_wave) return false;
     dim3 grid((unsigned)((pp.B + 3) / 4)), block(kThreads);
     if (vbytes == 1) hipLaunchKernelGGL(k_slice_rows<uint8_t>, grid, block, 0, st, pp);
     else hipLaunchKernelGGL(k_slice_rows<float>, grid, block, 0, st, pp);
@@ -467,8 +461,6 @@ bool try_launch_slice(const ProjParams& pp, int vbytes, hipStream_t st) {
 
 bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt) {
     DeriveGeom g;
-    const char* env = getenv("RML_DERIVE_FUSED");
-    if (env && atoi(env) == 0) return false;
     return ntgt >= 1 && derive_geom(X, Y, Z, ntgt, &g);
 }
 
@@ -476,9 +468,7 @@ bool derive_slice_shape_ok(int X, int Y, int Z, int ntgt) {
 // false: the shape has no fused kernel (rows that are not whole quads, Z > 256, odd part of Z/4 above 15)
 bool try_launch_derive_slice(const ProjParams& pp_in, int vbytes, int num_cu, hipStream_t st) {
     DeriveGeom g;
-    if (!quads_ok(pp_in, vbytes) || pp_in.B <= 0 || pp_in.ntgt < 1) return false;
-    const char* env = getenv("RML_DERIVE_FUSED");
-    if (env && atoi(env) == 0) return false;
+    if (!quads_ok(pp_in, vbytes) || pp_in.B <= 0 || pp_in.ntgt < 1 || !pp_in.k_derive_fused) return false;
     if (!derive_geom(pp_in.X, pp_in.Y, pp_in.Z, pp_in.ntgt, &g)) return false;
     ProjParams pp = pp_in;
     pp.wave_lds = (int)g.wave_lds;

@@ -38,9 +38,6 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 template <int NM, bool PRED, int FCPR, bool RMW = false>
 // 192 registers: two of these workgroups and the 128-register waves of one k_svm_gemm workgroup share a SIMD's 512 in the fused pipeline
 __global__ __launch_bounds__(kThreads) void k_project_u8_max(ProjParams a, int CPR_rt, int S) {
-#ifdef RML_PRIO_PROJ
-    __builtin_amdgcn_s_setprio(RML_PRIO_PROJ);      // experiment: issue priority of the projection waves beside the GEMM's
-#endif
     extern __shared__ __align__(16) unsigned char lds8[];
     if constexpr (PRED) { if (*a.o.skip_if_set) return; }
     const int X = a.X, Y = a.Y, Z = a.Z;

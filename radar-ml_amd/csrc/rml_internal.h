@@ -23,12 +23,35 @@ struct rml_pre_tab {
     size_t off[6];
 };
 
+// rml_ctx_set_option values.  The defaults are the tuned configuration; the others exist for A/B measurements and for the tests
+// that pin one kernel family against another (they used to be environment variables read with getenv inside the launch paths:
+// a data race beside a caller's setenv, and invisible in the API).
+struct rml_opts {
+    int project_share_cu = 0;   // RML_OPT_PROJECT_SHARE_CU
+    int waveframe = 1;          // RML_OPT_WAVEFRAME: 0 off, 1 on, 2 quarter-plane buffers everywhere, 3 also short rows stand-alone
+    int linplane = 1;           // RML_OPT_LINPLANE: k_project_lin for rows of 40 / 44 / 48 / 56 quads
+    int stage_codes = 1;        // RML_OPT_STAGE_CODES: per-wave LDS code stage of the wave-per-frame kernels
+    int slice_wave = 1;         // RML_OPT_SLICE_WAVE: k_slice_rows (0: the round-1 workgroup-per-row kernel)
+    int derive_fused = 1;       // RML_OPT_DERIVE_FUSED: k_derive_slice (0: sum planes + top-k + slices)
+    int code_rmw = -1;          // RML_OPT_CODE_RMW: -1 = the measured rule (rml_code_rmw), 0 / 1 forced
+    int gemm_big = -1;          // RML_OPT_GEMM_BIG: -1 = whole-round rule (use_big_gemm), 0 never, 1 for every n >= 256
+    int c1_pk = 1;              // RML_OPT_C1_PK: packed first-layer kernels of the SGAN branches
+    int64_t chunk = 0;          // RML_OPT_CHUNK: rows per chunk of the chunked front doors, 0 = chosen per batch
+};
+
+struct rml_ws_retired {         // a workspace block that was outgrown: freed once the work queued before its retirement is done
+    void* p;
+    hipEvent_t ev;
+};
+
 struct rml_ctx {
     int device = 0;
     int num_cu = 256;
     // grow-on-demand device workspace for the fused front doors (owned by the ctx)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::vector<rml_ws_retired> ws_retired;
+    rml_opts opt;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_proj[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // chunk pipeline of rml_project_svm (two workspaces)
     hipStream_t aux_stream = nullptr;   // second stream for overlapping GEMM with projection
@@ -42,10 +65,6 @@ struct rml_ctx {
     double prof_ops_g = 0.0;
     std::vector<rml_resize_tab> resize_tabs;    // owned; freed with the context
     std::vector<rml_pre_tab> pre_tabs;          // owned; freed with the context
-    // RML_OPT_PROJECT_SHARE_CU: stand-alone projection launches (rml_project*) use the configuration the fused pipeline uses
-    // beside a GEMM -- one persistent workgroup per CU, LDS request padded -- so that another kernel of the caller's (on another
-    // stream) finds room on every CU
-    int opt_project_share_cu = 0;
     // Entry points that use the shared workspace / events / caches take `mu` for the duration of the call and order
     // their stream behind the previous user's work (ev_last), so calls from several host threads or on several
     // streams cannot interleave on the workspace (rml_ctx_guard below).
@@ -59,12 +78,19 @@ struct rml_ctx {
 struct rml_ctx_guard {
     rml_ctx* ctx;
     hipStream_t st;
+    bool capturing = false;
     explicit rml_ctx_guard(rml_ctx* c, hipStream_t stream) : ctx(c), st(stream) {
         ctx->mu.lock();
-        if (ctx->ev_last_valid) (void)hipStreamWaitEvent(st, ctx->ev_last, 0);
+        // Inside a stream capture (a caller recording the call into a HIP graph) the cross-call ordering is the caller's: an event
+        // recorded by an earlier, un-captured call cannot be waited for from a captured stream on every runtime, and an event recorded
+        // INSIDE the capture must not become the "last use" that later un-captured calls wait for.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        capturing = cs != hipStreamCaptureStatusNone;
+        if (!capturing && ctx->ev_last_valid) (void)hipStreamWaitEvent(st, ctx->ev_last, 0);
     }
     ~rml_ctx_guard() {
-        if (ctx->ev_last && hipEventRecord(ctx->ev_last, st) == hipSuccess) ctx->ev_last_valid = true;
+        if (!capturing && ctx->ev_last && hipEventRecord(ctx->ev_last, st) == hipSuccess) ctx->ev_last_valid = true;
         ctx->mu.unlock();
     }
     rml_ctx_guard(const rml_ctx_guard&) = delete;
@@ -108,7 +134,8 @@ int rml_hip_fail(hipError_t e, const char* what, const char* file, int line);
         }                                   \
     } while (0)
 
-int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out);
+// workspace of at least `bytes` (inside an rml_ctx_guard on `st`); growing allocates -- not inside a stream capture: context.hip
+int rml_ws_reserve(rml_ctx* ctx, size_t bytes, void** out, hipStream_t st);
 
 // ---- projection (project.hip) -------------------------------------------------------------
 struct ProjOut {
@@ -160,10 +187,8 @@ struct ProjOut {
 //     without -- but the prefetched old words and the test in front of every store cost k_project_lin 9 % in situ (0.735 -> 0.665)
 //     and the headline 1 % against the library before: those kernels store plainly again (Emitter::rmw = false)              off
 // The CNN chain's first pass keeps plain stores (5.98 / 5.97 M frames/s without, 5.87 / 5.96 with).
-// RML_CODE_RMW=0 / 1 forces it off / on where a kernel has it (read per call: the tests flip it).
+// rml_ctx_set_option(RML_OPT_CODE_RMW, 0 / 1) forces it off / on where a kernel has it (-1: this rule).
 inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
-    const char* e = getenv("RML_CODE_RMW");
-    if (e && *e) return atoi(e) != 0;
     // round 5, FRESH frames (bench.py's sliding windows: no workspace row meets its own frame's old codes; sessions r5c / r5d):
     // 64x64x128 uint8 +2.7 % (the +6-10 % above came with a batch re-run 20 times), derive -> slice +1.6 % / +1.3 % -- below the
     // 2 % bar: the derive pipelines store plainly
@@ -173,7 +198,7 @@ inline int rml_code_rmw(int64_t D, int64_t frame_bytes, bool derive, bool u8) {
 
 // true when rml_launch_project would use the persistent wave-per-frame kernel for this shape (the fused pipeline then
 // pairs it with the 128x128 GEMM, whose workgroups fit beside it on a CU)
-bool rml_project_uses_wave_kernel(int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B, int num_cu);
+bool rml_project_uses_wave_kernel(const rml_ctx* ctx, int vdtype, int mode, int X, int Y, int Z, bool share_cu, int64_t B);
 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);

@@ -92,13 +92,7 @@ __device__ __forceinline__ void exp_tab_init(double* tab, int tid) {
     if (tid < 64) tab[tid] = kExp2Tab[tid];
 }
 
-#ifndef RML_LIBM_EXP
-#define RML_LIBM_EXP 0      // experiment builds only: 1 = the library exp() in the epilogues
-#endif
 __device__ __forceinline__ double rml_exp_neg(double x, const double* tab) {
-#if RML_LIBM_EXP
-    return exp(x);
-#else
     x = fmax(x, -1000.0);
     const double nf = rint(x * 0x1.71547652b82fep+6);              // x * 64/ln2
     double r = fma(nf, -0x1.62e42fee00000p-7, x);
@@ -111,7 +105,6 @@ __device__ __forceinline__ double rml_exp_neg(double x, const double* tab) {
     p = fma(r, p, 0.5);
     p = fma(r * r, p, r);
     return ldexp(fma(T, p, T), n >> 6);
-#endif
 }
 
 struct GemmArgs {
@@ -139,9 +132,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 template <int PATH, int PT, bool KM = false>
 __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
-#ifdef RML_PRIO_GEMM
-    __builtin_amdgcn_s_setprio(RML_PRIO_GEMM);      // experiment: issue priority of the GEMM waves beside the projection's
-#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -230,13 +220,10 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
     }
     const int kgrp = lane >> 4;
 
-#ifndef RML_GEMM_ABL
-#define RML_GEMM_ABL 0      // experiment builds only (radar-ml_amd/build.py --variant): 2 = no staging, 3 = no MFMA, 1 = no exp
-#endif
     stage(0, 0);
     for (int kt = 0; kt < a.KT; ++kt) {
         __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
-        if (RML_GEMM_ABL != 2 && kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < a.KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 2 * kTileBytes;
         const unsigned char* sB = sA + kTileBytes;
         if constexpr (PATH == PATH_F64) {
@@ -288,11 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if constexpr (PATH == PATH_I8) {
-#if RML_GEMM_ABL == 3
-                            acc[i][j][0] += af[kk & 1][i][0] ^ bf[kk & 1][j][1];
-#else
                             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-#endif
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
@@ -420,11 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_svm_gemm(GemmArgs a) {
         if (rbf) {
             double d2 = xt + e[0] - 2.0 * g;
             d2 = d2 > 0.0 ? d2 : 0.0;
-#if RML_GEMM_ABL == 1
-            kv = d2;
-#else
             kv = rml_exp_neg(-a.gs * d2, etab);
-#endif
         } else {
             kv = (PATH == PATH_I8) ? (g + xt + e[0]) * a.gs : g;
         }
@@ -1051,10 +1030,8 @@ inline bool use_dig_gemm(const rml_svm* m, int policy, int64_t n, int num_cu) {
 // does the 256x256 ring kernel take the exact tiles of a chunk of n rows against this model?  It runs at up to 0.6 of the int8
 // peak when its tiles fill whole rounds of one workgroup per CU and proportionally less otherwise; the 128x128 kernel (two
 // workgroups per CU, four times as many tiles) sits at 0.40-0.46 whatever the batch.  So: at least three quarters of a round,
-// and the last round at least three quarters full.  RML_GEMM_BIG=0 turns it off, =1 forces it for every n >= 256.
-inline bool use_big_gemm(const rml_svm* m, int64_t n, int num_cu) {
-    const char* env = getenv("RML_GEMM_BIG");          // read per call: tests flip it
-    const int knob = env ? atoi(env) : -1;
+// and the last round at least three quarters full.  knob = RML_OPT_GEMM_BIG: 0 turns it off, 1 forces it for every n >= 256.
+inline bool use_big_gemm(const rml_svm* m, int64_t n, int num_cu, int knob) {
     if (knob == 0 || m->PT > 6) return false;
     if (knob == 1) return n >= 256;
     const int64_t wgs = ((n + kBig - 1) / kBig) * ((m->Mpad + kBig - 1) / kBig);
@@ -1302,18 +1279,17 @@ int launch_gemm_big(const rml_svm* m, const GemmArgs& ga, hipStream_t st) {
 // Rows per chunk of the chunked front doors.  Where the 256x256 ring kernel runs (an exact model, or the multi-digit path) a
 // chunk costs ceil(tiles / CUs) rounds of one workgroup per CU, so the chunk size is chosen for the WHOLE batch: among the
 // multiples of 256 rows in 4096..32768 the one with the fewest rounds in total (full chunks + the remainder) plus a small charge
-// per chunk, the larger chunk on a tie.  Otherwise `fallback`.  RML_CHUNK overrides.
-int64_t pick_chunk_env(int64_t fallback) {
-    const char* e = getenv("RML_CHUNK");
-    const int64_t v = e ? atoll(e) : 0;
+// per chunk, the larger chunk on a tie.  Otherwise `fallback`.  RML_OPT_CHUNK overrides.
+int64_t pick_chunk_opt(const rml_ctx* ctx, int64_t fallback) {
+    const int64_t v = ctx->opt.chunk;
     return v >= 128 ? round_up(v, kTile) : fallback;
 }
 
-int64_t pick_chunk(const rml_svm* m, int64_t rows, int64_t fallback, int num_cu, bool dig = false) {
-    const int64_t env = pick_chunk_env(0);
+int64_t pick_chunk(const rml_ctx* ctx, const rml_svm* m, int64_t rows, int64_t fallback, int num_cu, bool dig = false) {
+    const int64_t env = pick_chunk_opt(ctx, 0);
     int64_t ch = fallback;
     if (env) ch = env;
-    else if (dig || (m->exact && use_big_gemm(m, 32768, num_cu))) {
+    else if (dig || (m->exact && use_big_gemm(m, 32768, num_cu, ctx->opt.gemm_big))) {
         const int64_t st2 = (m->Mpad + kBig - 1) / kBig;
         auto rounds = [&](int64_t n) { return n <= 0 ? (int64_t)0 : (((n + kBig - 1) / kBig) * st2 + num_cu - 1) / num_cu; };
         // cost in units of a twentieth of a round: a chunk also costs its launches and a fill / drain in which the CUs run in
@@ -1411,7 +1387,7 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
     RML_REQUIRE(run_i8 || run_gen, RML_ERR_STATE, "svm: no usable operand path (model exact=%d)", (int)m->exact);
     // large exact batches go to the 256x256 kernel; the tile predicate is then decided per pair of 128-sample tiles
     const int gemm_cus = ctx->num_cu;
-    const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, gemm_cus);
+    const bool big = allow_big && run_i8 && !kmat && use_big_gemm(m, n, gemm_cus, ctx->opt.gemm_big);
     // general tiles whose rows fit the model's fixed-point range go to the multi-digit int8 kernel (digit planes in w.dig)
     const bool run_dig = dig_ready && w.dig && run_gen && !gen_f32 && !kmat && m->dig_ok;
     if (!tiles_done) {
@@ -1659,15 +1635,15 @@ extern "C" int rml_svm_decision(rml_ctx* ctx, const rml_svm* m, int path,
     // float rows of a model that is not on the code grid: the multi-digit kernel when the batch fills enough 256 x 256 tiles
     // (chunks sized for whole rounds of one workgroup per CU, like the exact 256 x 256 kernel's)
     const bool dig = feat != nullptr && !m->exact && use_dig_gemm(m, path, N, ctx->num_cu);
-    const int64_t CH = feat ? ((dig || m->exact) ? pick_chunk(m, N, 8192, ctx->num_cu, dig) : std::min<int64_t>(round_up(N, kTile), 8192))
-                            : pick_chunk(m, N, 8192, ctx->num_cu);
+    const int64_t CH = feat ? ((dig || m->exact) ? pick_chunk(ctx, m, N, 8192, ctx->num_cu, dig) : std::min<int64_t>(round_up(N, kTile), 8192))
+                            : pick_chunk(ctx, m, N, 8192, ctx->num_cu);
     const bool need_q = feat != nullptr && m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     const bool need_f32 = feat != nullptr;
     // a model on the code grid can meet general rows as well (mixed batches): digit planes then ride along with the codes
     const bool need_dig = feat != nullptr && (dig || (m->exact && use_dig_gemm(m, path, N, ctx->num_cu)));
     ChunkWs probe = carve(m, CH, nullptr, need_q, need_f32, need_dig);
     void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, probe.bytes, &ws);
+    int rc = rml_ws_reserve(ctx, probe.bytes, &ws, st);
     if (rc) return rc;
     ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, need_f32, need_dig);
     DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
@@ -1709,7 +1685,7 @@ extern "C" int rml_svm_kernel_matrix(rml_ctx* ctx, const rml_svm* m, int path, c
     const bool need_q = m->exact && (path == RML_PATH_AUTO || path == RML_PATH_I8);
     ChunkWs probe = carve(m, CH, nullptr, need_q, true);
     void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, probe.bytes, &ws);
+    int rc = rml_ws_reserve(ctx, probe.bytes, &ws, st);
     if (rc) return rc;
     ChunkWs w = carve(m, CH, static_cast<unsigned char*>(ws), need_q, true);
     DecisionOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1745,7 +1721,7 @@ extern "C" int rml_derive_project_svm(rml_ctx* ctx, const rml_svm* m, const void
                                       float scale_div, uint32_t mask, int32_t* ijk_out,
                                       double* dec_ovo, double* dec_ovr, double* proba,
                                       int32_t* label_vote, int32_t* label_calib, void* stream) {
-    RML_REQUIRE(rml_derive_slice_supported(V, vdtype, X, Y, Z, 1) == 1, RML_ERR_UNSUPPORTED,
+    RML_REQUIRE(rml_derive_slice_supported(ctx, V, vdtype, X, Y, Z, 1) == 1, RML_ERR_UNSUPPORTED,
                 "rml_derive_project_svm: no fused derive kernel for %dx%dx%d (rows of whole quads, Z <= 256, odd part of Z/4 <= 15): "
                 "use rml_derive_targets + rml_project_svm(mode SLICE)", X, Y, Z);
     return project_svm_impl(ctx, m, V, vdtype, B, X, Y, Z, RML_MODE_SLICE, nullptr, true, ijk_out, scale_div, mask, dec_ovo, dec_ovr, proba,
@@ -1782,7 +1758,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // derive -> slice: the persistent k_derive_slice takes the same pairing (one 8-wave workgroup per CU beside 128x128 GEMM
     // workgroups; the ring GEMM in whole-round chunks, the two kernels taking turns, measured 1-2 % slower: DESIGN.md 3.3)
     const bool wave_proj = derive ? true
-                                  : rml_project_uses_wave_kernel(vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192), ctx->num_cu);
+                                  : rml_project_uses_wave_kernel(ctx, vdtype, mode, X, Y, Z, /*share_cu=*/true, std::min<int64_t>(B, 8192));
     // Byte volumes (k_project_u8_max): the GEMM is a third of the step there, and since the projection's cross-lane steps left the
     // LDS pipe (round 3: 0.59 -> 0.71 of 8 TB/s alone) each kernel is worth more alone than beside the other: the 256x256 ring
     // kernel in whole-round chunks, the projection between its rounds (64x64x128 uint8, same box: 6.5-6.9 -> 7.4-7.5 M frames/s;
@@ -1804,16 +1780,16 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // and GEMM workgroups: on the GEMM stream it waited for the end of the running projection launch, chunk after chunk
     // (profiles/r03_stats_walabot_f32.txt of session r3o: 224 launches of k_svm_gemm_ring<3,1>, up to 325 us each)
     const bool use_dig = !grid_ok && vdtype != RML_VOL_U8 && use_dig_gemm(m, RML_PATH_AUTO, B, ctx->num_cu);
-    const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(m, B, small_chunk, gemm_cus)
-                       : (!grid_ok && use_dig)  ? pick_chunk(m, B, 8192, ctx->num_cu, true)
-                                                : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_env(small_chunk) : 8192);
+    const int64_t CH = (grid_ok && !small_gemm) ? pick_chunk(ctx, m, B, small_chunk, gemm_cus)
+                       : (!grid_ok && use_dig)  ? pick_chunk(ctx, m, B, 8192, ctx->num_cu, true)
+                                                : std::min<int64_t>(round_up(B, kTile), grid_ok ? pick_chunk_opt(ctx, small_chunk) : 8192);
     const bool ws_ijk = derive && !ijk_out;             // the derived (i,j,k) stay in the chunk's workspace when the caller does not want them
     ChunkWs probe = carve(m, CH, nullptr, grid_ok, true, use_dig, ws_ijk);
     // workspaces in rotation: 2 (projection of chunk c+1 beside the GEMM of chunk c; a third one -- the projection two chunks
     // ahead -- changed nothing at 64x64x128 and cost 2 % at the Walabot grid: DESIGN.md 3.3)
     constexpr int NBUF = 2;
     void* ws = nullptr;
-    int rc = rml_ws_reserve(ctx, (size_t)NBUF * probe.bytes, &ws);
+    int rc = rml_ws_reserve(ctx, (size_t)NBUF * probe.bytes, &ws, st);
     if (rc) return rc;
     ChunkWs w2[NBUF];
     for (int i = 0; i < NBUF; ++i) w2[i] = carve(m, CH, static_cast<unsigned char*>(ws) + (size_t)i * probe.bytes, grid_ok, true, use_dig, ws_ijk);
@@ -1856,7 +1832,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         o.qstride = m->Dq; o.qrow = grid_ok ? w.q : nullptr; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = w.flags; o.scale_div = scale_div;
         o.share_cu = 1;
-        o.q_rmw = rml_code_rmw(m->D, frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4), derive, vdtype == RML_VOL_U8);
+        o.q_rmw = ctx->opt.code_rmw >= 0 ? ctx->opt.code_rmw : rml_code_rmw(m->D, frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4), derive, vdtype == RML_VOL_U8);
         const void* Vc = static_cast<const unsigned char*>(V) + r0 * frame_elems * (vdtype == RML_VOL_U8 ? 1 : 4);
         const int32_t* ijkc = ijk ? ijk + r0 * 3 : nullptr;
         // fused derive -> slice: the first pass derives (i,j,k) per frame and slices there in one launch; a second pass (float rows
@@ -1901,7 +1877,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
             if (rc) return rc;
             RML_HIP(hipEventRecord(ev_proj[c % NBUF], sp));
             RML_HIP(hipStreamWaitEvent(side, ev_proj[c % NBUF], 0));
-            const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
+            const int group = (use_dig || (!small_gemm && use_big_gemm(m, n, gemm_cus, ctx->opt.gemm_big))) ? 2 : 1;      // the same decision run_chunk takes for this chunk
             hipLaunchKernelGGL(k_tile_flags, dim3((FT + group - 1) / group + 1), dim3(128 * group), 0, side, w.flags, n, FT, 0, 1, w.tile_exact,
                                w.all_exact, group);
         }

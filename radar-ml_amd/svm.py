@@ -217,7 +217,7 @@ class GpuSVC(_Base):
             derived = ijk is None
             # no SDK target: DerivedTarget.get_derived_targets (common.py:49-80) on the GPU -- in the same pass as the slices and
             # the SVM where the shape has the fused kernel (rml_derive_project_svm), as a launch of its own otherwise
-            fused_derive = derived and bool(lib.rml_derive_slice_supported(_lib.ptr(v), vdt, X, Y, Z, 1))
+            fused_derive = derived and bool(lib.rml_derive_slice_supported(_lib.context(v.device), _lib.ptr(v), vdt, X, Y, Z, 1))
             if derived and not fused_derive:
                 ijk = derive_targets(v, 1)[:, 0, :]
             if fused_derive:

@@ -41,6 +41,21 @@ def rml(built_lib):
     return radar_ml_amd
 
 
+@pytest.fixture
+def rml_opt(rml):
+    """rml_opt(name, value): rml_ctx_set_option on the current device's context (radar_ml_amd._lib.OPTIONS names), restored after the test.
+    (Rounds 1-5 flipped environment variables the library read with getenv on every launch.)"""
+    from radar_ml_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.set_option(name, int(value))
+        saved.setdefault(name, old)
+    yield set_
+    for k, v in saved.items():
+        _lib.set_option(k, v)
+
+
 def svm_model_arrays(g):
     """dict of model arrays from a golden svm fixture (SVs back from their uint8 codes)."""
     sv = (g["sv_u8"].astype(np.float32) / np.float32(255.0)).astype(np.float64)

@@ -732,7 +732,7 @@ def test_fused_conv1_bn_lrelu_pad_matches_torch(rml, dtype, sparse, c, hw, n):
 
 
 @pytest.mark.parametrize("hw,n", [(32, 5), (64, 3), (128, 7)])
-def test_packed_conv1_backward_equals_the_general_kernel(rml, hw, n, monkeypatch):
+def test_packed_conv1_backward_equals_the_general_kernel(rml, hw, n, rml_opt):
     """k_c1_bwd1_pk sums what k_c1_bwd1<., 4> sums, per thread in the same order (the same taps, products and masks): with the same
     number of workgroups the two would agree to the bit; the packed kernel runs one round of resident workgroups, so the partial
     sums are grouped differently -- the weight / gamma / beta gradients agree to float32 round-off of the sums."""
@@ -745,7 +745,7 @@ def test_packed_conv1_backward_equals_the_general_kernel(rml, hw, n, monkeypatch
     dy = torch.randn((n, c, hw // 2 + 1, hw // 2 + 1), device="cuda").half().contiguous(memory_format=torch.channels_last)
     grads = []
     for pk in ("1", "0"):
-        monkeypatch.setenv("RML_C1_PK", pk)
+        rml_opt("c1_pk", int(pk))
         torch.manual_seed(3)
         conv = torch.nn.Conv2d(1, c, 3, stride=2, padding=0).cuda()
         bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()

@@ -47,18 +47,18 @@ def test_sum_projection_exact_on_integer_data(rml, shape):
 
 @pytest.mark.parametrize("shape,knob", [(s, k) for k in ("1", "2") for s in [(22, 31, 176), (4, 8, 132), (3, 20, 180), (6, 32, 256), (2, 13, 148)]]
                          + [(s, "3") for s in [(16, 64, 128), (6, 16, 64), (5, 20, 128), (8, 62, 128), (4, 128, 64), (3, 4, 64)]])
-def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
+def test_wave_per_frame_kernel_many_frames(rml, shape, knob, rml_opt):
     """The persistent wave-per-frame kernel (k_project_wave): more frames than resident waves, so every wave walks several
     frames with the cross-frame prefetch, in both buffer configurations (RML_WAVEFRAME=1 whole plane / 2 quarter plane),
     max and sum, float rows + codes + statistics.  Knob 3: short rows (Z/4 = 32 or 16) through the same kernel, 2 or 4 real
     rows per virtual 64-quad row -- the configuration the fused pipeline uses beside the GEMM (forced stand-alone here, also
     with RML_WAVE_SHARE: quarter-plane buffers, one workgroup per CU)."""
     import torch
-    monkeypatch.setenv("RML_WAVEFRAME", knob)
-    monkeypatch.setenv("RML_LINPLANE", "0")           # rows of 44 quads: this test keeps them on k_project_wave (the linear-plane kernel
+    rml_opt("waveframe", int(knob))
+    rml_opt("linplane", 0)           # rows of 44 quads: this test keeps them on k_project_wave (the linear-plane kernel
     #                                                   has its own test below)
     if knob == "3" and shape[0] % 2 == 0:
-        monkeypatch.setenv("RML_WAVE_SHARE", "1")
+        rml_opt("project_share_cu", 1)
     X, Y, Z = shape
     B = 2600 if X * Y * Z < 60000 else 1100
     rng = np.random.default_rng(X * 1000 + Y)
@@ -92,17 +92,17 @@ def test_wave_per_frame_kernel_many_frames(rml, shape, knob, monkeypatch):
                                    (22, 31, 160), (22, 31, 192), (16, 24, 224), (5, 12, 160), (3, 16, 192), (4, 9, 224), (2, 20, 160),
                                    (3, 17, 192), (2, 25, 224), (3, 32, 160)])
 @pytest.mark.parametrize("share", ["0", "1"])
-def test_linear_plane_kernel_many_frames(rml, shape, share, monkeypatch):
+def test_linear_plane_kernel_many_frames(rml, shape, share, rml_opt):
     """k_project_lin (csrc/project_lin.hip): rows of 44 quads loaded as the contiguous array of quads a plane is (the Walabot
     arena grid 22 x 31 x 176 and its neighbours with 17..32 rows): more frames than resident waves, so every wave walks
     several frames with the cross-frame prefetch; stand-alone (two workgroups per CU) and in the configuration the fused
     pipeline uses beside the GEMM (RML_WAVE_SHARE: one workgroup per CU); max and sum, float rows + codes + statistics,
     integer and non-integer / negative data -- bit-exact against the oracle, and against k_project_wave on the same frames."""
-    monkeypatch.setenv("RML_LINPLANE", "1")
+    rml_opt("linplane", 1)
     if share == "1":
-        monkeypatch.setenv("RML_WAVE_SHARE", "1")
+        rml_opt("project_share_cu", 1)
     else:
-        monkeypatch.delenv("RML_WAVE_SHARE", raising=False)
+        rml_opt("project_share_cu", 0)
     X, Y, Z = shape
     B = 2600 if X * Y * Z < 60000 else 1300
     rng = np.random.default_rng(X * 1000 + Y)
@@ -129,11 +129,11 @@ def test_linear_plane_kernel_many_frames(rml, shape, share, monkeypatch):
     lin = rml.project(vf, mode="max")
     for g, w in zip(lin, O.project_max(vf)):
         np.testing.assert_array_equal(g, w)
-    monkeypatch.setenv("RML_LINPLANE", "0")
+    rml_opt("linplane", 0)
     for g, w in zip(rml.project(vf, mode="max"), lin):                     # the wave kernel gives the same bits
         np.testing.assert_array_equal(g, w)
     # masks: only some planes wanted
-    monkeypatch.setenv("RML_LINPLANE", "1")
+    rml_opt("linplane", 1)
     for mask in ((True, False, True), (False, True, False)):
         f2 = rml.process_volumes(v[:600], mode="max", proj_mask=rml.ProjMask(*mask), scale=True)
         np.testing.assert_array_equal(f2.cpu().numpy(), O.features_from_projections(xz[:600], yz[:600], xy[:600], mask, True))
@@ -418,7 +418,7 @@ def test_uint8_byte_kernel_lane_layouts_and_codes_only_output(rml, shape):
 
 @pytest.mark.parametrize("shape,share", [((22, 31, 176), 0), ((22, 31, 176), 1), ((22, 31, 160), 0), ((16, 24, 224), 0), ((64, 64, 128), 1),
                                          ((22, 31, 180), 0), ((9, 20, 256), 0), ((32, 32, 64), 1)])
-def test_codes_only_pass_with_the_code_stage(rml, shape, share, monkeypatch):
+def test_codes_only_pass_with_the_code_stage(rml, shape, share, rml_opt):
     """The fused pipelines' first pass on float32 volumes (codes + statistics, no float rows) through the wave-per-frame kernels:
     the xz / xy codes wait in a wave-private LDS stage and leave in one burst per frame (Emitter::stage / flush_wave).  Bit for bit
     NumPy's projections as codes, the statistics, the flags (a frame with a non-integer return is flagged, its codes are whatever),
@@ -427,7 +427,7 @@ def test_codes_only_pass_with_the_code_stage(rml, shape, share, monkeypatch):
     from radar_ml_amd import _lib
     X, Y, Z = shape
     if share:
-        monkeypatch.setenv("RML_WAVE_SHARE", "1")       # the pipeline's configuration: k_project_wave also for rows of 16 / 32 quads
+        rml_opt("project_share_cu", 1)       # the pipeline's configuration: k_project_wave also for rows of 16 / 32 quads
     rng = np.random.default_rng(X * 131 + Z)
     B = 2 * 256 + 77                                    # persistent kernels take batches of >= 2 frames per CU
     vf = rng.integers(0, 256, (B, X, Y, Z)).astype(np.float32)
@@ -445,7 +445,7 @@ def test_codes_only_pass_with_the_code_stage(rml, shape, share, monkeypatch):
     st = torch.cuda.current_stream(dev).cuda_stream
     outs = {}
     for knob, off in (("1", 0), ("0", 0), ("1", 4)):
-        monkeypatch.setenv("RML_STAGE_CODES", knob)
+        rml_opt("stage_codes", int(knob))
         buf = torch.full((B * ldq + 16,), 7, dtype=torch.uint8, device=dev)
         q = buf[off:off + B * ldq].view(B, ldq)
         isum = torch.empty(B, dtype=torch.int32, device=dev); isq = torch.empty(B, dtype=torch.int64, device=dev)
@@ -681,7 +681,7 @@ DERIVE_SHAPES = [(64, 64, 128), (22, 31, 176), (8, 10, 16), (5, 7, 12), (3, 70, 
 
 @pytest.mark.parametrize("shape", DERIVE_SHAPES)
 @pytest.mark.parametrize("nt", [1, 3])
-def test_fused_derive_slice_kernel(rml, shape, nt, monkeypatch):
+def test_fused_derive_slice_kernel(rml, shape, nt, rml_opt):
     """k_derive_slice (csrc/project_slice.hip): DerivedTarget.get_derived_targets (common.py:49-80) and the slices of
     predict.py:102-107 at the derived voxels in ONE pass -- every period P of the column accumulators (Z/4 = 2^a * {1,3,...,15}),
     planes that are not a whole number of load groups, odd frames (the idle group), more frames than resident waves (every wave
@@ -695,7 +695,8 @@ def test_fused_derive_slice_kernel(rml, shape, nt, monkeypatch):
     while zq % 2 == 0 and zq > 0:
         zq //= 2
     fused = zq <= 15                                     # (4,8,132), (3,20,180), (1,24,200): odd part of Z/4 = 33, 45, 25 -> two kernels
-    assert lib.rml_derive_slice_supported(None, 0, X, Y, Z, nt) == int(fused)
+    ctx = rml._lib.context()
+    assert lib.rml_derive_slice_supported(ctx, None, 0, X, Y, Z, nt) == int(fused)
     B = 3000 if X * Y * Z < 30000 else (1300 if X * Y * Z < 200000 else 260)
     rng = np.random.default_rng(X * 7919 + Y * 31 + Z)
     v = _tie_free_volumes(rng, B, X, Y, Z)
@@ -726,8 +727,8 @@ def test_fused_derive_slice_kernel(rml, shape, nt, monkeypatch):
             assert int(isum[r]) == int(raw.astype(np.int64).sum()) and int(isq[r]) == int((raw.astype(np.int64) ** 2).sum())
     assert flags.cpu().numpy().all()
     # the two-kernel path on the same frames
-    monkeypatch.setenv("RML_DERIVE_FUSED", "0")
-    assert lib.rml_derive_slice_supported(None, 0, X, Y, Z, nt) == 0
+    rml_opt("derive_fused", 0)
+    assert lib.rml_derive_slice_supported(ctx, None, 0, X, Y, Z, nt) == 0 and lib.rml_derive_slice_supported(None, None, 0, X, Y, Z, nt) == int(fused)
     ijk_old, prof_old = rml.derive_targets(dv, nt, return_profiles=True)
     np.testing.assert_array_equal(prof_old.cpu().numpy(), prof)
     for ax in range(3):       # same energies (an exact tie may be resolved alike or not: both follow radarml.h, checked below)
@@ -738,7 +739,7 @@ def test_fused_derive_slice_kernel(rml, shape, nt, monkeypatch):
     np.testing.assert_array_equal(ijk_old.cpu().numpy(), ijk)             # the documented tie rule is the same in both
     f_old = rml.process_volumes(dv, mode="slice", num_targets=nt, scale=True)
     assert torch.equal(f_old, feat)
-    monkeypatch.delenv("RML_DERIVE_FUSED")
+    rml_opt("derive_fused", 1)
     # uint8 volumes: identical
     d8 = dv.to(torch.uint8)
     f8, q8, isum8, isq8, fl8, ijk8 = rml.process_volumes(d8, mode="slice", num_targets=nt, scale=True, codes=True, return_ijk=True)
@@ -791,7 +792,7 @@ def test_derive_tie_rule_and_non_integer_data(rml):
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 12), (3, 70, 24), (9, 130, 32), (2, 3, 260), (6, 5, 7)])
-def test_slice_rows_kernel_matches_the_general_kernel(rml, shape, monkeypatch):
+def test_slice_rows_kernel_matches_the_general_kernel(rml, shape, rml_opt):
     """k_slice_rows (one wave per output row: whole-quad loads for xz / yz, four xy cells per lane) against the oracle and
     against the round-1 kernel (RML_SLICE_WAVE=0) -- negative indices, several targets per frame, masks, codes, float32 and
     uint8; (2,3,260) has no whole quads... it has (260 = 65 quads) but (6,5,7) has none and stays on the general kernel."""
@@ -803,7 +804,7 @@ def test_slice_rows_kernel_matches_the_general_kernel(rml, shape, monkeypatch):
     ijk = np.stack([rng.integers(-X, X, (B, T)), rng.integers(-Y, Y, (B, T)), rng.integers(-Z, Z, (B, T))], -1)
     out = {}
     for knob in ("1", "0"):
-        monkeypatch.setenv("RML_SLICE_WAVE", knob)
+        rml_opt("slice_wave", int(knob))
         feat, q, isum, isq, flags = rml.process_volumes(v, mode="slice", ijk=ijk, scale=True, codes=True)
         f8 = rml.process_volumes(v.astype(np.uint8), mode="slice", ijk=ijk, scale=True)
         assert torch.equal(f8, feat)

@@ -279,7 +279,7 @@ def test_fused_multi_chunk_deterministic(rml):
 @pytest.mark.parametrize("name,shape", [("svm_small.npz", (8, 10, 16)), ("svm_walabot.npz", (22, 31, 176))])
 @pytest.mark.parametrize("u8", [False, True])
 @pytest.mark.parametrize("derive", [False, True])
-def test_read_compare_write_of_the_code_rows_changes_nothing(rml, name, shape, u8, derive, monkeypatch):
+def test_read_compare_write_of_the_code_rows_changes_nothing(rml, name, shape, u8, derive, rml_opt):
     """ProjOut::q_rmw (rml_internal.h): the chunk workspaces' code rows are read and only the words that changed are stored.
     Whatever the workspace held -- here the rows of a different batch, of the same batch, and of a batch with frames off the
     code grid -- the outputs are the bits of the plain stores."""
@@ -298,10 +298,10 @@ def test_read_compare_write_of_the_code_rows_changes_nothing(rml, name, shape, u
         batches.append(off)
     kw = dict(mode="slice") if derive else dict(mode="max")      # slice without ijk: the fused derive -> slice -> SVM pass
     want = []
-    monkeypatch.setenv("RML_CODE_RMW", "0")
+    rml_opt("code_rmw", 0)
     for v in batches:
         want.append({k: t.clone() for k, t in svc.decide_volumes(v, proj_mask=mask, scale=True, **kw).items()})
-    monkeypatch.setenv("RML_CODE_RMW", "1")
+    rml_opt("code_rmw", 1)
     for order in ((0, 1, 1, 0), (2, 0, 2) if not u8 else (1, 0)):
         for i in order:
             got = svc.decide_volumes(batches[i], proj_mask=mask, scale=True, **kw)
@@ -546,7 +546,7 @@ def test_pairwise_proba_is_asynchronous_and_needs_platt_coefficients(rml):
 
 
 @pytest.mark.parametrize("name", ["svm_small.npz", "svm_walabot.npz", "svm_small_linear.npz", "svm_small_binary.npz"])
-def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
+def test_large_tile_exact_gemm_matches_the_oracle(rml, name, rml_opt):
     """k_svm_gemm_ring (256 SVs x 256 samples per workgroup, 5-slot operand-stage ring) is what large batches run on; forced
     here (RML_GEMM_BIG=1) on ragged batches: a row count that is no multiple of 256, an SV count that is no multiple of
     256, and -- through the float rows -- sample tiles that are NOT on the code grid, which must fall to the float64
@@ -562,7 +562,7 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
     want = O.svm_decision_ovo(X, m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["kernel"])
     outs = {}
     for big in ("0", "1"):
-        monkeypatch.setenv("RML_GEMM_BIG", big)
+        rml_opt("gemm_big", int(big))
         svc.decision_function_shape = "ovo"
         got = svc.decision_function(X)
         got = got.reshape(len(X), -1)
@@ -580,7 +580,7 @@ def test_large_tile_exact_gemm_matches_the_oracle(rml, name, monkeypatch):
         vol = torch.from_numpy(np.tile(g["test_vol_u8"], (12, 1, 1, 1))[:700].astype(np.float32)).cuda()
         res = {}
         for big in ("0", "1"):
-            monkeypatch.setenv("RML_GEMM_BIG", big)
+            rml_opt("gemm_big", int(big))
             o = svc.decide_volumes(vol, mode="max", scale=True, want_proba=True)
             res[big] = {k: v.cpu().numpy() for k, v in o.items()}
         for k in ("label_vote", "label_calib"):

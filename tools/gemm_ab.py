@@ -5,7 +5,7 @@
     python tools/gemm_ab.py digits --grid 64x64x128 --svs 2562 --frames 16384 [--rounds 3]
 
 exact : code rows -> k_svm_gemm_ring (5-slot operand-stage ring, interleaved DMA issue) vs k_svm_gemm_i8_256 (two 64 KiB
-        stages) vs the 128 x 128 kernel, each as ONE launch over the whole batch (RML_CHUNK pinned to the batch), GEMM + finish.
+        stages) vs the 128 x 128 kernel, each as ONE launch over the whole batch (RML_OPT_CHUNK pinned to the batch), GEMM + finish.
 digits: float rows off the code grid -> RML_PATH_DIGITS (ten int8 digit-plane products) vs RML_PATH_F64 (float64 MFMA),
         row preparation included, plus the largest |dec| difference between the two.
 RML_LIB selects a variant build (e.g. the library-exp() build for the epilogue A/B).
@@ -42,6 +42,7 @@ def main():
     a = ap.parse_args()
     import torch
     import radar_ml_amd as rml
+    from radar_ml_amd import _lib
     X, Y, Z = (int(t) for t in a.grid.split("x"))
     D = rml.feature_len(X, Y, Z)
     M = a.svs
@@ -66,14 +67,15 @@ def main():
             qq = torch.zeros((B, ldq), dtype=torch.uint8, device=dev)
             qq[:, :q.shape[1]] = q[:B]
             qq[:, D:] = 0
-            os.environ["RML_CHUNK"] = str((B + 127) // 128 * 128)
+            _lib.set_option("chunk", (B + 127) // 128 * 128)
             fn = lambda: svc.decide_codes(qq, isum[:B], isq[:B], flags[:B], want_proba=True)
-            arms = {"ring": {"RML_GEMM_BIG": "1"}, "tile128": {"RML_GEMM_BIG": "0"}}       # (the two-stage 256 x 256 arm left the tree in round 4)
+            arms = {"ring": {"gemm_big": 1}, "tile128": {"gemm_big": 0}}       # (the two-stage 256 x 256 arm left the tree in round 4)
             res = {k: [] for k in arms}
             outs = {}
             for r in range(a.rounds):
                 for name, env in arms.items():
-                    os.environ.update(env)
+                    for k_, v_ in env.items():
+                        _lib.set_option(k_, v_)
                     med, mn = timed(torch, fn, a.iters)
                     res[name].append(med)
                     if r == 0:
@@ -98,7 +100,7 @@ def main():
             noise = torch.randn(Xd.shape, device=dev, dtype=torch.float32) * 1e-3
             Xd = Xd + noise * (Xd > 0)
             del noise
-            os.environ["RML_CHUNK"] = str((B + 127) // 128 * 128)
+            _lib.set_option("chunk", (B + 127) // 128 * 128)
             arms = {"digits": "digits", "f64": "f64"}
             res = {k: [] for k in arms}
             outs = {}

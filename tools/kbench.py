@@ -85,14 +85,14 @@ def main():
                 _lib.check(lib.rml_project(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), 255.0, 7, None, 0, q.data_ptr(), qb,
                                            isum.data_ptr(), isq.data_ptr(), flags.data_ptr(), st))
             for knob in ("1", "0"):
-                os.environ["RML_SLICE_WAVE"] = knob
+                _lib.set_option("slice_wave", int(knob))
                 for label, fn, alg in (("f32 rows /255", f_rows, esz * D + 4 * D + 12), ("codes+stats", f_codes, esz * D + D + 16 + 12)):
                     med, mn, _ = timeit(torch, fn, a.iters)
                     rows.append({"what": "slice (ijk given) %s, %s" % (label, "k_slice_rows" if knob == "1" else "k_project_slice (round 1)"),
                                  "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4), "rows_per_s": round(B / med * 1e3),
                                  "alg_bytes_per_row": alg, "alg_GBs": round(B * alg / med / 1e6, 1),
                                  "request_floor_bytes_per_row": floor_rd + (alg - esz * D), "floor_GBs": round(B * (floor_rd + alg - esz * D) / med / 1e6, 1)})
-            os.environ.pop("RML_SLICE_WAVE", None)
+            _lib.set_option("slice_wave", 1)
         else:
             def f_derive():
                 _lib.check(lib.rml_derive_targets(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, st))
@@ -103,15 +103,15 @@ def main():
                 _lib.check(lib.rml_derive_slice(ctx, V.data_ptr(), vdt, B, X, Y, Z, 1, ijk.data_ptr(), None, 255.0, 7, feat.data_ptr(), D, None, 0,
                                                 None, None, None, st))
             for knob in ("1", "0"):
-                os.environ["RML_DERIVE_FUSED"] = knob
-                os.environ["RML_SLICE_WAVE"] = knob
+                _lib.set_option("derive_fused", int(knob))
+                _lib.set_option("slice_wave", int(knob))
                 for label, fn, alg in (("derive only", f_derive, frame + 12), ("derive -> slice, codes+stats", f_fused_codes, frame + 16),
                                        ("derive -> slice, f32 rows", f_fused_rows, frame + 4 * D + 12)):
                     med, mn, _ = timeit(torch, fn, a.iters)
                     rows.append({"what": "%s (%s)" % (label, "k_derive_slice" if knob == "1" else "sum planes + k_profiles_topk + k_project_slice"),
                                  "grid": [X, Y, Z], "B": B, "ms_med": round(med, 4), "ms_min": round(mn, 4), "frames_per_s": round(B / med * 1e3),
                                  "alg_GBs": round(B * alg / med / 1e6, 1), "frac_of_8TBs": round(B * alg / med / 1e6 / 8000, 4)})
-            os.environ.pop("RML_DERIVE_FUSED", None); os.environ.pop("RML_SLICE_WAVE", None)
+            _lib.set_option("derive_fused", 1); _lib.set_option("slice_wave", 1)
         for r in rows:
             print(json.dumps(r))
         return

@@ -43,6 +43,16 @@ static void phase_a_arguments() {
     CHECK(rml_profile_read(nullptr, &n, &d, &n) < 0);
     CHECK(rml_probe_stream(nullptr, &f, 1 << 20, 1, &d, nullptr) < 0);
     CHECK(rml_ctx_set_option(nullptr, RML_OPT_PROJECT_SHARE_CU, 1) < 0);
+    {
+        int v = 0;
+        CHECK(rml_ctx_get_option(nullptr, RML_OPT_CHUNK, &v) < 0 && rml_ctx_reserve_workspace(nullptr, 1 << 20) < 0 && rml_ctx_workspace_bytes(nullptr) == 0);
+        CHECK(rml_dnn_trunk_x3_supported(80, 80) == 1 && rml_dnn_trunk_x3_supported(128, 128) == 0 && rml_dnn_trunk_x3_supported(81, 80) == 0);
+        CHECK(rml_dnn_trunk_x3(nullptr, &f, &f, &f, 1, 80, 80, &f, &f, &f, &f, 2, &f, nullptr) < 0);
+        CHECK(rml_dnn_exact_features_scratch_bytes(RML_VOL_F32, 10, 22, 31, 176, 80, 80, 1) > 10 * 22 * 31 * 176 * 4);
+        CHECK(rml_dnn_exact_features(nullptr, &f, RML_VOL_F32, nullptr, 1, 2, 2, 4, RML_MODE_MAX, 80, 80, &f, &f, &f, &f, 2, &f, 1, &f, nullptr) < 0);
+        CHECK(rml_dnn_top2_gap(nullptr, &f, 3, 1, 3, &f, nullptr) < 0);
+        CHECK(rml_dnn_guard_apply(nullptr, &f, 3, 3, nullptr, 1, &f, 1e-4f, nullptr, nullptr, nullptr, nullptr) < 0);
+    }
     CHECK(rml_svm_free(nullptr, nullptr) == RML_OK && rml_linear_free(nullptr, nullptr) == RML_OK && rml_ctx_destroy(nullptr) == RML_OK);
     CHECK(rml_svm_is_exact(nullptr) == 0 && rml_svm_num_sv(nullptr) == 0 && rml_svm_dim(nullptr) == 0);
     CHECK(rml_ctx_device(nullptr) < 0);
@@ -55,8 +65,8 @@ static void phase_a_arguments() {
             for (int Z = 4; Z <= 260; Z += 36)
                 for (int o : {16, 80, 128}) {
                     (void)rml_dnn_preprocess_supported(X, Y, Z, o, o);
-                    (void)rml_derive_slice_supported(&f, RML_VOL_F32, X, Y, Z, 1);
-                    (void)rml_derive_slice_supported(&f, RML_VOL_U8, X, Y, Z, 3);
+                    (void)rml_derive_slice_supported(nullptr, &f, RML_VOL_F32, X, Y, Z, 1);
+                    (void)rml_derive_slice_supported(nullptr, &f, RML_VOL_U8, X, Y, Z, 3);
                     (void)rml_code_rmw_default(rml_feature_len(X, Y, Z, RML_MASK_ALL), (int64_t)X * Y * Z, X & 1, Y & 1);
                 }
     CHECK(rml_dnn_preprocess_supported(22, 31, 176, 80, 80) == 1);
