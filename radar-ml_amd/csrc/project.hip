@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
 
     const float id = Op<MODE>::ident();
     const float4 id4 = make_float4(id, id, id, id);
-    for (int idx = tid; idx < X * Z; idx += kThreads) xz_lds[idx] = id;
+    for (int idx = tid; idx < X * Z; idx += kThreads) xz_lds[idx] = Op<MODE>::lds_ident();
     __syncthreads();
 
     float4 yz[NM];
@@ -124,8 +124,10 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     __syncthreads();
     // xz and xy from LDS, coalesced
     const int nxz4 = (X * Z) >> 2;
-    for (int idx = tid; idx < nxz4; idx += kThreads)
-        em.put4(0, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xz_lds + idx * 4));
+    for (int idx = tid; idx < nxz4; idx += kThreads) {
+        const float4 q = *reinterpret_cast<const float4*>(xz_lds + idx * 4);         // combined through Op::lds_atomic: its image
+        em.put4(0, (int64_t)idx * 4, make_float4(Op<MODE>::lds_value(q.x), Op<MODE>::lds_value(q.y), Op<MODE>::lds_value(q.z), Op<MODE>::lds_value(q.w)));
+    }
     const int nxy = X * Y;
     const int nxy4 = nxy >> 2;
     for (int idx = tid; idx < nxy4; idx += kThreads)
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
     const QT* __restrict__ Vb = reinterpret_cast<const QT*>(static_cast<const VT*>(a.V) + b * (int64_t)X * Y * Z);
     const float id = Op<MODE>::ident();
     const float4 id4 = make_float4(id, id, id, id);
-    for (int idx = tid; idx < X * Z; idx += T) xz_lds[idx] = id;
-    for (int idx = tid; idx < X * Y; idx += T) xy_lds[idx] = id;
+    for (int idx = tid; idx < X * Z; idx += T) xz_lds[idx] = Op<MODE>::lds_ident();
+    for (int idx = tid; idx < X * Y; idx += T) xy_lds[idx] = Op<MODE>::lds_ident();
     __syncthreads();
 
     float4 yz[NM];
@@ -221,14 +223,15 @@ __global__ __launch_bounds__(1024) void k_project_rowgroup(ProjParams a, int R) 
         if (rv[m]) em.put4(1, (int64_t)j * Z + 4 * kq, yz[m]);
     }
     __syncthreads();
+    auto val4 = [](const float4& q) { return make_float4(Op<MODE>::lds_value(q.x), Op<MODE>::lds_value(q.y), Op<MODE>::lds_value(q.z), Op<MODE>::lds_value(q.w)); };
     const int nxz4 = (X * Z) >> 2;
     for (int idx = tid; idx < nxz4; idx += T)
-        em.put4(0, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xz_lds + idx * 4));
+        em.put4(0, (int64_t)idx * 4, val4(*reinterpret_cast<const float4*>(xz_lds + idx * 4)));
     const int nxy = X * Y;
     const int nxy4 = nxy >> 2;
     for (int idx = tid; idx < nxy4; idx += T)
-        em.put4(2, (int64_t)idx * 4, *reinterpret_cast<const float4*>(xy_lds + idx * 4));
-    for (int idx = nxy4 * 4 + tid; idx < nxy; idx += T) em.put1(2, idx, xy_lds[idx]);
+        em.put4(2, (int64_t)idx * 4, val4(*reinterpret_cast<const float4*>(xy_lds + idx * 4)));
+    for (int idx = nxy4 * 4 + tid; idx < nxy; idx += T) em.put1(2, idx, Op<MODE>::lds_value(xy_lds[idx]));
     em.finish(red);
 }
 
@@ -698,11 +701,6 @@ int launch_project_t(const ProjParams& pp, int mode, int num_cu, hipStream_t st)
     bool fast = false;
     if (mode == RML_MODE_MAX) launch_mode<VT, RML_MODE_MAX>(pp, num_cu, st, &fast);
     else if (mode == RML_MODE_SUM) launch_mode<VT, RML_MODE_SUM>(pp, num_cu, st, &fast);
-    else if (mode == RML_MODE_MAX_NAN) {
-        // NumPy's NaN policy, opt-in: bytes hold no NaN (same kernels as MAX); float volumes take the general kernel
-        if constexpr (sizeof(VT) == 1) launch_mode<VT, RML_MODE_MAX>(pp, num_cu, st, &fast);
-        else hipLaunchKernelGGL((k_project_generic<VT, RML_MODE_MAX_NAN>), dim3((unsigned)pp.B), dim3(kThreads), 0, st, pp);
-    }
     else if (mode == RML_MODE_SLICE) {
         RML_REQUIRE(pp.ijk != nullptr, RML_ERR_INVALID, "rml_project: mode SLICE needs ijk");
         if (!try_launch_slice(pp, (int)sizeof(VT), st))        // rows that are not whole quads: the general kernel
@@ -726,7 +724,7 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame) {
     if (B == 0) return RML_OK;
     RML_REQUIRE(vdtype == RML_VOL_F32 || vdtype == RML_VOL_U8, RML_ERR_INVALID, "rml_project: unknown volume dtype %d", vdtype);
-    if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
+    if (mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // round 6: mode MAX itself has NumPy's NaN policy (the old name stays valid)
     RML_REQUIRE(targets_per_frame == 1 || mode == RML_MODE_SLICE, RML_ERR_INVALID, "rml_project: several targets per frame only in mode SLICE");
     ProjParams pp;
     fill_params(pp, ctx, V, B, X, Y, Z, ijk, o);       // B counts output rows

@@ -32,25 +32,37 @@ struct ProjParams {
 };
 
 template <int MODE> struct Op;
+// Mode MAX is np.max (SURVEY 8 a-1'): a line that holds a NaN gives NaN.  gfx950 has the IEEE-754-2019 `maximum` as ONE instruction
+// (v_maximum3_f32: a NaN operand is the result) -- the same issue slot as v_max_f32 / v_max3_f32 (maxNum: drops the NaN), so NumPy's
+// policy costs the streaming kernels nothing (rounds 1-5 ran maxNum by default and NumPy's rule only in the untuned RML_MODE_MAX_NAN).
+// The cross-wave LDS combine of k_project_fast / k_project_rowgroup cannot use ds_max_f32 (maxNum again): it runs ds_max_u32 on an
+// order-preserving key of the float -- every NaN maps to the largest key.
 template <> struct Op<RML_MODE_MAX> {
     static __device__ __forceinline__ float ident() { return -INFINITY; }
-    static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float f(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+    static __device__ __forceinline__ uint32_t key(float v) {
+        const uint32_t b = __float_as_uint(v);
+        const uint32_t k = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);      // negative: ~b; non-negative: b | sign bit
+        return v != v ? 0xFFFFFFFFu : k;
+    }
+    static __device__ __forceinline__ float lds_ident() { return __uint_as_float(key(-INFINITY)); }
+    static __device__ __forceinline__ float lds_value(float stored) {            // what the LDS image holds -> the float it stands for
+        const uint32_t k = __float_as_uint(stored);
+        const uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+        return k == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : __uint_as_float(b);
+    }
     static __device__ __forceinline__ void lds_atomic(float* p, float v) {
-        __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(reinterpret_cast<uint32_t*>(p), key(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 template <> struct Op<RML_MODE_SUM> {
     static __device__ __forceinline__ float ident() { return 0.0f; }
     static __device__ __forceinline__ float f(float a, float b) { return a + b; }
+    static __device__ __forceinline__ float lds_ident() { return 0.0f; }
+    static __device__ __forceinline__ float lds_value(float stored) { return stored; }
     static __device__ __forceinline__ void lds_atomic(float* p, float v) {
         __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-};
-
-// np.max: a NaN anywhere in the line is the result (the first one met; every NaN compares unequal to itself)
-template <> struct Op<RML_MODE_MAX_NAN> {
-    static __device__ __forceinline__ float ident() { return -INFINITY; }
-    static __device__ __forceinline__ float f(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 };
 
 template <int MODE> __device__ __forceinline__ float4 op4(float4 a, float4 b) {
@@ -326,13 +338,13 @@ template <int J> __device__ __forceinline__ float park_lane(float acc, float uni
     return acc;
 }
 
-// max without the v_max_f32 x,x "canonicalise" copy hipcc puts in front of every fmaxf of a loaded value (IEEE mode: it
-// would quiet a signalling NaN; v_max_f32 itself already returns the other operand for ANY NaN, which is the documented NaN
-// policy of the max-projection).  4 VALU less per row of the streaming loop.
+// max as ONE instruction on a loaded value: hipcc puts a v_max_f32 x,x "canonicalise" copy in front of every fmaxf / maximum of a
+// loaded value (IEEE mode: it would quiet a signalling NaN).  v_maximum3_f32 d, a, b, b is the IEEE-754-2019 maximum itself: a NaN
+// operand -- quiet or signalling -- is the result (np.max).  4 VALU less per row of the streaming loop.
 template <int MODE> __device__ __forceinline__ float op_raw(float a, float b) {
     if constexpr (MODE == RML_MODE_MAX) {
         float r;
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(a), "v"(b));
         return r;
     } else
     {

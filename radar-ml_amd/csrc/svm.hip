@@ -1741,7 +1741,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
                 (long long)rml_feature_len(X, Y, Z, mask), (long long)m->D);
     RML_REQUIRE(!(proba || label_calib) || m->has_calib, RML_ERR_STATE, "rml_project_svm: model has no calibrators");
     RML_REQUIRE(mode != RML_MODE_SLICE || ijk || derive, RML_ERR_INVALID, "rml_project_svm: mode SLICE needs ijk");
-    if (vdtype == RML_VOL_U8 && mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // a byte is never a NaN
+    if (mode == RML_MODE_MAX_NAN) mode = RML_MODE_MAX;         // round 6: mode MAX itself has NumPy's NaN policy
     // the code grid of the features must be the model's: codes are the unscaled values
     const bool scaled = scale_div > 1.0f;
     const bool grid_ok = m->exact && ((scaled && (double)scale_div == m->code_scale) || (!scaled && m->code_scale == 1.0));

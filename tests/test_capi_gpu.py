@@ -421,7 +421,8 @@ def test_entry_points_capture_into_a_hip_graph_after_a_warm_up(rml):
     ctx = _lib.context()
     dnn = importlib.import_module("radar_ml_amd.dnn")
     g = load_golden("svm_walabot.npz")
-    svc = rml.GpuSVC(**svm_model_arrays(g), device="cuda")
+    m = svm_model_arrays(g)
+    svc = rml.GpuSVC(m["sv"], m["dual_coef"], m["intercept"], m["n_support"], m["gamma"], m["classes"], calib_a=m["calib_a"], calib_b=m["calib_b"])
     torch.manual_seed(3)
     model = dnn.define_classifier(device="cuda").eval()
     B = 3000

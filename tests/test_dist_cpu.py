@@ -62,6 +62,28 @@ def test_two_rank_gloo_sharding_matches_single_process(n_frames):
         np.testing.assert_array_equal(probs, wantp)
 
 
+def test_eight_rank_gloo_sharding_with_ragged_slabs():
+    """The world size the driver's scaling run ends at: 8 ranks, 37 frames (slabs of 5 and 4), labels and a (frames, 3) array gathered
+    in frame order on every rank."""
+    world, n_frames = 8, 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _fake_classify(_make(0, n_frames)).numpy()
+    wantp = _make(0, n_frames).reshape(-1, 24)[:, :3].numpy()
+    assert sorted(r for r, _, _ in res) == list(range(world))
+    for rank, got, probs in res:
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(probs, wantp)
+
+
 def test_shard_range_partitions():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

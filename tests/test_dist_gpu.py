@@ -72,6 +72,43 @@ def test_two_rank_bench_on_one_device_matches_the_single_process_run():
     assert l2["config"]["collective_backend"] == "gloo"
 
 
+def test_eight_rank_bench_on_one_device_dry_run():
+    """N = 8 without the hardware: `python bench.py --gpus 8` starting its own eight ranks on ONE device (gloo), against the
+    single-process run of the same global batch -- so that the driver's first 8-GPU run is not also the first 8-rank run of the
+    control flow (model broadcast, eight slabs, label all-gather, general rows, CNN row, SGAN replicas with graph replay and the
+    flat-bucket all-reduce).  No rate is asked of it."""
+    per_rank, world = 512, 8
+    common = ["--steps", "1", "--warmup", "1", "--train", "1500", "--no-cpu", "--no-pmc", "--no-u8", "--no-slice", "--parity", "128",
+              "--general-frames", "256", "--dnn-frames", "256", "--dnn-parity", "32", "--dnn-train-steps", "40"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RML_BENCH_ONE_DEVICE", None)
+    import tempfile
+    env["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="rml_miopen_db_")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", str(world * per_rank),
+                          "--walabot-frames", str(world * 2 * per_rank)] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=1500)
+    assert one.returncode == 0, one.stderr.decode()[-3000:]
+    l1 = _line(one.stdout.decode())
+    env8 = dict(env, RML_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env8.pop(k, None)
+    eight = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--frames", str(per_rank),
+                            "--walabot-frames", str(2 * per_rank)] + common, cwd=ROOT, env=env8, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=2400)
+    assert eight.returncode == 0, eight.stderr.decode()[-3000:]
+    l8 = _line(eight.stdout.decode())
+    assert l8["n_gpus"] == world and l8["config"]["collective_backend"] == "gloo" and l8["scaling"] == "weak"
+    assert l8["config"]["global_frames"] == world * per_rank == l1["config"]["global_frames"]
+    assert l8["labels_crc32"] == l1["labels_crc32"]                                                     # eight slabs, gathered in frame order
+    assert l8["doc"]["walabot_grid"]["labels_crc32"] == l1["doc"]["walabot_grid"]["labels_crc32"]
+    assert l8["summary"]["parity_gate"] == "pass" and l1["summary"]["parity_gate"] == "pass"
+    sg = l8["doc"]["sgan_train_step"]
+    assert "error" not in sg, sg
+    assert sg["replicas_identical"] is True and sg["n_gpus"] == world
+    assert l8["doc"]["dnn_forward"]["parity"]["label_mismatch"] == 0
+    assert l8["roofline"].get("traffic") is None
+
+
 def _check_pair(l1, l2, per_rank):
     """l1: the single-process line of the global batch, l2: the two-rank line (_line attaches the verbose rows under "doc")."""
     assert l2["n_gpus"] == 2 and l2["config"]["global_frames"] == 2 * per_rank == l1["config"]["global_frames"]
