@@ -53,23 +53,22 @@ typedef struct rml_svm rml_svm;
 typedef struct rml_linear rml_linear;
 
 /* projection modes */
-#define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V.
-                              NaN policy (a pinned deviation from SURVEY 8 a-1', which defines it "as NumPy"): np.max propagates a
-                              NaN, this mode IGNORES it (IEEE maxNum: v_max_f32 / ds_max_f32), i.e. it equals np.fmax.reduce, and a
-                              line of nothing but NaN gives -inf.  Radar magnitudes are integers 0..255 (common.py:30-31): the
-                              reference path never meets one; tests/test_projection_gpu.py pins the behaviour of every kernel.
-                              RML_MODE_MAX_NAN below is the NumPy-faithful variant */
+#define RML_MODE_MAX   0   /* BASELINE-named max-projection: xz=max_j V, yz=max_i V, xy=max_k V -- np.max, NaN policy included
+                              (SURVEY 8 a-1'): a line that holds a NaN gives NaN (round 6: gfx950's IEEE-754-2019 maximum,
+                              v_maximum3_f32, in every kernel family at the cost of the maxNum instruction it replaced; rounds 1-5
+                              ignored NaNs here).  Radar magnitudes are integers 0..255 (common.py:30-31): the reference path never
+                              meets one; tests/test_projection_gpu.py pins the behaviour of every kernel. */
 #define RML_MODE_SLICE 1   /* reference-faithful plane slices through (i,j,k): predict.py:102-107       */
 #define RML_MODE_SUM   2   /* sum-projection (the reductions of common.py:51-53), float32 accumulation  */
-#define RML_MODE_MAX_NAN 3 /* the max-projection with NumPy's NaN policy (SURVEY 8 a-1'): a line that holds a NaN gives NaN, like
-                              np.max.  Opt-in and not tuned: every shape runs on the general kernel (three passes over a frame, the
-                              second and third from L2); uint8 volumes cannot hold a NaN and take the RML_MODE_MAX kernels.  A row with
-                              a NaN is off the code grid, so the SVM front doors score it on the float64 path -- where the NaN does
-                              NOT survive: the RBF epilogue clamps the squared distance with "d2 > 0 ? d2 : 0", which maps NaN to 0,
-                              so every kernel value of the row is 1 and its decision values are the finite, meaningless
-                              sum of the pair weights + intercept (scikit-learn raises ValueError on such a row instead).  Callers
-                              that may meet NaNs must test the projections themselves; pinned by
-                              tests/test_svm_gpu.py::test_nan_row_through_the_svm_is_finite_and_documented */
+#define RML_MODE_MAX_NAN 3 /* = RML_MODE_MAX since round 6 (kept for callers of rounds 3-5, when NumPy's NaN policy was this opt-in
+                              mode on an untuned kernel).
+                              Non-finite rows and the SVM: a row with a NaN is off the code grid, so the asynchronous front doors
+                              (rml_svm_decision, rml_project_svm) score it on the float64 path, whose RBF epilogue clamps the squared
+                              distance with "d2 > 0 ? d2 : 0" -- the row's decision values are finite and meaningless; rows next to
+                              it are untouched.  The reference raises instead (predict.py:60 -> sklearn validate_data): the
+                              sklearn-protocol classes of radar-ml_amd/svm.py test their input rows and raise the same ValueError
+                              (tests/test_svm_gpu.py::test_nan_row_through_the_svm_raises_like_scikit_learn); callers of the bare ABI
+                              that may meet NaNs test the row flags / projections themselves. */
 
 /* element type of the volumes */
 #define RML_VOL_F32    0

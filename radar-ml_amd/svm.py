@@ -40,8 +40,12 @@ def _detect_code_scale(sv):
 class _Base:
     classes_ = None
 
-    def _rows(self, X):
-        """Accept numpy or torch, any real dtype -> (N,D) float32 CUDA tensor."""
+    def _rows(self, X, check_finite=True):
+        """Accept numpy or torch, any real dtype -> (N,D) float32 CUDA tensor.  ``check_finite`` (the sklearn-protocol methods):
+        scikit-learn's own input validation -- ``clf.predict`` of predict.py:60 goes through ``validate_data`` and raises
+        ValueError on a NaN or an infinity; so do the GPU twins (one reduction pass over the rows on the device; these methods
+        hand NumPy arrays back and synchronise anyway).  The tensor-in / tensor-out entries (``_decide``, ``decide_volumes``) stay
+        asynchronous and do not check."""
         torch = _torch()
         if not isinstance(X, torch.Tensor):
             X = np.asarray(X)
@@ -51,7 +55,10 @@ class _Base:
             raise ValueError("X has %d features, but %s is expecting %d features as input."
                              % (X.shape[1], type(self).__name__, self.n_features_in_))
         # rows go to the model's device (its buffers and its context live there), whatever the current device is
-        return _as_device_f32(X, getattr(self, "_dev", None))
+        Xd = _as_device_f32(X, getattr(self, "_dev", None))
+        if check_finite and Xd.numel() and not bool(torch.isfinite(Xd).all()):
+            raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")      # sklearn's message
+        return Xd
 
 
 MAX_CLASSES = 6         # kMaxC of csrc/svm.hip (15 one-vs-one pairs)

@@ -559,31 +559,40 @@ def test_slices_for_several_targets_per_frame(rml):
 
 @pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 9), (7, 37, 160)])
 def test_nan_policy_of_the_max_projection_is_pinned(rml, shape):
-    """Documented deviation: NumPy's max PROPAGATES NaN, the hardware maximum (v_max_f32 / ds_max_f32, IEEE
-    maxNum) IGNORES it -- the result is np.fmax.reduce, and a line that holds nothing but NaN gives -inf (the identity).
-    Radar magnitudes are integers 0..255 (common.py:30-31), so the reference path never meets one; the policy is pinned here
-    for every kernel family (fast / wave-per-frame / generic / row-group)."""
+    """SURVEY 8 a-1': the max-projection's NaN policy is NumPy's -- np.max PROPAGATES a NaN.  Round 6: mode "max" itself does so, in
+    every kernel family (fast with its ordered-key LDS combine / wave-per-frame / linear-plane / generic / row-group), on
+    gfx950's IEEE-754-2019 maximum (v_maximum3_f32) at the cost of the maxNum instruction it replaces; rounds 1-5 ran maxNum
+    (np.fmax.reduce) by default.  A line of nothing but NaN is NaN, a line without one is its maximum, bit for bit."""
     X, Y, Z = shape
     rng = np.random.default_rng(9)
     B = 520 if shape == (22, 31, 176) else 3           # >= 512 frames: the persistent wave-per-frame kernel takes the launch
     v = (rng.standard_normal((B, X, Y, Z)) * 20).astype(np.float32)
-    v[rng.random(v.shape) < 0.05] = np.nan
+    v[rng.random(v.shape) < 0.002] = np.nan
     v[1, :, 0, 0] = np.nan                     # a whole line of the yz plane of frame 1
+    v[2] = np.nan_to_num(v[2])                 # one frame without any NaN
+    v[0, 0, 0, 1] = -np.nan                    # a NaN with its sign bit set, and a signalling one
+    v.view(np.uint32)[0, 1, 1, 1] = 0xFF800001
     got = rml.project(v, mode="max")
     with np.errstate(invalid="ignore"):
-        want = [np.fmax.reduce(v, axis=2), np.fmax.reduce(v, axis=1), np.fmax.reduce(v, axis=3)]
-    want = [np.where(np.isnan(w), -np.inf, w) for w in want]
+        want = O.project_max(v)                # np.max
     for g, w in zip(got, want):
-        assert not np.isnan(g).any()
-        np.testing.assert_array_equal(g, w)
-    assert got[1][1, 0, 0] == -np.inf
+        assert np.isnan(w).any() and not np.isnan(w[2]).any()
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(w))
+        np.testing.assert_array_equal(np.nan_to_num(g, nan=-1e30), np.nan_to_num(w, nan=-1e30))
+    assert np.isnan(got[1][1, 0, 0])
+    # the same through the rows (scaled) and their code-grid flags: a row with a NaN is off the grid
+    rows, q, isum, isq, flags = rml.process_volumes(v[:3], mode="max", scale=True, codes=True)
+    with np.errstate(invalid="ignore"):
+        ref = np.stack([np.concatenate([(w[b] / np.float32(255.0)).ravel() for w in want]) for b in range(3)])
+    np.testing.assert_array_equal(np.isnan(rows.cpu().numpy()), np.isnan(ref))
+    assert not flags.cpu().numpy()[:2].any()
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 128), (22, 31, 176), (5, 7, 9), (7, 37, 160)])
 def test_max_nan_mode_has_numpys_nan_policy(rml, shape):
-    """RML_MODE_MAX_NAN (include/radarml.h; SURVEY 8 a-1' defines the policy "as NumPy"): np.max bit for bit, NaN positions
-    included -- through ``project``, through ``process_volumes`` (scaled rows) and, for uint8 volumes (no NaN possible),
-    identical to mode 'max'."""
+    """RML_MODE_MAX_NAN (include/radarml.h; SURVEY 8 a-1' defines the policy "as NumPy"; since round 6 an alias of mode MAX, which
+    has that policy itself): np.max bit for bit, NaN positions included -- through ``project``, through ``process_volumes``
+    (scaled rows) and, for uint8 volumes (no NaN possible), identical to mode 'max'."""
     X, Y, Z = shape
     rng = np.random.default_rng(19)
     B = 3

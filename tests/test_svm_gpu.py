@@ -666,26 +666,30 @@ def test_fused_front_door_edge_batch_sizes(rml, u8):
             assert torch.equal(part[k], whole[k][8193 - n:]), (k, n)
 
 
-def test_nan_row_through_the_svm_is_finite_and_documented(rml):
-    """include/radarml.h (RML_MODE_MAX_NAN): a feature row that holds a NaN is off the code grid and is scored on the float64 path,
-    whose RBF epilogue clamps the squared distance with "d2 > 0 ? d2 : 0" -- NaN becomes 0, every kernel value of the row is 1,
-    and the decision values are the finite sum of the pair weights + intercept (scikit-learn raises ValueError on such a row).
-    Pinned here so that a change of the epilogue shows up: the row's scores are finite and equal W.1 + intercept, and the rows
-    next to it are untouched."""
+def test_nan_row_through_the_svm_raises_like_scikit_learn(rml):
+    """predict.py:60 -> clf.predict -> sklearn's validate_data: a row that holds a NaN or an infinity raises ValueError("Input contains
+    NaN ...").  The sklearn-protocol methods of the three GPU twins do the same (round 5 returned finite garbage for such a row);
+    the array-in / tensor-out entry (_decide, the fused decide_volumes) stays asynchronous and documents what it returns instead:
+    the row is off the code grid, runs on the float64 path, and the rows next to it are untouched."""
     g = load_golden("svm_walabot.npz")
     svc, m = _model(rml, g)
     X = (g["test_feat_u8"][:9].astype(np.float32) / np.float32(255.0))
     clean = svc.decision_function(X)
     Xn = X.copy()
     Xn[4, 123] = np.nan
+    Xi = X.copy()
+    Xi[2, 7] = np.inf
     import sklearn.svm
     with pytest.raises(ValueError):
         sklearn.svm.SVC().fit(X[:4], [0, 1, 0, 1]).predict(Xn)         # the reference library refuses the row
-    ovo, ovr, vote, proba, lab = svc._decide(svc._rows(Xn), want_proba=True)
-    ovo = ovo.cpu().numpy()
-    assert np.isfinite(ovo).all()
-    W = O.ovo_weight_matrix(m["dual_coef"], m["n_support"])             # (P, M): the pair weights of libsvm's loop
-    np.testing.assert_allclose(ovo[4], W.sum(1) + m["intercept"], rtol=0, atol=1e-9)
+    cal = rml.GpuCalibratedClassifier(svc)
+    lin = rml.GpuLinearClassifier(np.zeros((3, X.shape[1])), np.zeros(3), np.arange(3))
+    for bad in (Xn, Xi):
+        for fn in (svc.predict, svc.decision_function, cal.predict, cal.predict_proba, lin.predict, lin.decision_function):
+            with pytest.raises(ValueError, match="Input contains NaN"):
+                fn(bad)
+    np.testing.assert_array_equal(svc.decision_function(X), clean)      # ... and clean rows still pass
+    ovo, ovr, vote, proba, lab = svc._decide(svc._rows(Xn, check_finite=False), want_proba=True)
     keep = [r for r in range(9) if r != 4]
     # (the tile holding the NaN row runs on the float64 kernel as a whole: its other rows agree with the exact path to rounding)
     np.testing.assert_allclose(ovr.cpu().numpy()[keep], clean[keep], rtol=0, atol=1e-6)
