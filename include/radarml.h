@@ -450,6 +450,17 @@ int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld_feat, int 
                        const float* w2t, const float* b2, const float* w3, const float* b3, int n_classes, float* workspace,
                        int64_t workspace_bytes, float* proba, void* stream);
 
+/* The same tail on FLOAT32 feature rows (feat [N][ld_feat], w1 [64][K] float32 in torch's Linear layout, the other operands as
+ * above): the last stage of the margin guard's re-scoring (radar-ml_amd/dnn.py Classifier._tail_float32; Keras runs these layers in
+ * float32, dnn.py:78-88).  Its result for a row depends on that row alone -- the K axis is cut into splits that are a function of
+ * K only, every partial sum is one fma chain in ascending k, the splits are added in order -- so a row scored alone, inside any
+ * candidate set, or twice has the same bits (a library float32 GEMM that splits K with atomics does not).  K and ld_feat multiples
+ * of 4; workspace: rml_dnn_dense_tail_f32_workspace_bytes(N, K) bytes, 16-byte aligned. */
+int64_t rml_dnn_dense_tail_f32_workspace_bytes(int64_t N, int64_t K);
+int rml_dnn_dense_tail_f32(rml_ctx* ctx, const float* feat, int64_t ld_feat, int64_t N, int64_t K, const float* w1, const float* b1,
+                           const float* w2t, const float* b2, const float* w3, const float* b3, int n_classes, float* workspace,
+                           int64_t workspace_bytes, float* proba, void* stream);
+
 /* ---- SGAN discriminator branches: fused BatchNorm(train) + LeakyReLU + 'same' pad (sgan.py:137-158) -------------
  * x: N x H x W x C (NHWC, dense) float16 (dtype 0) or bfloat16 (dtype 1), the convolution output; y: N x (H+pad_h) x
  * (W+pad_w) x C, the zero-padded input of the next stride-2 'same' convolution (pad 0: plain output).  Batch

@@ -97,6 +97,9 @@ SIGNATURES = {
     "rml_dnn_dense_workspace_bytes": (c_int64, [c_void_p, c_int64, c_int64]),
     "rml_dnn_dense_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rml_dnn_dense_tail_f32_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "rml_dnn_dense_tail_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "rml_bn_workspace_floats": (c_int64, [c_void_p, c_int]),
     "rml_bn_lrelu_pad_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

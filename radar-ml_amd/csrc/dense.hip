@@ -248,6 +248,92 @@ __global__ __launch_bounds__(256) void k_dense_finish(FinishArgs a) {
     }
 }
 
+// ---- the first dense layer on float32 feature rows (the margin guard's re-scoring tail: dnn.py Classifier._tail_float32) ------------
+// What the guard needs from it is a result that is a function of the ROW alone: hipBLASLt's float32 GEMM for (a few hundred rows) x
+// 38 400 x 64 splits K with atomics -- the same call twice gave probabilities 1e-7 apart, and a row scored alone or inside a larger
+// candidate set 7e-7 apart (session r6b) -- so "the same call again: the same bits" did not hold with the guard on.  Here the K
+// axis is cut into splits of kF32Split elements whatever the batch (a function of K only); a workgroup takes 128 rows x 64 units x
+// one split, a wave 32 rows x 64 units on v_mfma_f32_32x32x2_f32 (float32 operands, float32 accumulation: the arithmetic class Keras
+// runs these layers in), and an output element's sum runs over its split in ONE fixed order -- K-steps of 32 ascending; inside a
+// step the instruction t = 0..15 adds the pair (k0 + t, k0 + 16 + t) -- that no other row takes part in; k_dense_finish adds the
+// splits in order.  No LDS and no barrier: a lane's operands are the 64 contiguous bytes of ITS row (lane half h: k0 + 16 h ..) and
+// of its two weight rows, loaded as four 16-byte pieces each, one K-step ahead in registers; per row and step a whole 128-byte
+// line.  (The first version -- 4 x 4 register tiles on the vector ALU out of LDS tiles -- ran at 26 TFLOP/s: 3.1 ms per 16 384 rows
+// against 3.4 for the float32-class trunk in front of it, session r6c.)
+constexpr int kF32Split = 2560, kF32Step = 32;
+
+struct Fc1F32Args {
+    const float* x; int64_t ldx;        // float32 rows, ldx floats apart
+    int64_t N, K;
+    const float* w; int64_t ldw;        // [64][K] float32 (torch Linear layout)
+    int S;                              // splits = ceil(K / kF32Split)
+    float* partial;                     // [S][N][64]
+};
+
+__global__ __launch_bounds__(256) void k_fc1_f32(Fc1F32Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x / a.S, s = blockIdx.x - tile * a.S;
+    const int64_t r0 = (int64_t)tile * 128 + 32 * wave;       // the wave's 32 rows
+    const int64_t k0 = (int64_t)s * kF32Split;
+    const int64_t k1 = a.K < k0 + kF32Split ? a.K : k0 + kF32Split;
+    const int n = lane & 31, h = lane >> 5;
+    int64_t row = r0 + n;
+    row = row < a.N ? row : a.N - 1;                          // rows past the batch re-read the last one; nothing of them is stored
+    const float* __restrict__ xp = a.x + row * a.ldx + 16 * h;
+    const float* __restrict__ wp0 = a.w + (int64_t)n * a.ldw + 16 * h;
+    const float* __restrict__ wp1 = a.w + (int64_t)(n + 32) * a.ldw + 16 * h;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    v16f acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float4 xa[4], wa[4], wb[4];
+    // K and the split are multiples of 4: a 16-byte piece is inside or outside [k0, k1) as a whole.  The loads are unconditional (a
+    // piece outside re-reads the split's first); what they returned is replaced by zeros on both sides when the step USES it -- a
+    // select behind the load would make the wave wait for its prefetch before the matrix instructions it should run under
+    auto fetch = [&](int64_t kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t kk = kb + 4 * q;
+            const int64_t kc = (kk + 16 * h < k1) ? kk : k0;
+            xa[q] = *reinterpret_cast<const float4*>(xp + kc);
+            wa[q] = *reinterpret_cast<const float4*>(wp0 + kc);
+            wb[q] = *reinterpret_cast<const float4*>(wp1 + kc);
+        }
+    };
+    fetch(k0);
+    for (int64_t kb = k0; kb < k1; kb += kF32Step) {
+        float4 xc[4], wc[4], wd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = kb + 4 * q + 16 * h < k1;
+            xc[q] = in ? xa[q] : z4; wc[q] = in ? wa[q] : z4; wd[q] = in ? wb[q] : z4;
+        }
+        fetch(kb + kF32Step < k1 ? kb + kF32Step : k0);      // the next step's operands are in flight under this step's 32 MFMAs
+        __builtin_amdgcn_sched_barrier(0);                    // ... and stay there: no wait for them is needed before the loop's next trip
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xv[4] = {xc[q].x, xc[q].y, xc[q].z, xc[q].w};
+            const float wv[4] = {wc[q].x, wc[q].y, wc[q].z, wc[q].w};
+            const float wu[4] = {wd[q].x, wd[q].y, wd[q].z, wd[q].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[c], wv[c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[c], wu[c], acc1, 0, 0, 0);
+            }
+        }
+    }
+    // D[row of A = sample (r & 3) + 8 (r >> 2) + 4 h][column of B = unit n]: a lane half writes 32 consecutive units of one sample
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t smp = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (smp < a.N) {
+            float* dst = a.partial + ((int64_t)s * a.N + smp) * kHidden + n;
+            dst[0] = acc0[r];
+            dst[32] = acc1[r];
+        }
+    }
+}
+
 int pick_splits(int64_t tiles, int KT, int num_cu) {
     // one round of three workgroups per CU where the K extent allows it; K-steps per split as even as possible
     int64_t s = ((int64_t)3 * num_cu + tiles - 1) / tiles;
@@ -294,6 +380,41 @@ extern "C" int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld
     fa.steps = (fa.KT + fa.S - 1) / fa.S;
     fa.partial = workspace;
     hipLaunchKernelGGL(k_fc1_splitk, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
+    FinishArgs fi{};
+    fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
+    const int64_t blocks = (N + 3) / 4;
+    hipLaunchKernelGGL(k_dense_finish, dim3((unsigned)(blocks < 2 * ctx->num_cu ? blocks : 2 * ctx->num_cu)), dim3(256), 0, st, fi);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+extern "C" int64_t rml_dnn_dense_tail_f32_workspace_bytes(int64_t N, int64_t K) {
+    if (N <= 0 || K <= 0) return 0;
+    return ((K + kF32Split - 1) / kF32Split) * N * kHidden * (int64_t)sizeof(float);
+}
+
+extern "C" int rml_dnn_dense_tail_f32(rml_ctx* ctx, const float* feat, int64_t ld_feat, int64_t N, int64_t K, const float* w1, const float* b1,
+                                      const float* w2t, const float* b2, const float* w3, const float* b3, int n_classes, float* workspace,
+                                      int64_t workspace_bytes, float* proba, void* stream) {
+    RML_REQUIRE(ctx && N >= 0 && K > 0, RML_ERR_INVALID, "rml_dnn_dense_tail_f32: bad arguments");
+    RML_REQUIRE(K % 4 == 0 && ld_feat >= K && ld_feat % 4 == 0, RML_ERR_UNSUPPORTED,
+                "rml_dnn_dense_tail_f32: K = %lld and ld_feat must be multiples of 4", (long long)K);
+    RML_REQUIRE(n_classes >= 1 && n_classes <= 16, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail_f32: 1..16 classes");
+    if (N == 0) return RML_OK;
+    RML_REQUIRE(feat && w1 && b1 && w2t && b2 && w3 && b3 && workspace && proba, RML_ERR_INVALID, "rml_dnn_dense_tail_f32: NULL argument");
+    RML_REQUIRE(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+                RML_ERR_INVALID, "rml_dnn_dense_tail_f32: feat, w1 and the workspace need 16-byte alignment");
+    RML_REQUIRE(N < (int64_t)1 << 31 && K < (int64_t)1 << 30, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail_f32: too large");
+    RML_REQUIRE(workspace_bytes >= rml_dnn_dense_tail_f32_workspace_bytes(N, K), RML_ERR_INVALID, "rml_dnn_dense_tail_f32: workspace too small");
+    RML_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Fc1F32Args fa{};
+    fa.x = feat; fa.ldx = ld_feat; fa.N = N; fa.K = K; fa.w = w1; fa.ldw = K;
+    fa.S = (int)((K + kF32Split - 1) / kF32Split);
+    fa.partial = workspace;
+    const int64_t tiles = (N + 127) / 128;
+    RML_REQUIRE(tiles * fa.S < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail_f32: too large");
+    hipLaunchKernelGGL(k_fc1_f32, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
     FinishArgs fi{};
     fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
     const int64_t blocks = (N + 3) / 4;

@@ -619,10 +619,32 @@ class Classifier(_module_base()):
         return torch.softmax(F.linear(h, w3, b3), dim=-1)
 
     def _tail_float32(self, fv):
-        """Dense 64 relu, Dense 64 relu, Dense n softmax in float32 on float32 feature rows (no dropout: inference)."""
+        """Dense 64 relu, Dense 64 relu, Dense n softmax in float32 on float32 feature rows (no dropout: inference).  CUDA rows
+        (two hidden layers of 64 units, <= 16 classes, K % 4 == 0): csrc/dense.hip rml_dnn_dense_tail_f32 -- a row's result depends
+        on that row alone (fixed K splits, one fma chain each, added in order), so a row re-scored alone, inside any candidate set
+        or twice has the same bits; hipBLASLt's float32 GEMM for these shapes splits K with atomics and does not (session r6b:
+        the same call twice 1e-7 apart).  Other shapes / CPU tensors: the plain PyTorch layers."""
         import torch
         import torch.nn.functional as F
         (w1, b1), (w2, b2), (w3, b3) = self._exact_weights(torch.float32)["fc"]
+        if (fv.is_cuda and fv.dtype == torch.float32 and fv.ndim == 2 and fv.stride(1) == 1 and fv.shape[1] % 4 == 0 and fv.stride(0) % 4 == 0
+                and fv.data_ptr() % 16 == 0 and tuple(w1.shape) == (64, int(fv.shape[1])) and tuple(w2.shape) == (64, 64) and self.n_classes <= 16):
+            from . import _lib
+            lib = _lib.load()
+            dev, n, K = fv.device, int(fv.shape[0]), int(fv.shape[1])
+            out = torch.empty((n, self.n_classes), dtype=torch.float32, device=dev)
+            if n == 0:
+                return out
+            self._tail_weights()
+            bb1, w2t, bb2, w3f, bb3 = self._tail_f32
+            nbytes = int(lib.rml_dnn_dense_tail_f32_workspace_bytes(n, K))
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+            w1c = w1 if w1.is_contiguous() else w1.contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(lib.rml_dnn_dense_tail_f32(_lib.context(dev), _lib.ptr(fv), int(fv.stride(0)), n, K, _lib.ptr(w1c), _lib.ptr(bb1),
+                                                      _lib.ptr(w2t), _lib.ptr(bb2), _lib.ptr(w3f), _lib.ptr(bb3), self.n_classes, _lib.ptr(ws),
+                                                      nbytes, _lib.ptr(out), _lib.stream_ptr(dev)), "rml_dnn_dense_tail_f32")
+            return out
         h = F.relu(F.linear(fv, w1, b1))
         h = F.relu(F.linear(h, w2, b2))
         return torch.softmax(F.linear(h, w3, b3), dim=-1)

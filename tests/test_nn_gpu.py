@@ -182,6 +182,55 @@ def test_dnn_trained_model_labels_match_the_oracle_on_every_row(rml):
     np.testing.assert_array_equal(got_h, got)
 
 
+def test_float32_tail_is_a_function_of_the_row(rml):
+    """csrc/dense.hip rml_dnn_dense_tail_f32 (the margin guard's re-scoring tail): the probabilities of a row do not depend on the
+    rows scored with it (alone, a prefix, the whole set, ragged counts), nor on the call (twice: the same bits) -- what a library
+    float32 GEMM that splits K with atomics does not give (session r6b) -- and they are float32-class: within 2e-6 of the float64
+    layers on the same float32 rows and weights.  Error paths of the entry point through the raw ABI."""
+    import ctypes as C
+    dnn = importlib.import_module("radar_ml_amd.dnn")
+    _lib = importlib.import_module("radar_ml_amd._lib")
+    torch.manual_seed(11)
+    m = dnn.define_classifier(device="cuda").eval()
+    with torch.no_grad():
+        for fc in (m.fc1, m.fc2, m.fc3):
+            fc.bias.normal_(0.0, 0.1)
+        K = m.flat_features
+        fv = torch.relu(torch.randn((333, K), device="cuda")) * 3.0
+        whole = m._tail_float32(fv)
+        assert whole.shape == (333, 3) and whole.dtype == torch.float32
+        assert torch.equal(m._tail_float32(fv), whole)
+        for n in (1, 2, 63, 64, 65, 137):
+            assert torch.equal(m._tail_float32(fv[:n]), whole[:n]), n
+        assert torch.equal(m._tail_float32(fv[200:]), whole[200:])
+        pick = torch.tensor([5, 300, 17, 64], device="cuda")
+        assert torch.equal(m._tail_float32(fv[pick]), whole[pick])
+        wide = torch.zeros((333, K + 8), device="cuda")            # rows 16 bytes apart from a multiple of K: ld_feat > K
+        wide[:, :K] = fv
+        assert torch.equal(m._tail_float32(wide[:, :K]), whole)
+        F = torch.nn.functional
+        h = F.relu(F.linear(fv.double(), m.fc1.weight.double(), m.fc1.bias.double()))
+        h = F.relu(F.linear(h, m.fc2.weight.double(), m.fc2.bias.double()))
+        want = torch.softmax(F.linear(h, m.fc3.weight.double(), m.fc3.bias.double()), dim=-1)
+        err = float((whole.double() - want).abs().max())
+        print("float32 tail vs float64 layers: max |dp| = %.2e" % err)
+        assert err <= 2e-6
+        assert m._tail_float32(fv[:0]).shape == (0, 3)
+    lib, ctx = _lib.load(), _lib.context(torch.device("cuda", 0))
+    ws = torch.empty((int(lib.rml_dnn_dense_tail_f32_workspace_bytes(4, K)) // 4,), device="cuda")
+    out = torch.empty((4, 3), device="cuda")
+    m._tail_weights()
+    b1, w2t, b2, w3, b3 = m._tail_f32
+    w1 = m.fc1.weight.detach().contiguous()
+    args = lambda n, k, ld, nc, nbytes: (ctx, _lib.ptr(fv), ld, n, k, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2t), _lib.ptr(b2), _lib.ptr(w3),
+                                         _lib.ptr(b3), nc, _lib.ptr(ws), nbytes, _lib.ptr(out), None)
+    assert lib.rml_dnn_dense_tail_f32(*args(4, K - 2, K, 3, ws.numel() * 4)) == -2       # RML_ERR_UNSUPPORTED: K % 4
+    assert lib.rml_dnn_dense_tail_f32(*args(4, K, K, 17, ws.numel() * 4)) == -2          # classes
+    assert lib.rml_dnn_dense_tail_f32(*args(4, K, K, 3, 16)) == -1 and b"workspace" in lib.rml_last_error()
+    assert lib.rml_dnn_dense_tail_f32(*args(0, K, K, 3, 0)) == 0
+    assert lib.rml_dnn_dense_tail_f32_workspace_bytes(4, K) == ((K + 2559) // 2560) * 4 * 64 * 4
+
+
 def test_x3_trunk_is_float32_class(rml):
     """csrc/dnn_x3.hip (every operand a bf16 pair, three matrix-core products per product) against float64 layers on the same
     float32 planes and weights: features to ~1e-5 relative of the row's scale, class probabilities within DNN_X3_PROBA_TOL --
