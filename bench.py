@@ -820,6 +820,22 @@ def run_dnn(a, env):
     rguard = dict(rmodel.last_guard)
     if rank != 0:
         return None
+    # the guard's bound is empirical (a row OUTSIDE the covered gap whose bf16 error exceeds half its margin would keep a wrong
+    # label): check it on every frame of the timed batch -- all of them once more through the float32-class trunk on exact inputs
+    # (outside the timed region), labels compared wherever that chain itself is not at a tie
+    with torch.no_grad():
+        px3 = model.rescore_exact(V, precision="x3")
+        pg, pn = res["f32"][1].float(), res["f32_noguard"][1].float()
+        g3 = model._gaps(px3)
+        sure = g3 >= dnn.LABEL_GUARD_X3
+        outside = model._gaps(pn) >= float(guard["f32"].get("gap") or dnn.LABEL_GUARD)
+        whole = {"rows": int(B), "label_mismatch_vs_float32_class_chain": int((px3.argmax(1) != pg.argmax(1))[sure].sum()),
+                 "rows_at_a_float32_tie": int((~sure).sum()),
+                 "label_mismatch_without_guard": int((px3.argmax(1) != pn.argmax(1))[sure].sum()),
+                 "max_bf16_error_outside_the_gap": float((pn - px3.float()).abs().max(1).values[outside].max()) if bool(outside.any()) else 0.0,
+                 "max_bf16_error": float((pn - px3.float()).abs().max()),
+                 "half_gap": 0.5 * float(guard["f32"].get("gap") or dnn.LABEL_GUARD)}
+        del px3
     # parity on a few frames: NumPy restatement of the whole chain (oracle projections, Pillow restatement, Keras layers)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_np as O
@@ -867,7 +883,8 @@ def run_dnn(a, env):
                             "rounds": guard["f32"].get("rounds"), "covered": guard["f32"].get("covered"),
                             "value_without_guard": round(world * B * a.steps / res["f32_noguard"][0], 1),
                             "cost_frac": round(res["f32"][0] / res["f32_noguard"][0] - 1.0, 4),
-                            "label_mismatch_without_guard": int((res["f32_noguard"][1][:npar].float().cpu().numpy().argmax(1) != want.argmax(1)).sum())},
+                            "label_mismatch_without_guard": int((res["f32_noguard"][1][:npar].float().cpu().numpy().argmax(1) != want.argmax(1)).sum()),
+                            "whole_batch_check": whole},
            "random_init": {"value": round(world * B * a.steps / float(rdt.item()), 1), "unit": "frames/s",
                            "note": "untrained weights (outputs ~1/3 each): the guard's worst case, nearly every row scored twice",
                            "rescored": rguard["rescored"], "rescored_x6": rguard.get("rescored_x6"), "rescored_float64": rguard["rescored_float64"],
@@ -1217,6 +1234,9 @@ def main():
             dp = dnn_row["parity"]
             if dp["label_mismatch"] != 0:
                 fails.append("dnn.label_mismatch=%d" % dp["label_mismatch"])
+            wb = dnn_row["margin_guard"]["whole_batch_check"]
+            if wb["label_mismatch_vs_float32_class_chain"] != 0:
+                fails.append("dnn.whole_batch.label_mismatch=%d" % wb["label_mismatch_vs_float32_class_chain"])
             ri = dnn_row["random_init"]
             if ri["parity"]["label_mismatch"] != 0:
                 fails.append("dnn.random_init.label_mismatch=%d" % ri["parity"]["label_mismatch"])
@@ -1224,7 +1244,9 @@ def main():
                                     "random_init_v": ri["value"], "random_init_rescored": ri["rescored"],
                                     "par": [dp["frames"], dp["label_mismatch"], float("%.2g" % dp["proba_max_abs_err_vs_float64_oracle"])],
                                     "guard": [dnn_row["margin_guard"]["rescored"], dnn_row["margin_guard"]["rescored_float64"], dnn_row["margin_guard"]["rows"],
-                                              dnn_row["margin_guard"]["cost_frac"]]}
+                                              dnn_row["margin_guard"]["cost_frac"]],
+                                    "whole": [wb["rows"], wb["label_mismatch_vs_float32_class_chain"], wb["label_mismatch_without_guard"],
+                                              float("%.2g" % wb["max_bf16_error_outside_the_gap"]), float("%.2g" % wb["half_gap"])]}
         if sgan_row is not None and "value" in sgan_row:
             summ["sgan_configs4"] = {"v": sgan_row["value"], "ms": sgan_row["ms_per_step"], "same": sgan_row["replicas_identical"],
                                      "mfma": sgan_row["roofline"]["frac"]}

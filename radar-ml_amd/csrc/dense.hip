@@ -6,12 +6,14 @@
 // (MT64x64x256, one 135 KB workgroup per CU) streams it at 3.4 TB/s (186 us, profiles/r04_stats_dnn.txt); behind it PyTorch launches
 // two GEMMs, two clamps, a cast and a softmax of ~5 us each.  Here:
 //
-//  * k_fc1_splitk: 128 rows x 64 outputs per workgroup and K-step of 64 elements (128 B per row), split-K so that the grid is one
-//    round of three workgroups per CU; the tiles of a step are loaded lane-contiguously into registers three K-steps ahead and go
+//  * k_fc1_splitk: 128 rows x 64 outputs per workgroup and K-step of 64 elements (128 B per row), split-K -- in fixed pieces of
+//    kFixSteps K-steps with one partial sum each, a workgroup taking as many whole pieces as make the grid about one round of three
+//    workgroups per CU (round 6: the pieces, and with them every bit of the result, no longer depend on the batch size) --;
+//    the tiles of a step are loaded lane-contiguously into registers three K-steps ahead and go
 //    through two XOR-swizzled [rows][128 B] LDS stages, one LDS-only barrier per step; v_mfma_f32_32x32x16_bf16 with the weights
 //    as the A (row) operand and the samples as B, so a lane ends up with 4 consecutive outputs of ONE sample per accumulator quad:
 //    float4 stores of the float32 partial sums.
-//  * k_dense_finish: one wave per sample sums the partials in split order (deterministic), adds the bias, relu; the two small
+//  * k_dense_finish: one wave per sample sums the partials in piece order (deterministic), adds the bias, relu; the two small
 //    layers run in float32 in the wave (lane = output unit, the previous layer's activations broadcast with v_readlane), softmax in
 //    lane order.  Activations between the layers stay float32 (the autocast chain this replaces rounded them to bf16).
 #include "rml_internal.h"
@@ -33,9 +35,15 @@ struct Fc1Args {
     int64_t N;
     const uint8_t* w; int64_t ldw;      // [64][K] bf16, ldw bytes apart ...
     int64_t wstride;                    // ... and 128 bytes per K-step; K-block layout: [K/64][64][64], ldw = 128, wstride = 8192
-    int KT, S, steps;                   // K-steps in all, splits, K-steps per split
-    float* partial;                     // [S][N][64]
+    int KT, S, steps;                   // K-steps in all, workgroup ranges, K-steps per range (a multiple of kFixSteps)
+    float* partial;                     // [NF][N][64], NF = ceil(KT / kFixSteps)
 };
+
+// The K axis is cut into FIXED pieces of kFixSteps K-steps -- a function of K alone -- and every piece has its own partial sum, added
+// up in order by k_dense_finish: a sample's probabilities do not depend on the batch it came in (round 6; rounds 4-5 cut K by the
+// batch's tile count, so that another batch size gave other bits).  A workgroup takes a RANGE of whole pieces (as many as fill the
+// machine at this batch size) in one run of its load pipeline and writes / clears its accumulators at every piece boundary.
+constexpr int kFixSteps = 50;
 
 // K-steps in flight per thread: the workgroup's sample tile and weight tile of a step wait in registers (six 16-byte chunks per thread)
 constexpr int kDepth = 3;
@@ -119,6 +127,25 @@ __global__ __launch_bounds__(256, 3) void k_fc1_splitk(Fc1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    // acc[i][4 j + t] = hidden unit 32 i + 8 j + 4 (lane >> 5) + t of sample n0 + wave * 32 + (lane & 31)
+    const int64_t n = n0 + rb;
+    float* pdst = a.partial + ((int64_t)(k0 / kFixSteps) * a.N + (n < a.N ? n : 0)) * kHidden + 4 * chalf;
+    int fill = 0;
+    auto flush = [&]() __attribute__((always_inline)) {         // one fixed piece is complete: its partial sums leave, the accumulators restart
+        if (n < a.N) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(pdst + 32 * i + 8 * j) = make_float4(acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]);
+        }
+        pdst += a.N * kHidden;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        fill = 0;
+    };
     if (cnt > 0) {
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) issue(d, xs[d], ws[d]);
@@ -144,22 +171,13 @@ __global__ __launch_bounds__(256, 3) void k_fc1_splitk(Fc1Args a) {
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
                         }
                     }
+                    if (++fill == kFixSteps || kt == cnt - 1) flush();
                 }
                 issue(kt + kDepth + 1, xs[(d + 1) % kDepth], ws[(d + 1) % kDepth]);     // the set that has just gone to LDS
             }
         }
     }
 
-    // acc[i][4 j + t] = hidden unit 32 i + 8 j + 4 (lane >> 5) + t of sample n0 + wave * 32 + (lane & 31)
-    const int64_t n = n0 + rb;
-    if (n < a.N) {
-        float* dst = a.partial + ((int64_t)split * a.N + n) * kHidden + 4 * chalf;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(dst + 32 * i + 8 * j) = make_float4(acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]);
-    }
 }
 
 struct FinishArgs {
@@ -334,22 +352,22 @@ __global__ __launch_bounds__(256) void k_fc1_f32(Fc1F32Args a) {
     }
 }
 
-int pick_splits(int64_t tiles, int KT, int num_cu) {
-    // one round of three workgroups per CU where the K extent allows it; K-steps per split as even as possible
-    int64_t s = ((int64_t)3 * num_cu + tiles - 1) / tiles;
-    if (s < 1) s = 1;
-    if (s > 32) s = 32;
-    if (s > KT) s = KT;
-    return (int)s;
+int fixed_pieces(int KT) { return (KT + kFixSteps - 1) / kFixSteps; }
+
+// fixed pieces per workgroup range: about one round of three workgroups per CU where the K extent allows it
+int pick_group(int64_t tiles, int KT, int num_cu) {
+    const int nf = fixed_pieces(KT);
+    int64_t want = ((int64_t)3 * num_cu + tiles - 1) / tiles;      // ranges wanted
+    if (want < 1) want = 1;
+    if (want > nf) want = nf;
+    return (int)((nf + want - 1) / want);
 }
 
 }  // namespace
 
 extern "C" int64_t rml_dnn_dense_workspace_bytes(rml_ctx* ctx, int64_t N, int64_t K) {
     if (!ctx || N <= 0 || K <= 0) return 0;
-    const int64_t tiles = (N + kXRows - 1) / kXRows;
-    const int S = pick_splits(tiles, (int)(K / 64), ctx->num_cu);
-    return (int64_t)S * N * kHidden * (int64_t)sizeof(float);
+    return (int64_t)fixed_pieces((int)(K / 64)) * N * kHidden * (int64_t)sizeof(float);
 }
 
 extern "C" int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld_feat, int kblock, int64_t N, int64_t K, const uint16_t* w1, const float* b1,
@@ -376,12 +394,13 @@ extern "C" int rml_dnn_dense_tail(rml_ctx* ctx, const uint16_t* feat, int64_t ld
     fa.ldw = kblock ? kStepBytes : K * 2;
     fa.wstride = kblock ? kWBytes : kStepBytes;
     fa.KT = (int)(K / 64);
-    fa.S = pick_splits(tiles, fa.KT, ctx->num_cu);
-    fa.steps = (fa.KT + fa.S - 1) / fa.S;
+    const int nf = fixed_pieces(fa.KT), grp = pick_group(tiles, fa.KT, ctx->num_cu);
+    fa.S = (nf + grp - 1) / grp;
+    fa.steps = grp * kFixSteps;
     fa.partial = workspace;
     hipLaunchKernelGGL(k_fc1_splitk, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
     FinishArgs fi{};
-    fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
+    fi.partial = workspace; fi.S = nf; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
     const int64_t blocks = (N + 3) / 4;
     hipLaunchKernelGGL(k_dense_finish, dim3((unsigned)(blocks < 2 * ctx->num_cu ? blocks : 2 * ctx->num_cu)), dim3(256), 0, st, fi);
     RML_HIP(hipGetLastError());

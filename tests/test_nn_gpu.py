@@ -343,9 +343,12 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     """BASELINE configs[3] at its stated per-GPU size -- 32 768 frames of the Walabot arena grid through
     Classifier.predict_volumes (projection -> [-1,1] scaling + bicubic resize -> fused bf16 trunk -> dense tail) -- by
     properties that need no oracle of that size:
-      * batching independence: the whole batch in one call against the same frames in three ragged calls (other internal batch
-        boundaries, other last-batch sizes): probabilities equal to bf16 round-off (2e-3; hipBLASLt picks its kernel by the
-        batch's row count), labels equal on every row (the margin guard); the same batches again, on one stream or two: BIT-identical;
+      * batching independence: the whole batch in one call against the same frames in three ragged calls and with another internal
+        batch size (other batch boundaries, other last-batch sizes): the chain itself (label_guard=None) gives BIT-identical
+        probabilities -- every kernel of it computes a frame from that frame alone, the first dense layer's split-K pieces are a
+        function of K only (round 6) --; with the margin guard the labels are equal on every row and the probabilities to bf16
+        round-off (a row near the guard's gap may be re-scored in one batching and not in the other); the same call again, on
+        one stream or two: BIT-identical with the guard too;
       * ingest independence: the same frames as uint8 volumes give bit-identical probabilities (the projections are the same
         float32 values either way);
       * the float64 NumPy restatement of the chain on 96 frames drawn from the whole range, trained weights with real margins:
@@ -362,21 +365,19 @@ def test_dnn_full_size_batch_size_independent_properties(rml):
     assert whole.shape == (frames, 3)
 
     def same(a, b, what):
-        # the dense tail runs on hipBLASLt, which picks its kernel (and with it the order of the K = 38 400 sum) by the batch's row
-        # count: a batch of another size gives the same probabilities to bf16 round-off, not the same bits
-        # ... and a row near the guard's gap may be re-scored (exact inputs, float32) in one batching and not in the other: the two
-        # then differ by the bf16 chain's own error
+        # with the margin guard a row near the gap may be re-scored (exact inputs, float32-class) in one batching and not in the other
+        # -- the gap follows the largest error seen on the call's own candidates --: the two then differ by the bf16 chain's own error
         a, b = a.float(), b.float()
         assert float((a - b).abs().max()) <= DNN_BF16_PROBA_TOL, (what, float((a - b).abs().max()))
         assert torch.equal(a.argmax(1), b.argmax(1)), what          # float64 labels either way (margin guard)
 
+    raw = gpu.predict_volumes(V, label_guard=None)
     cuts = [0, frames // 3 + 777, frames // 3 + 777 + 9999, frames]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         same(gpu.predict_volumes(V[lo:hi]), whole[lo:hi], (lo, hi))
+        assert torch.equal(gpu.predict_volumes(V[lo:hi], label_guard=None), raw[lo:hi]), (lo, hi)      # the chain: the same bits
     same(gpu.predict_volumes(V[:5000], batch_size=1024), whole[:5000], "batch 1024")       # another internal batch size
-    # the same batches: the same bits from the chain itself; with the margin guard (one pass over the whole call: its gap and its
-    # chunks see the other rows) equal labels and probabilities to the bf16 tolerance
-    raw = gpu.predict_volumes(V, label_guard=None)
+    assert torch.equal(gpu.predict_volumes(V[:5000], batch_size=1024, label_guard=None), raw[:5000])
     assert torch.equal(gpu.predict_volumes(V[:16384], label_guard=None), raw[:16384])
     assert torch.equal(gpu.predict_volumes(V[:16384], overlap=False, label_guard=None), raw[:16384])      # one stream or two: the same bits
     same(gpu.predict_volumes(V[:16384]), whole[:16384], "first pass alone")
