@@ -288,23 +288,34 @@ struct Fc1F32Args {
     float* partial;                     // [S][N][64]
 };
 
+// RB = row blocks of 32 per wave.  One block: 128 rows per workgroup, the shape for a few hundred candidates (more workgroups).  Two:
+// 256 rows per workgroup and half the operand bytes per matrix instruction -- with one block a CU's twelve waves ask the vector
+// cache for 70 B/clk (every wave re-reads the 8 KB weight slice of its step), more than it delivers: 52 TFLOP/s (session r6d); large
+// candidate sets take two.  The sums of an output element are the same instruction sequence either way: the same bits.
+template <int RB>
 __global__ __launch_bounds__(256) void k_fc1_f32(Fc1F32Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x / a.S, s = blockIdx.x - tile * a.S;
-    const int64_t r0 = (int64_t)tile * 128 + 32 * wave;       // the wave's 32 rows
+    const int64_t r0 = (int64_t)tile * (128 * RB) + 32 * RB * wave;       // the wave's 32 RB rows
     const int64_t k0 = (int64_t)s * kF32Split;
     const int64_t k1 = a.K < k0 + kF32Split ? a.K : k0 + kF32Split;
     const int n = lane & 31, h = lane >> 5;
-    int64_t row = r0 + n;
-    row = row < a.N ? row : a.N - 1;                          // rows past the batch re-read the last one; nothing of them is stored
-    const float* __restrict__ xp = a.x + row * a.ldx + 16 * h;
+    const float* __restrict__ xp[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        int64_t row = r0 + 32 * b + n;
+        row = row < a.N ? row : a.N - 1;                      // rows past the batch re-read the last one; nothing of them is stored
+        xp[b] = a.x + row * a.ldx + 16 * h;
+    }
     const float* __restrict__ wp0 = a.w + (int64_t)n * a.ldw + 16 * h;
     const float* __restrict__ wp1 = a.w + (int64_t)(n + 32) * a.ldw + 16 * h;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    v16f acc0, acc1;
+    v16f acc[RB][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    float4 xa[4], wa[4], wb[4];
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[b][0][r] = 0.0f; acc[b][1][r] = 0.0f; }
+    float4 xa[RB][4], wa[4], wb[4];
     // K and the split are multiples of 4: a 16-byte piece is inside or outside [k0, k1) as a whole.  The loads are unconditional (a
     // piece outside re-reads the split's first); what they returned is replaced by zeros on both sides when the step USES it -- a
     // select behind the load would make the wave wait for its prefetch before the matrix instructions it should run under
@@ -313,43 +324,51 @@ __global__ __launch_bounds__(256) void k_fc1_f32(Fc1F32Args a) {
         for (int q = 0; q < 4; ++q) {
             const int64_t kk = kb + 4 * q;
             const int64_t kc = (kk + 16 * h < k1) ? kk : k0;
-            xa[q] = *reinterpret_cast<const float4*>(xp + kc);
+#pragma unroll
+            for (int b = 0; b < RB; ++b) xa[b][q] = *reinterpret_cast<const float4*>(xp[b] + kc);
             wa[q] = *reinterpret_cast<const float4*>(wp0 + kc);
             wb[q] = *reinterpret_cast<const float4*>(wp1 + kc);
         }
     };
     fetch(k0);
     for (int64_t kb = k0; kb < k1; kb += kF32Step) {
-        float4 xc[4], wc[4], wd[4];
+        float4 xc[RB][4], wc[4], wd[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool in = kb + 4 * q + 16 * h < k1;
-            xc[q] = in ? xa[q] : z4; wc[q] = in ? wa[q] : z4; wd[q] = in ? wb[q] : z4;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) xc[b][q] = in ? xa[b][q] : z4;
+            wc[q] = in ? wa[q] : z4; wd[q] = in ? wb[q] : z4;
         }
-        fetch(kb + kF32Step < k1 ? kb + kF32Step : k0);      // the next step's operands are in flight under this step's 32 MFMAs
+        fetch(kb + kF32Step < k1 ? kb + kF32Step : k0);      // the next step's operands are in flight under this step's MFMAs
         __builtin_amdgcn_sched_barrier(0);                    // ... and stay there: no wait for them is needed before the loop's next trip
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float xv[4] = {xc[q].x, xc[q].y, xc[q].z, xc[q].w};
             const float wv[4] = {wc[q].x, wc[q].y, wc[q].z, wc[q].w};
             const float wu[4] = {wd[q].x, wd[q].y, wd[q].z, wd[q].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[c], wv[c], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[c], wu[c], acc1, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const float xv = c == 0 ? xc[b][q].x : (c == 1 ? xc[b][q].y : (c == 2 ? xc[b][q].z : xc[b][q].w));
+                    acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv[c], acc[b][0], 0, 0, 0);
+                    acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wu[c], acc[b][1], 0, 0, 0);
+                }
             }
         }
     }
     // D[row of A = sample (r & 3) + 8 (r >> 2) + 4 h][column of B = unit n]: a lane half writes 32 consecutive units of one sample
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t smp = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (smp < a.N) {
-            float* dst = a.partial + ((int64_t)s * a.N + smp) * kHidden + n;
-            dst[0] = acc0[r];
-            dst[32] = acc1[r];
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t smp = r0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (smp < a.N) {
+                float* dst = a.partial + ((int64_t)s * a.N + smp) * kHidden + n;
+                dst[0] = acc[b][0][r];
+                dst[32] = acc[b][1][r];
+            }
         }
-    }
 }
 
 int fixed_pieces(int KT) { return (KT + kFixSteps - 1) / kFixSteps; }
@@ -431,9 +450,11 @@ extern "C" int rml_dnn_dense_tail_f32(rml_ctx* ctx, const float* feat, int64_t l
     fa.x = feat; fa.ldx = ld_feat; fa.N = N; fa.K = K; fa.w = w1; fa.ldw = K;
     fa.S = (int)((K + kF32Split - 1) / kF32Split);
     fa.partial = workspace;
-    const int64_t tiles = (N + 127) / 128;
+    const bool two = N >= 4096;                             // (the choice changes no bit of the result: see k_fc1_f32)
+    const int64_t tiles = two ? (N + 255) / 256 : (N + 127) / 128;
     RML_REQUIRE(tiles * fa.S < (int64_t)1 << 31, RML_ERR_UNSUPPORTED, "rml_dnn_dense_tail_f32: too large");
-    hipLaunchKernelGGL(k_fc1_f32, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
+    if (two) hipLaunchKernelGGL(k_fc1_f32<2>, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
+    else hipLaunchKernelGGL(k_fc1_f32<1>, dim3((unsigned)(tiles * fa.S)), dim3(256), 0, st, fa);
     FinishArgs fi{};
     fi.partial = workspace; fi.S = fa.S; fi.N = N; fi.b1 = b1; fi.w2t = w2t; fi.b2 = b2; fi.w3 = w3; fi.b3 = b3; fi.C = n_classes; fi.out = proba;
     const int64_t blocks = (N + 3) / 4;

@@ -205,6 +205,8 @@ def test_float32_tail_is_a_function_of_the_row(rml):
         assert torch.equal(m._tail_float32(fv[200:]), whole[200:])
         pick = torch.tensor([5, 300, 17, 64], device="cuda")
         assert torch.equal(m._tail_float32(fv[pick]), whole[pick])
+        big = m._tail_float32(fv.repeat(13, 1))                     # 4 329 rows: the kernel's two-row-block form (N >= 4 096)
+        assert torch.equal(big, whole.repeat(13, 1))                # ... the same instruction sequence per output element: the same bits
         wide = torch.zeros((333, K + 8), device="cuda")            # rows 16 bytes apart from a multiple of K: ld_feat > K
         wide[:, :K] = fv
         assert torch.equal(m._tail_float32(wide[:, :K]), whole)

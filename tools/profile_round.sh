@@ -27,6 +27,11 @@ prof() {   # prof <name> <command...>
     case "$*" in *bench.py*) doc=(--doc-file $R/gpurun_out/${TAG}_bench_$name.json);; esac
     rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$name -o k -- "$@" "${doc[@]}" > $R/gpurun_out/${TAG}_bench_$name.log 2> $R/gpurun_out/prof_$name.err
     python $R/tools/prof_summary.py stats $R/gpurun_out/prof_$name/k_results.db > $R/gpurun_out/${TAG}_stats_$name.txt
+    # kernel timeline of the steady state of the two float32 pipelines (which stream carries what, the gaps of the projection stream)
+    case $name in
+        headline_f32) python $R/tools/timeline.py $R/gpurun_out/prof_$name/k_results.db --rows 50 > $R/gpurun_out/${TAG}_timeline_headline.txt 2>&1;;
+        walabot_f32) python $R/tools/timeline.py $R/gpurun_out/prof_$name/k_results.db --rows 50 > $R/gpurun_out/${TAG}_timeline_walabot.txt 2>&1;;
+    esac
     rm -rf $R/gpurun_out/prof_$name
 }
 prof headline_f32 python $R/bench.py $COMMON --no-walabot --no-u8 --no-general --no-dnn --no-sgan
