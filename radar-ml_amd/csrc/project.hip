@@ -736,6 +736,104 @@ int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X
     return RML_OK;
 }
 
+// ---- single observations: the frame split over the chip ---------------------------------------------------------------------------
+// The reference classifies ONE observation per call (predict.py:98-119: the loop over the radar's targets).  Every projection
+// kernel above gives a frame to one workgroup or one wave -- the right grain for thousands of frames, and 118-141 us for ONE frame
+// of 2 MiB (profiles/r06_stats_latency.txt: one workgroup streams at 15 GB/s).  A max-projection splits along x without any new
+// arithmetic: the same memory viewed as B*S frames of X/S planes gives, per piece, its rows of xz and xy -- final, they belong to
+// single planes -- and a partial yz; k_project_finalize takes the maximum of the S partial yz planes and sends the assembled row
+// through the Emitter (float row, codes, statistics, pad: whatever the caller asked for).  Two launches, S workgroups per frame in
+// the first: 141 -> ~15 us at 64x64x128.  Used for batches of at most RML_SMALL_FRAMES float32 frames.
+namespace {
+constexpr int kFinalThreads = 1024;      // one workgroup per frame: a few quads per thread, every load of a plane in flight at once
+__global__ __launch_bounds__(kFinalThreads) void k_project_finalize(ProjParams a, const float* __restrict__ scr, int S, int Xs, int64_t ldv) {
+    __shared__ int64_t red[64];
+    const int X = a.X, Y = a.Y, Z = a.Z;
+    const int64_t b = blockIdx.x;
+    const float* __restrict__ fr = scr + b * S * ldv;              // the S pieces of this frame: [xz_s (Xs x Z) | yz_s (Y x Z) | xy_s (Xs x Y)]
+    const int64_t oyz = (int64_t)Xs * Z, oxy = oyz + (int64_t)Y * Z;
+    Emitter em(a, b);
+    em.rmw = false;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < (X * Z) >> 2; idx += kFinalThreads) {      // xz[i, :] = piece i / Xs, row i % Xs
+        const int i = (idx * 4) / Z, k = idx * 4 - i * Z, s = i / Xs;
+        em.put4(0, (int64_t)idx * 4, *reinterpret_cast<const float4*>(fr + s * ldv + (int64_t)(i - s * Xs) * Z + k));
+    }
+    for (int idx = tid; idx < (Y * Z) >> 2; idx += kFinalThreads) {      // yz = max over the pieces (NumPy's NaN policy: Op<MAX>)
+        // eight pieces' quads in flight at a time (one load behind the other's maximum is a memory latency per piece: 76 us per frame
+        // with 256 threads, session r6m)
+        const float* __restrict__ q0 = fr + oyz + (int64_t)idx * 4;
+        float4 v = *reinterpret_cast<const float4*>(q0);
+        for (int s0 = 1; s0 < S; s0 += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(q0 + (int64_t)(s0 + u < S ? s0 + u : 0) * ldv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v = op4<RML_MODE_MAX>(v, t[u]);       // (a piece past S re-reads piece 0: max(v, v0) = v)
+        }
+        em.put4(1, (int64_t)idx * 4, v);
+    }
+    const int nxy = X * Y;
+    if ((Y & 3) == 0) {
+        for (int idx = tid; idx < nxy >> 2; idx += kFinalThreads) {
+            const int i = (idx * 4) / Y, j = idx * 4 - i * Y, s = i / Xs;
+            em.put4(2, (int64_t)idx * 4, *reinterpret_cast<const float4*>(fr + s * ldv + oxy + (int64_t)(i - s * Xs) * Y + j));
+        }
+    } else {
+        // rows of the xy plane that are not whole quads (Walabot grid: 31): quads of the ROW may straddle two planes' pieces
+        for (int idx = tid; idx < nxy >> 2; idx += kFinalThreads) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = idx * 4 + e, i = t / Y, j = t - i * Y, s = i / Xs;
+                v[e] = fr[s * ldv + oxy + (int64_t)(i - s * Xs) * Y + j];
+            }
+            em.put4(2, (int64_t)idx * 4, make_float4(v[0], v[1], v[2], v[3]));
+        }
+        for (int t = (nxy & ~3) + tid; t < nxy; t += kFinalThreads) {
+            const int i = t / Y, j = t - i * Y, s = i / Xs;
+            em.put1(2, t, fr[s * ldv + oxy + (int64_t)(i - s * Xs) * Y + j]);
+        }
+    }
+    em.finish(red);
+}
+}  // namespace
+
+// pieces per frame for the split projection of a single observation: 0 = shape not taken (rows that are not whole quads, one plane)
+int rml_project_split_pieces(int X, int Y, int Z) {
+    if (Z % 4 != 0 || X < 2 || Y < 1) return 0;
+    int best = 0;
+    for (int s = 2; s <= X && s <= 32; ++s)
+        if (X % s == 0) best = s;                    // the largest divisor up to 32: 16 at X = 64, 11 at X = 22
+    return best;
+}
+int64_t rml_project_split_ld(int X, int Y, int Z, int S) {
+    const int Xs = X / S;
+    return (((int64_t)Xs * Z + (int64_t)Y * Z + (int64_t)Xs * Y) + 3) & ~(int64_t)3;
+}
+size_t rml_project_split_scratch_bytes(int64_t B, int X, int Y, int Z, int S) {
+    return (size_t)B * S * rml_project_split_ld(X, Y, Z, S) * sizeof(float);
+}
+
+// mode MAX of B float32 / uint8 frames through the split view; scratch: rml_project_split_scratch_bytes, 16-byte aligned
+int rml_launch_project_split(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, const ProjOut& o, float* scratch, int S,
+                             hipStream_t st) {
+    RML_REQUIRE(S >= 2 && X % S == 0 && Z % 4 == 0 && scratch, RML_ERR_INVALID, "rml_launch_project_split: bad split");
+    const int Xs = X / S;
+    const int64_t ldv = rml_project_split_ld(X, Y, Z, S);
+    ProjOut os{};
+    os.p[0] = scratch; os.p[1] = scratch + (int64_t)Xs * Z; os.p[2] = os.p[1] + (int64_t)Y * Z;
+    os.stride[0] = os.stride[1] = os.stride[2] = ldv;
+    os.sel = RML_MASK_ALL;
+    int rc = rml_launch_project(ctx, V, vdtype, B * S, Xs, Y, Z, RML_MODE_MAX, nullptr, os, st);
+    if (rc) return rc;
+    ProjParams pp;
+    fill_params(pp, ctx, V, B, X, Y, Z, nullptr, o);
+    hipLaunchKernelGGL(k_project_finalize, dim3((unsigned)B), dim3(kFinalThreads), 0, st, pp, (const float*)scratch, S, Xs, ldv);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
 // derive (-> slice) in one pass where the shape has a fused kernel: RML_OK when launched, RML_ERR_UNSUPPORTED (no message: the
 // callers fall back to the two-kernel path) otherwise.  o.sel == 0: derive only.
 int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,

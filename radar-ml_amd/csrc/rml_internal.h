@@ -203,6 +203,13 @@ bool rml_project_uses_wave_kernel(const rml_ctx* ctx, int vdtype, int mode, int 
 int rml_launch_project(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int mode,
                        const int32_t* ijk, const ProjOut& o, hipStream_t st, int targets_per_frame = 1);
 
+// single observations: mode MAX with every frame split into S pieces along x (project.hip); S = rml_project_split_pieces (0: not taken)
+constexpr int RML_SMALL_FRAMES = 8;
+int rml_project_split_pieces(int X, int Y, int Z);
+size_t rml_project_split_scratch_bytes(int64_t B, int X, int Y, int Z, int S);
+int rml_launch_project_split(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, const ProjOut& o, float* scratch, int S,
+                             hipStream_t st);
+
 // k_derive_slice (project_slice.hip): DerivedTarget.get_derived_targets (common.py:49-80) and the slices at the derived (i,j,k) in one
 // pass over the frames; o.sel == 0: derive only.  RML_ERR_UNSUPPORTED (no message set) when the shape has no fused kernel.
 int rml_launch_derive_slice(rml_ctx* ctx, const void* V, int vdtype, int64_t B, int X, int Y, int Z, int num_targets,

@@ -862,6 +862,145 @@ __global__ __launch_bounds__(512, 2) void k_svm_gemm_ring(RingArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Single observations (round 6): the exact path for a handful of rows.
+//
+// The reference classifies ONE observation per call (predict.py:98-119).  A 128 x 128 tile kernel then launches one workgroup per
+// 128 support vectors -- 21 workgroups, each streaming 2.6 MB of SV codes through one CU: 100-103 us per call
+// (profiles/r06_stats_latency.txt), a twelfth of the machine.  For n <= RML_SMALL_FRAMES rows the work is a matrix-VECTOR product,
+// bound by reading the SV codes once (52 MB at M = 2 562, D = 20 480): k_svm_dot_small gives every 8 SV rows a workgroup
+// (Mpad / 8 = 336 of them), a thread 16 bytes of K per step, v_dot4_i32_i8 on the biased codes (the very int32 the MFMA path
+// accumulates: exact, so the order does not matter), one wave reduction per (SV row, sample); k_svm_epi_small then evaluates the
+// kernel values of a 128-SV tile in parallel and adds them up EXACTLY as the tile kernels do -- two chains of 64 support vectors in
+// ascending order, fma(W, K, S), partial = chain 0 + chain 1 -- so decision values do not depend on which path ran (asserted:
+// tests/test_svm_gpu.py::test_single_observations_take_the_small_path_with_the_same_bits).
+// ------------------------------------------------------------------------------------------
+struct SmallArgs {
+    const uint8_t* sv; int64_t ld_sv;          // biased SV codes
+    const uint8_t* x; int64_t ld_x;            // biased sample codes
+    int64_t Kb;                                // bytes of K per row (a multiple of 128; pad bytes are 0 on both sides)
+    int N; int64_t Mpad;
+    const int32_t* tile_exact;                 // run iff NULL or tile_exact[0] == 1 (n <= 128: one sample tile)
+    int32_t* G;                                // [N][Mpad] biased dot products
+    const int32_t* x_isum; const int64_t* x_isq;
+    const double* sv_term; const double* W;
+    double gs; int kernel;
+    double* partial; int64_t Npart;
+};
+
+__device__ __forceinline__ int wave_sum_i32(int r) {
+    auto mv = [](int v, auto ctrl, auto rowmask, auto bound) {
+        return __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(rowmask)::value, 0xF, decltype(bound)::value);
+    };
+    r += mv(r, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{}, std::true_type{});     // quad_perm [1,0,3,2]
+    r += mv(r, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{}, std::true_type{});     // quad_perm [2,3,0,1]
+    r += mv(r, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{}, std::true_type{});    // row_half_mirror
+    r += mv(r, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{}, std::true_type{});    // row_mirror
+    r += mv(r, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}, std::false_type{});   // row_bcast15 into rows 1, 3
+    r += mv(r, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}, std::false_type{});   // row_bcast31 into rows 2, 3
+    return __builtin_amdgcn_readlane(r, 63);
+}
+
+constexpr int kSmallSv = 8;                    // SV rows per workgroup of k_svm_dot_small
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_svm_dot_small(SmallArgs a) {
+    if (a.tile_exact && a.tile_exact[0] != 1) return;
+    __shared__ int red[4][kSmallSv * NS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * kSmallSv;
+    int acc[kSmallSv][NS];
+#pragma unroll
+    for (int r = 0; r < kSmallSv; ++r)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[r][n] = 0;
+    const uint8_t* __restrict__ xr[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) xr[n] = a.x + (int64_t)(n < a.N ? n : a.N - 1) * a.ld_x;
+    const uint8_t* __restrict__ svr = a.sv + m0 * a.ld_sv;
+#pragma unroll 2
+    for (int64_t off = (int64_t)tid * 16; off < a.Kb; off += 256 * 16) {
+        v4i xs[NS], ss[kSmallSv];
+#pragma unroll
+        for (int r = 0; r < kSmallSv; ++r) ss[r] = *reinterpret_cast<const v4i*>(svr + r * a.ld_sv + off);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) xs[n] = *reinterpret_cast<const v4i*>(xr[n] + off);
+#pragma unroll
+        for (int r = 0; r < kSmallSv; ++r)
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                int t = acc[r][n];
+                t = __builtin_amdgcn_sdot4(ss[r].x, xs[n].x, t, false);
+                t = __builtin_amdgcn_sdot4(ss[r].y, xs[n].y, t, false);
+                t = __builtin_amdgcn_sdot4(ss[r].z, xs[n].z, t, false);
+                t = __builtin_amdgcn_sdot4(ss[r].w, xs[n].w, t, false);
+                acc[r][n] = t;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < kSmallSv; ++r)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int v = wave_sum_i32(acc[r][n]);
+            if (lane == 0) red[wave][r * NS + n] = v;
+        }
+    __syncthreads();
+    if (tid < kSmallSv * NS) {
+        const int r = tid / NS, n = tid - r * NS;
+        if (n < a.N) a.G[(int64_t)n * a.Mpad + m0 + r] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+template <int PT>
+__global__ __launch_bounds__(128) void k_svm_epi_small(SmallArgs a) {
+    if (a.tile_exact && a.tile_exact[0] != 1) return;
+    __shared__ double etab[64];
+    __shared__ double kvs[kTile];
+    __shared__ double wl[PT][kTile];
+    __shared__ double xch[PT];
+    const int tid = threadIdx.x, stile = blockIdx.x, n = blockIdx.y;
+    exp_tab_init(etab, tid);
+    const int64_t m = (int64_t)stile * kTile + tid;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) wl[p][tid] = a.W[(int64_t)p * a.Mpad + m];
+    __syncthreads();
+    const bool rbf = (a.kernel == RML_KERNEL_RBF);
+    // the arithmetic of the tile kernels' epilogue, value for value (k_svm_gemm<I8>)
+    const double xt = rbf ? (double)(a.x_isq[n] - 256 * (int64_t)a.x_isum[n]) : 128.0 * (double)a.x_isum[n];
+    const double g = (double)a.G[(int64_t)n * a.Mpad + m];
+    const double e0 = a.sv_term[m];
+    double kv;
+    if (rbf) {
+        double d2 = xt + e0 - 2.0 * g;
+        d2 = d2 > 0.0 ? d2 : 0.0;
+        kv = rml_exp_neg(-a.gs * d2, etab);
+    } else {
+        kv = (g + xt + e0) * a.gs;
+    }
+    kvs[tid] = kv;
+    __syncthreads();
+    if (tid < 2) {                                  // the two 64-row chains of the tile, in the tile kernels' order
+        double S[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) S[p] = 0.0;
+        for (int mm = 0; mm < 64; ++mm) {
+            const int ml = tid * 64 + mm;
+            const double k = kvs[ml];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) S[p] = fma(wl[p][ml], k, S[p]);
+        }
+        if (tid == 1) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) xch[p] = S[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // both chains live in one wave
+        if (tid == 0) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[p] + xch[p];
+        }
+    }
+}
+
 // digit planes of float32 rows: one workgroup per row, a thread takes 4 consecutive features per step.
 // ok[row] = every feature is finite and inside the model's fixed-point range.
 __global__ __launch_bounds__(256) void k_digit_rows(const float* f32, int64_t ld, int64_t D, int64_t Dq, int64_t plane, int8_t* dig,
@@ -1317,6 +1456,7 @@ struct ChunkWs {
     int8_t* dig; int64_t dig_plane; double* dnsq; int32_t* dflags;      // multi-digit operand of the general rows (or NULL)
     int32_t* stash;                                                     // scratch tiles of k_svm_gemm_ring<.., 1>
     int32_t* ijk;                                                       // derived (i,j,k) of the chunk's frames (fused derive -> slice), or NULL
+    int32_t* gsmall;                                                    // [RML_SMALL_FRAMES][Mpad] dot products of the single-observation path
     size_t bytes;
 };
 
@@ -1341,6 +1481,8 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     if (!need_dig) { w.dig = nullptr; w.dnsq = nullptr; w.dflags = nullptr; w.stash = nullptr; }
     w.ijk = (int32_t*)take(need_ijk ? (size_t)CH * 12 : 0);
     if (!need_ijk) w.ijk = nullptr;
+    w.gsmall = (int32_t*)take(need_q ? (size_t)RML_SMALL_FRAMES * m->Mpad * 4 : 0);
+    if (!need_q) w.gsmall = nullptr;
     w.bytes = off;
     return w;
 }
@@ -1370,6 +1512,30 @@ int run_finish(const rml_svm* m, int64_t n, const int32_t* flags, const ChunkWs&
     fa.dec_ovo = out.dec_ovo; fa.dec_ovr = out.dec_ovr; fa.proba = out.proba;
     fa.label_vote = out.label_vote; fa.label_calib = out.label_calib;
     hipLaunchKernelGGL(k_svm_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fa);
+    RML_HIP(hipGetLastError());
+    return RML_OK;
+}
+
+// the exact path for n <= RML_SMALL_FRAMES rows: k_svm_dot_small + k_svm_epi_small (bit-identical partial sums: see the kernels)
+int launch_small(const rml_svm* m, const GemmArgs& ga, int32_t* G, hipStream_t st) {
+    SmallArgs sa{};
+    sa.sv = ga.sv; sa.ld_sv = ga.ld_sv; sa.x = ga.x; sa.ld_x = ga.ld_x; sa.Kb = (int64_t)ga.KT * kStepBytes;
+    sa.N = (int)ga.N; sa.Mpad = ga.Mpad; sa.tile_exact = ga.tile_exact; sa.G = G;
+    sa.x_isum = ga.x_isum; sa.x_isq = ga.x_isq; sa.sv_term = ga.sv_term; sa.W = ga.W; sa.gs = ga.gs; sa.kernel = ga.kernel;
+    sa.partial = ga.partial; sa.Npart = ga.Npart;
+    const dim3 gd((unsigned)(ga.Mpad / kSmallSv)), ge((unsigned)ga.ST, (unsigned)ga.N);
+    if (ga.N <= 1) hipLaunchKernelGGL(k_svm_dot_small<1>, gd, dim3(256), 0, st, sa);
+    else if (ga.N <= 2) hipLaunchKernelGGL(k_svm_dot_small<2>, gd, dim3(256), 0, st, sa);
+    else if (ga.N <= 4) hipLaunchKernelGGL(k_svm_dot_small<4>, gd, dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL(k_svm_dot_small<8>, gd, dim3(256), 0, st, sa);
+    switch (m->PT) {
+        case 1: hipLaunchKernelGGL(k_svm_epi_small<1>, ge, dim3(128), 0, st, sa); break;
+        case 3: hipLaunchKernelGGL(k_svm_epi_small<3>, ge, dim3(128), 0, st, sa); break;
+        case 6: hipLaunchKernelGGL(k_svm_epi_small<6>, ge, dim3(128), 0, st, sa); break;
+        case 10: hipLaunchKernelGGL(k_svm_epi_small<10>, ge, dim3(128), 0, st, sa); break;
+        case 15: hipLaunchKernelGGL(k_svm_epi_small<15>, ge, dim3(128), 0, st, sa); break;
+        default: RML_REQUIRE(false, RML_ERR_UNSUPPORTED, "svm: unsupported pair count");
+    }
     RML_HIP(hipGetLastError());
     return RML_OK;
 }
@@ -1407,7 +1573,10 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         ga.want = 1; ga.x_isum = isum; ga.x_isq = isq; ga.sv_term = m->sv_term_q;
         const double sc2 = m->code_scale * m->code_scale;
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
-        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st));
+        // a handful of rows: the matrix-vector kernels (the SV codes read once by the whole chip instead of by Mpad / 128 workgroups)
+        const bool small = !kmat && n <= RML_SMALL_FRAMES && w.gsmall && (m->Mpad % kSmallSv) == 0;
+        int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st)
+                      : (small ? launch_small(m, ga, w.gsmall, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st)));
         if (rc) return rc;
     }
     if (run_dig) {
@@ -1750,6 +1919,54 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     hipStream_t caller = static_cast<hipStream_t>(stream);
     rml_ctx_guard guard(ctx, caller);       // shared workspaces, aux stream and chunk events (the caller's stream joins at the end)
     hipStream_t st = caller;                // the projections' stream
+    // Single observations -- how the reference calls the surface (predict.py:98-119: one target per call) -- and other batches of
+    // at most RML_SMALL_FRAMES frames on a code-grid model: everything on the caller's stream (no second stream, no events), the
+    // frame split over the chip (rml_launch_project_split) and the matrix-vector SVM kernels (run_chunk picks them by the row
+    // count): 64x64x128 float32 314 -> ~100 us per call on the host clock, GPU work 275 -> ~60 us.
+    if (B <= RML_SMALL_FRAMES && grid_ok && !derive && mode == RML_MODE_MAX) {
+        const int S = vdtype == RML_VOL_F32 ? rml_project_split_pieces(X, Y, Z) : 0;      // byte volumes: k_project_u8_max takes 24 us as it is
+        const int64_t CHs = kTile;
+        ChunkWs probe = carve(m, CHs, nullptr, true, vdtype != RML_VOL_U8, false, false);
+        const size_t sbytes = S ? ((rml_project_split_scratch_bytes(B, X, Y, Z, S) + 255) & ~(size_t)255) : 0;
+        void* ws = nullptr;
+        int rc = rml_ws_reserve(ctx, probe.bytes + sbytes, &ws, st);
+        if (rc) return rc;
+        const ChunkWs w = carve(m, CHs, static_cast<unsigned char*>(ws), true, vdtype != RML_VOL_U8, false, false);
+        float* scratch = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + probe.bytes);
+        const bool u8_exact = vdtype == RML_VOL_U8;
+        ProjOut o{};
+        int64_t off = 0;
+        for (int pl = 0; pl < 3; ++pl)
+            if (mask & (1u << pl)) {
+                o.q[pl] = w.q + off;
+                off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
+            }
+        o.sel = mask & RML_MASK_ALL;
+        o.qstride = m->Dq; o.qrow = w.q; o.qD = m->D;
+        o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = u8_exact ? nullptr : w.flags; o.scale_div = scale_div;
+        rc = S ? rml_launch_project_split(ctx, V, vdtype, B, X, Y, Z, o, scratch, S, st) : rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, nullptr, o, st);
+        if (rc) return rc;
+        DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
+        if (u8_exact)
+            return run_chunk(ctx, m, RML_PATH_I8, B, w.q, m->Dq, w.isum, w.isq, nullptr, nullptr, nullptr, w, out, st, /*tiles_done=*/true, nullptr, 0,
+                             /*all_exact_known=*/true, /*allow_big=*/false);
+        hipLaunchKernelGGL(k_tile_flags, dim3(2), dim3(128), 0, st, w.flags, B, 1, 0, 1, w.tile_exact, w.all_exact, 1);
+        // float rows + norms for frames that left the code grid (float64 path): a no-op when every frame is on it
+        ProjOut of{};
+        off = 0;
+        for (int pl = 0; pl < 3; ++pl)
+            if (mask & (1u << pl)) {
+                of.p[pl] = w.f32 + off; of.stride[pl] = m->Df;
+                off += pl == 0 ? (int64_t)X * Z : (pl == 1 ? (int64_t)Y * Z : (int64_t)X * Y);
+            }
+        of.sel = mask & RML_MASK_ALL;
+        of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
+        of.skip_if_set = w.all_exact;
+        rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, nullptr, of, st);
+        if (rc) return rc;
+        return run_chunk(ctx, m, RML_PATH_AUTO, B, w.q, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out, st, /*tiles_done=*/true, nullptr, 0, false,
+                         /*allow_big=*/false);
+    }
     // chunk so that GEMM(c) overlaps projection(c+1): two workspaces, aux stream for the GEMMs
     // frames per chunk: see small_chunk below; RML_CHUNK overrides
     // Persistent wave-per-frame projection (Walabot-like grids): one projection workgroup per CU plus 128x128 GEMM workgroups

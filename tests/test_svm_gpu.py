@@ -666,6 +666,55 @@ def test_fused_front_door_edge_batch_sizes(rml, u8):
             assert torch.equal(part[k], whole[k][8193 - n:]), (k, n)
 
 
+@pytest.mark.parametrize("grid,M", [((64, 64, 128), 2562), ((22, 31, 176), 700), ((8, 10, 16), 90)])
+def test_single_observations_take_the_small_path_with_the_same_bits(rml, grid, M):
+    """predict.py:98-119 classifies ONE observation per call.  Batches of 1..8 frames take the single-observation path (the frame
+    split over the chip + k_project_finalize, k_svm_dot_small + k_svm_epi_small, everything on the caller's stream): every output
+    equals, bit for bit, what the same frame gets inside a 300-frame batch (tile kernels); float32 and uint8 volumes, a projection
+    mask, a frame off the code grid (float64 path for that call), decision values against the float64 oracle."""
+    X, Y, Z = grid
+    rng = np.random.default_rng(5)
+    V, _ = rml.synth_volumes(300 + M, X, Y, Z, seed=41)
+    _, q, *_ = rml.process_volumes(V[300:], mode="max", scale=True, codes=True)
+    D = rml.feature_len(X, Y, Z)
+    sv = ((q[:, :D] ^ 0x80).cpu().numpy().astype(np.float32) / np.float32(255.0)).astype(np.float64)
+    ns = np.array([M // 3, M // 3, M - 2 * (M // 3)], dtype=np.int32)
+    dual, icpt = rng.uniform(-3, 3, (2, M)), np.array([0.1, -0.2, 0.3])
+    gamma = 4.0 / D
+    svc = rml.GpuSVC(sv, dual, icpt, ns, gamma, np.arange(3), calib_a=np.array([-1.0, -1.1, -0.9]), calib_b=np.array([0.0, 0.1, -0.1]))
+    V = V[:300].contiguous()
+    keys = ("dec_ovo", "dec_ovr", "proba", "label_vote", "label_calib")
+    for vol in (V, V.to(torch.uint8)):
+        whole = svc.decide_volumes(vol, mode="max", scale=True)
+        for n, at in ((1, 0), (1, 299), (2, 17), (3, 100), (5, 201), (8, 64)):
+            part = svc.decide_volumes(vol[at:at + n], mode="max", scale=True)
+            for k in keys:
+                assert torch.equal(part[k], whole[k][at:at + n]), (k, n, at, str(vol.dtype))
+        again = svc.decide_volumes(vol[5:6], mode="max", scale=True)
+        assert torch.equal(again["dec_ovo"], whole["dec_ovo"][5:6])
+    # against the float64 oracle (one frame)
+    xz, yz, xy = O.project_max(V[7:8].cpu().numpy())
+    want = O.svm_decision_ovo(O.features_from_projections(xz, yz, xy, scale=True), sv, dual, icpt, ns, gamma)
+    got = svc.decide_volumes(V[7:8], mode="max", scale=True)["dec_ovo"].cpu().numpy()
+    assert np.abs(got - want).max() <= TOL
+    # a projection mask (XZ + XY rows): the split projection still computes every plane, the row takes the ones asked for
+    if grid == (8, 10, 16):
+        Dm = rml.feature_len(X, Y, Z, rml.ProjMask(True, False, True))
+        svm = rml.GpuSVC(np.concatenate([sv[:, :X * Z], sv[:, X * Z + Y * Z:]], axis=1), dual, icpt, ns, gamma, np.arange(3))
+        assert Dm == X * Z + X * Y
+        mask = rml.ProjMask(True, False, True)
+        wm = svm.decide_volumes(V, mode="max", scale=True, proj_mask=mask)
+        pm = svm.decide_volumes(V[33:36], mode="max", scale=True, proj_mask=mask)
+        assert torch.equal(pm["dec_ovo"], wm["dec_ovo"][33:36]) and torch.equal(pm["label_vote"], wm["label_vote"][33:36])
+    # a frame off the code grid: that call takes the float64 path; within tolerance of the code-grid result of its neighbours' model
+    v2 = V[10:12].clone()
+    v2[0, 0, 0, 0] = 0.5
+    off = svc.decide_volumes(v2, mode="max", scale=True)
+    on = svc.decide_volumes(V[10:12], mode="max", scale=True)
+    assert np.abs(off["dec_ovo"][1].cpu().numpy() - on["dec_ovo"][1].cpu().numpy()).max() <= TOL
+    assert torch.equal(off["label_vote"][1], on["label_vote"][1])
+
+
 def test_nan_row_through_the_svm_raises_like_scikit_learn(rml):
     """predict.py:60 -> clf.predict -> sklearn's validate_data: a row that holds a NaN or an infinity raises ValueError("Input contains
     NaN ...").  The sklearn-protocol methods of the three GPU twins do the same (round 5 returned finite garbage for such a row);
