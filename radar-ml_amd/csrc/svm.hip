@@ -1923,8 +1923,9 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     // at most RML_SMALL_FRAMES frames on a code-grid model: everything on the caller's stream (no second stream, no events), the
     // frame split over the chip (rml_launch_project_split) and the matrix-vector SVM kernels (run_chunk picks them by the row
     // count): 64x64x128 float32 314 -> ~100 us per call on the host clock, GPU work 275 -> ~60 us.
-    if (B <= RML_SMALL_FRAMES && grid_ok && !derive && mode == RML_MODE_MAX) {
-        const int S = vdtype == RML_VOL_F32 ? rml_project_split_pieces(X, Y, Z) : 0;      // byte volumes: k_project_u8_max takes 24 us as it is
+    if (B <= RML_SMALL_FRAMES && grid_ok && !derive && (mode == RML_MODE_MAX || (mode == RML_MODE_SLICE && ijk))) {
+        // (slices at given voxels -- the SDK target of predict.py:98-107 -- are one wave per row as they are: k_slice_rows)
+        const int S = (vdtype == RML_VOL_F32 && mode == RML_MODE_MAX) ? rml_project_split_pieces(X, Y, Z) : 0;      // byte volumes: k_project_u8_max takes 24 us as it is
         const int64_t CHs = kTile;
         ChunkWs probe = carve(m, CHs, nullptr, true, vdtype != RML_VOL_U8, false, false);
         const size_t sbytes = S ? ((rml_project_split_scratch_bytes(B, X, Y, Z, S) + 255) & ~(size_t)255) : 0;
@@ -1944,7 +1945,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         o.sel = mask & RML_MASK_ALL;
         o.qstride = m->Dq; o.qrow = w.q; o.qD = m->D;
         o.row_isum = w.isum; o.row_isq = w.isq; o.row_flags = u8_exact ? nullptr : w.flags; o.scale_div = scale_div;
-        rc = S ? rml_launch_project_split(ctx, V, vdtype, B, X, Y, Z, o, scratch, S, st) : rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, nullptr, o, st);
+        rc = S ? rml_launch_project_split(ctx, V, vdtype, B, X, Y, Z, o, scratch, S, st) : rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, o, st);
         if (rc) return rc;
         DecisionOut out{dec_ovo, dec_ovr, proba, label_vote, label_calib};
         if (u8_exact)
@@ -1962,7 +1963,7 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
         of.sel = mask & RML_MASK_ALL;
         of.scale_div = scale_div; of.prow = w.f32; of.pD = m->D; of.pstride = m->Df; of.row_nsq = w.nsq;
         of.skip_if_set = w.all_exact;
-        rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, nullptr, of, st);
+        rc = rml_launch_project(ctx, V, vdtype, B, X, Y, Z, mode, ijk, of, st);
         if (rc) return rc;
         return run_chunk(ctx, m, RML_PATH_AUTO, B, w.q, m->Dq, w.isum, w.isq, w.flags, w.f32, w.nsq, w, out, st, /*tiles_done=*/true, nullptr, 0, false,
                          /*allow_big=*/false);

@@ -706,6 +706,13 @@ def test_single_observations_take_the_small_path_with_the_same_bits(rml, grid, M
         wm = svm.decide_volumes(V, mode="max", scale=True, proj_mask=mask)
         pm = svm.decide_volumes(V[33:36], mode="max", scale=True, proj_mask=mask)
         assert torch.equal(pm["dec_ovo"], wm["dec_ovo"][33:36]) and torch.equal(pm["label_vote"], wm["label_vote"][33:36])
+    # slices at given voxels (the SDK target of predict.py:98-107), one observation per call: the same bits as inside the batch
+    ijk = torch.stack([torch.randint(0, d, (300,), generator=torch.Generator().manual_seed(3)) for d in (X, Y, Z)], dim=1).to(torch.int32).cuda()
+    ws = svc.decide_volumes(V, mode="slice", ijk=ijk, scale=True)
+    for n, at in ((1, 4), (3, 150), (8, 292)):
+        ps = svc.decide_volumes(V[at:at + n], mode="slice", ijk=ijk[at:at + n], scale=True)
+        for k in keys:
+            assert torch.equal(ps[k], ws[k][at:at + n]), (k, n, at, "slice")
     # a frame off the code grid: that call takes the float64 path; within tolerance of the code-grid result of its neighbours' model
     v2 = V[10:12].clone()
     v2[0, 0, 0, 0] = 0.5

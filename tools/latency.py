@@ -52,11 +52,14 @@ def main():
     v1 = V[:1].contiguous()
     v1_u8 = v1.to(torch.uint8)
     v1_host = v1.cpu().numpy()
+    ijk1 = torch.tensor([[X // 2, Y // 2, Z // 3]], dtype=torch.int32, device=v1.device)
     row_host = feat[:1].cpu().numpy()
     res = {
         "grid": [X, Y, Z], "n_sv": M,
         "volume_on_gpu_to_labels (decide_volumes, B=1)": timed(lambda: svc.decide_volumes(v1)),
         "uint8_volume_on_gpu_to_labels (B=1)": timed(lambda: svc.decide_volumes(v1_u8)),
+        "slice_at_sdk_target_to_labels (predict.py:98-119, B=1)": timed(lambda: svc.decide_volumes(v1, mode="slice", ijk=ijk1, validate_ijk=False)),
+        "slice_at_derived_target_to_labels (B=1)": timed(lambda: svc.decide_volumes(v1, mode="slice")),
         "host_volume_to_host_proba (B=1, incl. PCIe)": timed(lambda: svc.decide_volumes(v1_host)["proba"].cpu()),
         "host_feature_row_predict_proba (predict.py:60)": timed(lambda: cal.predict_proba(row_host)),
         "batch_64_volumes_on_gpu": timed(lambda: svc.decide_volumes(V[:64])),
