@@ -1054,22 +1054,38 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float* feat, int64_t
     const int64_t b = blockIdx.x;
     const bool scaled = code_scale > 1.0f;
     int32_t s = 0; int64_t sq = 0; int ok = 1; double nn = 0.0;
-    for (int64_t idx = threadIdx.x; idx < Dq || idx < Df; idx += 256) {
-        float v = idx < D ? feat[b * ld + idx] : 0.0f;
-        if (idx < Df) f32[b * Df + idx] = v;
-        nn += (double)v * (double)v;
-        if (q && idx < Dq) {
-            uint8_t code = 0;
-            if (idx < D) {
-                float c = rintf(scaled ? v * code_scale : v);
-                float back = scaled ? __fdiv_rn(c, code_scale) : c;
-                bool good = (back == v) && c >= 0.0f && c <= 255.0f;
-                int ci = good ? (int)c : 0;
-                ok &= good ? 1 : 0;
-                s += ci; sq += (int64_t)(ci * ci);
-                code = (uint8_t)(ci ^ 0x80);
+    // eight of the thread's values in flight at a time (the loop used to wait out a memory latency per value: its stores may alias
+    // its loads as far as the compiler knows -- 44 us for ONE row of 20 480 values, most of a predict.py:60 call); the values are
+    // consumed in the same ascending order, so every sum is the one it was
+    const int64_t lim = Dq > Df ? Dq : Df;
+    const float* __restrict__ src = feat + b * ld;
+    for (int64_t base = threadIdx.x; base < lim; base += 256 * 8) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t idx = base + (int64_t)u * 256;
+            vv[u] = idx < D ? src[idx] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t idx = base + (int64_t)u * 256;
+            if (idx >= lim) break;
+            const float v = vv[u];
+            if (idx < Df) f32[b * Df + idx] = v;
+            nn += (double)v * (double)v;
+            if (q && idx < Dq) {
+                uint8_t code = 0;
+                if (idx < D) {
+                    float c = rintf(scaled ? v * code_scale : v);
+                    float back = scaled ? __fdiv_rn(c, code_scale) : c;
+                    bool good = (back == v) && c >= 0.0f && c <= 255.0f;
+                    int ci = good ? (int)c : 0;
+                    ok &= good ? 1 : 0;
+                    s += ci; sq += (int64_t)(ci * ci);
+                    code = (uint8_t)(ci ^ 0x80);
+                }
+                q[b * Dq + idx] = code;
             }
-            q[b * Dq + idx] = code;
         }
     }
     int64_t s64 = s;

