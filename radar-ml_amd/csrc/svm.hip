@@ -881,7 +881,8 @@ struct SmallArgs {
     int64_t Kb;                                // bytes of K per row (a multiple of 128; pad bytes are 0 on both sides)
     int N; int64_t Mpad;
     const int32_t* tile_exact;                 // run iff NULL or tile_exact[0] == 1 (n <= 128: one sample tile)
-    int32_t* G;                                // [N][Mpad] biased dot products
+    int32_t* G;                                // biased dot products of (SV m, sample n) at G[m * g_sm + n * g_sn]
+    int64_t g_sm, g_sn;
     const int32_t* x_isum; const int64_t* x_isq;
     const double* sv_term; const double* W;
     double gs; int kernel;
@@ -947,13 +948,13 @@ __global__ __launch_bounds__(256) void k_svm_dot_small(SmallArgs a) {
     __syncthreads();
     if (tid < kSmallSv * NS) {
         const int r = tid / NS, n = tid - r * NS;
-        if (n < a.N) a.G[(int64_t)n * a.Mpad + m0 + r] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (n < a.N) a.G[(m0 + r) * a.g_sm + (int64_t)n * a.g_sn] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
 }
 
 template <int PT>
 __global__ __launch_bounds__(128) void k_svm_epi_small(SmallArgs a) {
-    if (a.tile_exact && a.tile_exact[0] != 1) return;
+    if (a.tile_exact && a.tile_exact[blockIdx.y / kTile] != 1) return;
     __shared__ double etab[64];
     __shared__ double kvs[kTile];
     __shared__ double wl[PT][kTile];
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(128) void k_svm_epi_small(SmallArgs a) {
     const bool rbf = (a.kernel == RML_KERNEL_RBF);
     // the arithmetic of the tile kernels' epilogue, value for value (k_svm_gemm<I8>)
     const double xt = rbf ? (double)(a.x_isq[n] - 256 * (int64_t)a.x_isum[n]) : 128.0 * (double)a.x_isum[n];
-    const double g = (double)a.G[(int64_t)n * a.Mpad + m];
+    const double g = (double)a.G[m * a.g_sm + (int64_t)n * a.g_sn];
     const double e0 = a.sv_term[m];
     double kv;
     if (rbf) {
@@ -999,6 +1000,105 @@ __global__ __launch_bounds__(128) void k_svm_epi_small(SmallArgs a) {
             for (int p = 0; p < PT; ++p) a.partial[((int64_t)stile * a.Npart + n) * PT + p] = S[p] + xch[p];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batches that do not fill the machine with 128 x 128 tiles (9 .. ~1 500 rows: what train.py's `clf.predict(X_test)` and a
+// few dozen observations look like): FT x ST tiles are 21 .. 250 workgroups on 256 CUs, each walking all 160 K-steps -- 104 us
+// for 64 rows, whatever their number.  The int32 dot products are EXACT, so K may be cut anywhere and the pieces added in any
+// order: k_svm_gemm_splitk gives every (tile, K range) a workgroup -- the tile kernel's staging and MFMA loop over its range -- and
+// adds its accumulators into G[m][n] with int32 atomics (lanes run along n: whole 128-byte requests); k_svm_epi_small then forms the
+// kernel values and the partial sums in the tile kernels' order.  Bit-identical decision values, asserted with the small path.
+// ------------------------------------------------------------------------------------------
+struct SplitArgs {
+    const uint8_t* sv; int64_t ld_sv;
+    const uint8_t* x; int64_t ld_x;
+    int KT, per;                               // K-steps in all, per K range
+    int64_t N; int FT;
+    const int32_t* tile_exact;
+    int32_t* G; int64_t ldg;                   // [Mpad][ldg] (zeroed by the caller), ldg = FT * 128
+};
+
+__global__ __launch_bounds__(256, 2) void k_svm_gemm_splitk(SplitArgs a) {
+    __shared__ __align__(16) unsigned char smem[4 * kTileBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ftile = blockIdx.x % a.FT, stile = blockIdx.x / a.FT;
+    if (a.tile_exact && a.tile_exact[ftile] != 1) return;
+    const int kt0 = blockIdx.y * a.per;
+    const int kt1 = a.KT < kt0 + a.per ? a.KT : kt0 + a.per;
+    if (kt0 >= kt1) return;
+    const int64_t f0 = (int64_t)ftile * kTile, m0 = (int64_t)stile * kTile;
+    const uint8_t* gsv[4];
+    const uint8_t* gx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = (wave * 4 + q) * 64 + lane;          // 16-byte slot in the LDS image
+        int r = s >> 3;
+        int c = (s & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source
+        gsv[q] = a.sv + (m0 + r) * a.ld_sv + c * 16;
+        int64_t xr = f0 + r; xr = xr < a.N ? xr : a.N - 1;
+        gx[q] = a.x + xr * a.ld_x + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * 2 * kTileBytes;
+        const int64_t ko = (int64_t)kt * kStepBytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gsv[q] + ko, base + (wave * 4 + q) * 1024);
+            glds16(gx[q] + ko, base + kTileBytes + (wave * 4 + q) * 1024);
+        }
+    };
+    int aoff[2], asw[2], boff[2], bsw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int ra = wr * 64 + t * 32 + (lane & 31);
+        int rb = wc * 64 + t * 32 + (lane & 31);
+        aoff[t] = ra * kStepBytes; asw[t] = (ra >> 1) & 7;
+        boff[t] = rb * kStepBytes; bsw[t] = (rb >> 1) & 7;
+    }
+    const int chalf = lane >> 5;
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    stage(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int b = (kt - kt0) & 1;
+        __syncthreads();                       // DMA of step kt landed (vmcnt(0)) and visible
+        if (kt + 1 < kt1) stage(kt + 1, b ^ 1);
+        const unsigned char* sA = smem + b * 2 * kTileBytes;
+        const unsigned char* sB = sA + kTileBytes;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = 2 * kk + chalf;
+            v4i af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *reinterpret_cast<const v4i*>(sA + aoff[t] + ((ch ^ asw[t]) << 4));
+                bf[t] = *reinterpret_cast<const v4i*>(sB + boff[t] + ((ch ^ bsw[t]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row of A = SV (r & 3) + 8 (r >> 2) + 4 chalf][column of B = sample lane & 31]: the lanes of an atomic run along n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                const int nl = wc * 64 + j * 32 + (lane & 31);
+                __hip_atomic_fetch_add(a.G + (m0 + ml) * a.ldg + f0 + nl, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 }
 
 // digit planes of float32 rows: one workgroup per row, a thread takes 4 consecutive features per step.
@@ -1473,8 +1573,11 @@ struct ChunkWs {
     int32_t* stash;                                                     // scratch tiles of k_svm_gemm_ring<.., 1>
     int32_t* ijk;                                                       // derived (i,j,k) of the chunk's frames (fused derive -> slice), or NULL
     int32_t* gsmall;                                                    // [RML_SMALL_FRAMES][Mpad] dot products of the single-observation path
+    int32_t* gsplit;                                                    // [Mpad][CH] of the split-K path (chunks of at most kSplitRows rows), or NULL
     size_t bytes;
 };
+
+constexpr int64_t kSplitRows = 2048;        // the split-K path serves chunks of at most this many rows
 
 ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bool need_f32, bool need_dig = false, bool need_ijk = false) {
     ChunkWs w{};
@@ -1499,6 +1602,9 @@ ChunkWs carve(const rml_svm* m, int64_t CH, unsigned char* base, bool need_q, bo
     if (!need_ijk) w.ijk = nullptr;
     w.gsmall = (int32_t*)take(need_q ? (size_t)RML_SMALL_FRAMES * m->Mpad * 4 : 0);
     if (!need_q) w.gsmall = nullptr;
+    const bool need_split = need_q && CH <= kSplitRows;
+    w.gsplit = (int32_t*)take(need_split ? (size_t)m->Mpad * CH * 4 : 0);
+    if (!need_split) w.gsplit = nullptr;
     w.bytes = off;
     return w;
 }
@@ -1532,18 +1638,8 @@ int run_finish(const rml_svm* m, int64_t n, const int32_t* flags, const ChunkWs&
     return RML_OK;
 }
 
-// the exact path for n <= RML_SMALL_FRAMES rows: k_svm_dot_small + k_svm_epi_small (bit-identical partial sums: see the kernels)
-int launch_small(const rml_svm* m, const GemmArgs& ga, int32_t* G, hipStream_t st) {
-    SmallArgs sa{};
-    sa.sv = ga.sv; sa.ld_sv = ga.ld_sv; sa.x = ga.x; sa.ld_x = ga.ld_x; sa.Kb = (int64_t)ga.KT * kStepBytes;
-    sa.N = (int)ga.N; sa.Mpad = ga.Mpad; sa.tile_exact = ga.tile_exact; sa.G = G;
-    sa.x_isum = ga.x_isum; sa.x_isq = ga.x_isq; sa.sv_term = ga.sv_term; sa.W = ga.W; sa.gs = ga.gs; sa.kernel = ga.kernel;
-    sa.partial = ga.partial; sa.Npart = ga.Npart;
-    const dim3 gd((unsigned)(ga.Mpad / kSmallSv)), ge((unsigned)ga.ST, (unsigned)ga.N);
-    if (ga.N <= 1) hipLaunchKernelGGL(k_svm_dot_small<1>, gd, dim3(256), 0, st, sa);
-    else if (ga.N <= 2) hipLaunchKernelGGL(k_svm_dot_small<2>, gd, dim3(256), 0, st, sa);
-    else if (ga.N <= 4) hipLaunchKernelGGL(k_svm_dot_small<4>, gd, dim3(256), 0, st, sa);
-    else hipLaunchKernelGGL(k_svm_dot_small<8>, gd, dim3(256), 0, st, sa);
+int launch_epi(const rml_svm* m, const SmallArgs& sa, int ST, int64_t n, hipStream_t st) {
+    const dim3 ge((unsigned)ST, (unsigned)n);
     switch (m->PT) {
         case 1: hipLaunchKernelGGL(k_svm_epi_small<1>, ge, dim3(128), 0, st, sa); break;
         case 3: hipLaunchKernelGGL(k_svm_epi_small<3>, ge, dim3(128), 0, st, sa); break;
@@ -1554,6 +1650,42 @@ int launch_small(const rml_svm* m, const GemmArgs& ga, int32_t* G, hipStream_t s
     }
     RML_HIP(hipGetLastError());
     return RML_OK;
+}
+
+// the exact path for n <= RML_SMALL_FRAMES rows: k_svm_dot_small + k_svm_epi_small (bit-identical partial sums: see the kernels)
+int launch_small(const rml_svm* m, const GemmArgs& ga, int32_t* G, hipStream_t st) {
+    SmallArgs sa{};
+    sa.sv = ga.sv; sa.ld_sv = ga.ld_sv; sa.x = ga.x; sa.ld_x = ga.ld_x; sa.Kb = (int64_t)ga.KT * kStepBytes;
+    sa.N = (int)ga.N; sa.Mpad = ga.Mpad; sa.tile_exact = ga.tile_exact; sa.G = G; sa.g_sm = 1; sa.g_sn = ga.Mpad;
+    sa.x_isum = ga.x_isum; sa.x_isq = ga.x_isq; sa.sv_term = ga.sv_term; sa.W = ga.W; sa.gs = ga.gs; sa.kernel = ga.kernel;
+    sa.partial = ga.partial; sa.Npart = ga.Npart;
+    const dim3 gd((unsigned)(ga.Mpad / kSmallSv));
+    if (ga.N <= 1) hipLaunchKernelGGL(k_svm_dot_small<1>, gd, dim3(256), 0, st, sa);
+    else if (ga.N <= 2) hipLaunchKernelGGL(k_svm_dot_small<2>, gd, dim3(256), 0, st, sa);
+    else if (ga.N <= 4) hipLaunchKernelGGL(k_svm_dot_small<4>, gd, dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL(k_svm_dot_small<8>, gd, dim3(256), 0, st, sa);
+    return launch_epi(m, sa, ga.ST, ga.N, st);
+}
+
+// the exact path for batches whose tiles do not fill the machine: split-K tile kernel + the chain epilogue (see k_svm_gemm_splitk)
+int launch_split(const rml_svm* m, const GemmArgs& ga, int32_t* G, int num_cu, hipStream_t st) {
+    const int64_t ldg = (int64_t)ga.FT * kTile;
+    RML_HIP(hipMemsetAsync(G, 0, (size_t)ga.Mpad * ldg * 4, st));
+    SplitArgs sp{};
+    sp.sv = ga.sv; sp.ld_sv = ga.ld_sv; sp.x = ga.x; sp.ld_x = ga.ld_x; sp.KT = ga.KT; sp.N = ga.N; sp.FT = ga.FT;
+    sp.tile_exact = ga.tile_exact; sp.G = G; sp.ldg = ldg;
+    const int tiles = ga.FT * ga.ST;
+    int KS = (2 * num_cu + tiles - 1) / tiles;            // about two workgroups per CU
+    if (KS > ga.KT / 4) KS = ga.KT / 4;                   // at least four K-steps per range
+    if (KS < 1) KS = 1;
+    sp.per = (ga.KT + KS - 1) / KS;
+    KS = (ga.KT + sp.per - 1) / sp.per;
+    hipLaunchKernelGGL(k_svm_gemm_splitk, dim3((unsigned)tiles, (unsigned)KS), dim3(256), 0, st, sp);
+    SmallArgs sa{};
+    sa.N = (int)ga.N; sa.Mpad = ga.Mpad; sa.tile_exact = ga.tile_exact; sa.G = G; sa.g_sm = ldg; sa.g_sn = 1;
+    sa.x_isum = ga.x_isum; sa.x_isq = ga.x_isq; sa.sv_term = ga.sv_term; sa.W = ga.W; sa.gs = ga.gs; sa.kernel = ga.kernel;
+    sa.partial = ga.partial; sa.Npart = ga.Npart;
+    return launch_epi(m, sa, ga.ST, ga.N, st);
 }
 
 int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const uint8_t* q, int64_t ld_q, const int32_t* isum, const int64_t* isq,
@@ -1591,8 +1723,12 @@ int run_chunk(const rml_ctx* ctx, const rml_svm* m, int policy, int64_t n, const
         ga.gs = (m->kernel == RML_KERNEL_RBF ? m->gamma : 1.0) / sc2;
         // a handful of rows: the matrix-vector kernels (the SV codes read once by the whole chip instead of by Mpad / 128 workgroups)
         const bool small = !kmat && n <= RML_SMALL_FRAMES && w.gsmall && (m->Mpad % kSmallSv) == 0;
+        // ... and batches whose 128 x 128 tiles are fewer than the CUs: the same tiles cut along K (exact: any order)
+        const bool split = !kmat && !small && !big && w.gsplit && n <= kSplitRows && (int64_t)FT * ST < gemm_cus && ga.KT >= 8;
         int rc = kmat ? launch_gemm<PATH_I8, true>(m, ga, st)
-                      : (small ? launch_small(m, ga, w.gsmall, st) : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st)));
+                      : (small ? launch_small(m, ga, w.gsmall, st)
+                               : (split ? launch_split(m, ga, w.gsplit, gemm_cus, st)
+                                        : (big ? launch_gemm_big(m, ga, st) : launch_gemm<PATH_I8>(m, ga, st))));
         if (rc) return rc;
     }
     if (run_dig) {
@@ -1936,12 +2072,13 @@ int project_svm_impl(rml_ctx* ctx, const rml_svm* m, const void* V, int vdtype, 
     rml_ctx_guard guard(ctx, caller);       // shared workspaces, aux stream and chunk events (the caller's stream joins at the end)
     hipStream_t st = caller;                // the projections' stream
     // Single observations -- how the reference calls the surface (predict.py:98-119: one target per call) -- and other batches of
-    // at most RML_SMALL_FRAMES frames on a code-grid model: everything on the caller's stream (no second stream, no events), the
+    // at most one sample tile (128 frames) on a code-grid model: everything on the caller's stream (no second stream, no events), the
     // frame split over the chip (rml_launch_project_split) and the matrix-vector SVM kernels (run_chunk picks them by the row
     // count): 64x64x128 float32 314 -> ~100 us per call on the host clock, GPU work 275 -> ~60 us.
-    if (B <= RML_SMALL_FRAMES && grid_ok && !derive && (mode == RML_MODE_MAX || (mode == RML_MODE_SLICE && ijk))) {
+    if (B <= kTile && grid_ok && !derive && (mode == RML_MODE_MAX || (mode == RML_MODE_SLICE && ijk))) {
         // (slices at given voxels -- the SDK target of predict.py:98-107 -- are one wave per row as they are: k_slice_rows)
-        const int S = (vdtype == RML_VOL_F32 && mode == RML_MODE_MAX) ? rml_project_split_pieces(X, Y, Z) : 0;      // byte volumes: k_project_u8_max takes 24 us as it is
+        // (up to one sample tile of frames on this path; the frames are split while their pieces are fewer than ~4 per CU)
+        const int S = (vdtype == RML_VOL_F32 && mode == RML_MODE_MAX && B <= 64) ? rml_project_split_pieces(X, Y, Z) : 0;      // byte volumes: k_project_u8_max takes 24 us as it is
         const int64_t CHs = kTile;
         ChunkWs probe = carve(m, CHs, nullptr, true, vdtype != RML_VOL_U8, false, false);
         const size_t sbytes = S ? ((rml_project_split_scratch_bytes(B, X, Y, Z, S) + 255) & ~(size_t)255) : 0;

@@ -669,29 +669,38 @@ def test_fused_front_door_edge_batch_sizes(rml, u8):
 @pytest.mark.parametrize("grid,M", [((64, 64, 128), 2562), ((22, 31, 176), 700), ((8, 10, 16), 90)])
 def test_single_observations_take_the_small_path_with_the_same_bits(rml, grid, M):
     """predict.py:98-119 classifies ONE observation per call.  Batches of 1..8 frames take the single-observation path (the frame
-    split over the chip + k_project_finalize, k_svm_dot_small + k_svm_epi_small, everything on the caller's stream): every output
-    equals, bit for bit, what the same frame gets inside a 300-frame batch (tile kernels); float32 and uint8 volumes, a projection
-    mask, a frame off the code grid (float64 path for that call), decision values against the float64 oracle."""
+    split over the chip + k_project_finalize, k_svm_dot_small + k_svm_epi_small, everything on the caller's stream), batches whose
+    128 x 128 tiles do not fill the machine (9 .. ~1 500 rows) the split-K tile kernel + the same chain epilogue: every output
+    equals, bit for bit, what the same frame gets inside a 2 100-frame batch (the classic tile kernels); float32 and uint8 volumes,
+    a projection mask, a frame off the code grid (float64 path for that call), decision values against the float64 oracle."""
     X, Y, Z = grid
     rng = np.random.default_rng(5)
-    V, _ = rml.synth_volumes(300 + M, X, Y, Z, seed=41)
-    _, q, *_ = rml.process_volumes(V[300:], mode="max", scale=True, codes=True)
+    NW = 2100                                                       # 17 sample tiles x the model's SV tiles: more tiles than CUs
+    V, _ = rml.synth_volumes(NW + M, X, Y, Z, seed=41)
+    _, q, *_ = rml.process_volumes(V[NW:], mode="max", scale=True, codes=True)
     D = rml.feature_len(X, Y, Z)
     sv = ((q[:, :D] ^ 0x80).cpu().numpy().astype(np.float32) / np.float32(255.0)).astype(np.float64)
     ns = np.array([M // 3, M // 3, M - 2 * (M // 3)], dtype=np.int32)
     dual, icpt = rng.uniform(-3, 3, (2, M)), np.array([0.1, -0.2, 0.3])
     gamma = 4.0 / D
     svc = rml.GpuSVC(sv, dual, icpt, ns, gamma, np.arange(3), calib_a=np.array([-1.0, -1.1, -0.9]), calib_b=np.array([0.0, 0.1, -0.1]))
-    V = V[:300].contiguous()
+    V = V[:NW].contiguous()
     keys = ("dec_ovo", "dec_ovr", "proba", "label_vote", "label_calib")
     for vol in (V, V.to(torch.uint8)):
         whole = svc.decide_volumes(vol, mode="max", scale=True)
-        for n, at in ((1, 0), (1, 299), (2, 17), (3, 100), (5, 201), (8, 64)):
+        for n, at in ((1, 0), (1, NW - 1), (2, 17), (3, 100), (5, 201), (8, 64), (9, 500), (64, 1000), (100, 1100), (128, 1300), (300, 1500), (1200, 700)):
             part = svc.decide_volumes(vol[at:at + n], mode="max", scale=True)
             for k in keys:
                 assert torch.equal(part[k], whole[k][at:at + n]), (k, n, at, str(vol.dtype))
         again = svc.decide_volumes(vol[5:6], mode="max", scale=True)
         assert torch.equal(again["dec_ovo"], whole["dec_ovo"][5:6])
+    # the rows API (SVC.decision_function on feature rows: train.py's clf.predict(X_test)): 1, 7, 150 rows against the 2 100
+    feat = rml.process_volumes(V, mode="max", scale=True)
+    svc.decision_function_shape = "ovo"
+    dall = svc.decision_function(feat)
+    for n, at in ((1, 3), (7, 40), (150, 333)):
+        np.testing.assert_array_equal(svc.decision_function(feat[at:at + n]), dall[at:at + n])
+    np.testing.assert_array_equal(dall, whole["dec_ovo"].cpu().numpy())
     # against the float64 oracle (one frame)
     xz, yz, xy = O.project_max(V[7:8].cpu().numpy())
     want = O.svm_decision_ovo(O.features_from_projections(xz, yz, xy, scale=True), sv, dual, icpt, ns, gamma)
@@ -707,9 +716,9 @@ def test_single_observations_take_the_small_path_with_the_same_bits(rml, grid, M
         pm = svm.decide_volumes(V[33:36], mode="max", scale=True, proj_mask=mask)
         assert torch.equal(pm["dec_ovo"], wm["dec_ovo"][33:36]) and torch.equal(pm["label_vote"], wm["label_vote"][33:36])
     # slices at given voxels (the SDK target of predict.py:98-107), one observation per call: the same bits as inside the batch
-    ijk = torch.stack([torch.randint(0, d, (300,), generator=torch.Generator().manual_seed(3)) for d in (X, Y, Z)], dim=1).to(torch.int32).cuda()
+    ijk = torch.stack([torch.randint(0, d, (NW,), generator=torch.Generator().manual_seed(3)) for d in (X, Y, Z)], dim=1).to(torch.int32).cuda()
     ws = svc.decide_volumes(V, mode="slice", ijk=ijk, scale=True)
-    for n, at in ((1, 4), (3, 150), (8, 292)):
+    for n, at in ((1, 4), (3, 150), (8, 292), (40, 900)):
         ps = svc.decide_volumes(V[at:at + n], mode="slice", ijk=ijk[at:at + n], scale=True)
         for k in keys:
             assert torch.equal(ps[k], ws[k][at:at + n]), (k, n, at, "slice")
