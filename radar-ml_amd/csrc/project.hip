@@ -803,8 +803,8 @@ __global__ __launch_bounds__(kFinalThreads) void k_project_finalize(ProjParams a
 int rml_project_split_pieces(int X, int Y, int Z) {
     if (Z % 4 != 0 || X < 2 || Y < 1) return 0;
     int best = 0;
-    for (int s = 2; s <= X && s <= 32; ++s)
-        if (X % s == 0) best = s;                    // the largest divisor up to 32: 16 at X = 64, 11 at X = 22
+    for (int s = 2; s <= X && s <= 16; ++s)
+        if (X % s == 0) best = s;                    // the largest divisor up to 16: 16 at X = 64, 11 at X = 22
     return best;
 }
 int64_t rml_project_split_ld(int X, int Y, int Z, int S) {
