@@ -512,6 +512,29 @@ def run_workload(a, env, grid, frames, primary):
                        "sample": "%d of the same frames, oracle/oracle.c (max-projection + float64 libsvm loops, OpenMP over frames), "
                                  "%.1f s" % (ncpu, cdt)}
 
+    # ---- one observation per call: the grain the reference calls at (predict.py:98-119), host clock per call -------------------
+    single = None
+    if rank == 0 and a.ingest != "u8":
+        def _lat(fn, n=200):
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize(dev)
+            ts = []
+            for _ in range(n):
+                t1 = time.perf_counter(); fn(); torch.cuda.synchronize(dev); ts.append(time.perf_counter() - t1)
+            return round(float(np.percentile(np.array(ts) * 1e6, 50)), 1)
+        v1 = V[:1].contiguous()
+        v1u = v1.to(torch.uint8)
+        ijk1 = torch.tensor([[X // 2, Y // 2, Z // 3]], dtype=torch.int32, device=dev)
+        o1 = svc.decide_volumes(v1, mode="max", scale=True)
+        single = {"unit": "us per call (p50 of 200, host clock, B = 1)",
+                  "f32_volume_to_labels": _lat(lambda: svc.decide_volumes(v1, mode="max", scale=True)),
+                  "u8_volume_to_labels": _lat(lambda: svc.decide_volumes(v1u, mode="max", scale=True)),
+                  "slice_at_sdk_target_to_labels": _lat(lambda: svc.decide_volumes(v1, mode="slice", ijk=ijk1, scale=True, validate_ijk=False)),
+                  "batch_64_volumes_to_labels": _lat(lambda: svc.decide_volumes(V[:64], mode="max", scale=True), 100),
+                  "same_bits_as_in_the_batch": bool(torch.equal(o1["dec_ovo"], out["dec_ovo"][:1]) and torch.equal(o1["label_calib"], out["label_calib"][:1])),
+                  "note": "DESIGN.md 3.7: the frame split over the chip + matrix-vector SVM kernels, everything on one stream"}
+
     import zlib
     all_lab = out["all_labels"] if world > 1 else out["label_calib"]
     labels_crc = int(zlib.crc32(all_lab.cpu().numpy().astype(np.int32).tobytes()))      # of every frame's label, in global frame order
@@ -525,7 +548,7 @@ def run_workload(a, env, grid, frames, primary):
                    if world > 1 else "single GPU"},
         "hbm_frac_end_to_end": round(value / world * (frame_bytes + 16) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roofline, "gemm_roofline": groof, "projection_only": proj_only, "cpu_baseline": cpu, "parity": parity,
-        "uint8_ingest": u8, "slice_rows": slice_rows,
+        "uint8_ingest": u8, "slice_rows": slice_rows, "single_observation": single,
         "model": {"fit_s": round(fit_s, 1), "val_acc": model["val_acc"], "kernel_nondegenerate_frac": model["kfrac"]},
     }
     del V, Vall, out, svc
@@ -1219,6 +1242,11 @@ def main():
                 if key == "slice_mode" and sr.get("bound"):
                     row[key]["bound"] = "gemm"
                     row[key]["floor"] = sr["roofline"].get("frac_of_request_floor")
+            so = r.get("single_observation")
+            if so:
+                row["one_call_us"] = [so["f32_volume_to_labels"], so["u8_volume_to_labels"], so["slice_at_sdk_target_to_labels"], so["batch_64_volumes_to_labels"]]
+                if not so["same_bits_as_in_the_batch"]:
+                    fails.append(tag + ".single_observation.bits_differ")
             summ[tag] = row
         if res["projection_only"]:
             summ["proj_only_configs1"] = {k: v["frac"] for k, v in res["projection_only"].items()}
