@@ -1010,6 +1010,11 @@ __global__ __launch_bounds__(128) void k_svm_epi_small(SmallArgs a) {
 // adds its accumulators into G[m][n] with int32 atomics (lanes run along n: whole 128-byte requests); k_svm_epi_small then forms the
 // kernel values and the partial sums in the tile kernels' order.  Bit-identical decision values, asserted with the small path.
 // ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero16(v4i* p, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = v4i{0, 0, 0, 0};
+}
+
 struct SplitArgs {
     const uint8_t* sv; int64_t ld_sv;
     const uint8_t* x; int64_t ld_x;
@@ -1670,7 +1675,12 @@ int launch_small(const rml_svm* m, const GemmArgs& ga, int32_t* G, hipStream_t s
 // the exact path for batches whose tiles do not fill the machine: split-K tile kernel + the chain epilogue (see k_svm_gemm_splitk)
 int launch_split(const rml_svm* m, const GemmArgs& ga, int32_t* G, int num_cu, hipStream_t st) {
     const int64_t ldg = (int64_t)ga.FT * kTile;
-    RML_HIP(hipMemsetAsync(G, 0, (size_t)ga.Mpad * ldg * 4, st));
+    // (a kernel, not hipMemsetAsync: the memset of a captured stream was not replayed with the graph -- the second replay added
+    // onto the first one's sums, tests/test_capi_gpu.py)
+    {
+        const int64_t n16 = ga.Mpad * ldg / 4;             // Mpad and ldg are multiples of 128
+        hipLaunchKernelGGL(k_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<v4i*>(G), n16);
+    }
     SplitArgs sp{};
     sp.sv = ga.sv; sp.ld_sv = ga.ld_sv; sp.x = ga.x; sp.ld_x = ga.ld_x; sp.KT = ga.KT; sp.N = ga.N; sp.FT = ga.FT;
     sp.tile_exact = ga.tile_exact; sp.G = G; sp.ldg = ldg;

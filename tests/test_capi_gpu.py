@@ -451,6 +451,24 @@ def test_entry_points_capture_into_a_hip_graph_after_a_warm_up(rml):
         torch.cuda.synchronize()
         assert torch.equal(o["dec_ovo"], eager[name][0]) and torch.equal(o["label_calib"], eager[name][1]), name
         assert torch.equal(p, eager[name][2]), name
+    # the single-observation and the split-K paths (one stream, no events; a memset node in the second) capture and replay as well
+    small = {}
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for nb in (1, 64):
+            svc.decide_volumes(buf[:nb], mode="max", scale=True, want_proba=True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph_s = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph_s, stream=side):
+        for nb in (1, 64):
+            small[nb] = svc.decide_volumes(buf[:nb], mode="max", scale=True, want_proba=True)
+    for name, V in (("a", Va), ("b", Vb)):
+        buf.copy_(V)
+        graph_s.replay()
+        torch.cuda.synchronize()
+        for nb in (1, 64):
+            assert torch.equal(small[nb]["dec_ovo"], eager[name][0][:nb]) and torch.equal(small[nb]["label_calib"], eager[name][1][:nb]), (name, nb)
     # growth inside a capture: refused, nothing broken
     have = int(lib.rml_ctx_workspace_bytes(ctx))
     assert have > 0
