@@ -76,6 +76,9 @@ __global__ __launch_bounds__(kThreads) void k_project_fast(ProjParams a) {
     }
     const int plane = Y * ZQ;
 
+    // (`#pragma unroll 2` below is not honoured -- hipcc reports "loop not unrolled", the ISA shows NM loads, NM counted waits and
+    // nothing in flight at the loop's end --; a hand-written rolling window over the planes, 101 -> 131 registers at the same three
+    // workgroups per CU, measured the same: tools/exp/README.md round 6)
 #pragma unroll 2
     for (int i = 0; i < X; ++i) {
         const QT* __restrict__ Vi = Vb + (int64_t)i * plane;
