@@ -9,6 +9,7 @@
 #   stats_gemm_alone     code rows -> k_svm_gemm_ring<PT,0>, whole-round chunks (tools/gemm_ab.py)
 #   stats_dnn            bench.py's own CNN row (the line's dnn_forward.roofline and this summary's k_dnn_trunk_rf row come from ONE run)
 #   stats_sgan
+#   stats_latency        tools/latency.py: one observation per call (k_project_finalize, k_svm_dot_small, k_svm_epi_small, k_svm_gemm_splitk)
 #   stats_slice          the reference-faithful rows (k_derive_slice, k_slice_rows) cut out of the two f32 runs, both grids
 # then PMC passes (separate runs, kernel trace only -- never with sys/hip/hsa traces): FETCH_SIZE / WRITE_SIZE of the projection
 # kernels, matrix-core / issue counters and FETCH_SIZE of the GEMM kernels.  Summaries land in gpurun_out/; copy the ones to
@@ -49,6 +50,9 @@ open("$R/gpurun_out/${TAG}_stats_dnn.txt", "a").write("# bench.py dnn_forward of
     % (d["value"], d["value_uint8_volumes"], r["avg_launch_ms"], r["min_launch_ms"], r["max_launch_ms"], r["launches"], r["frames_per_launch"], r["achieved"], r["frac"]))
 PY
 prof sgan python $R/tools/bench_nn.py sgan --steps 100
+# one observation per call: the kernels of a B = 1 call, and the host-clock latencies of both grids
+prof latency python $R/tools/latency.py --grid 64x64x128 --svs 2560 --iters 30
+( for g in "64x64x128 2560" "22x31x176 2000"; do set -- $g; python $R/tools/latency.py --grid $1 --svs $2 2>/dev/null | tail -1; done ) > $R/gpurun_out/${TAG}_latency.txt
 ( echo "# k_derive_slice / k_slice_rows rows of ${TAG}_stats_headline_f32.txt (64x64x128) and ${TAG}_stats_walabot_f32.txt (22x31x176):"
   echo "# bench.py's slice_rows.derive_slice_svm / slice_mode (doc) of the same runs: in-situ avg launch ms beside them"
   for n in headline_f32 walabot_f32; do
