@@ -297,10 +297,13 @@ def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
     n = len(samples)
     if n == 0:
         return np.array([])          # np.array([]) is what the reference returns for no samples
-    planes = []
+    # the selected planes of all samples in ONE host buffer, plane-major ([all xz | all yz | all xy]): one upload instead of three
+    # (a per-target call of predict.py:112-116 is dominated by its host-device hops; the row-major concatenation, the scaling and a
+    # non-unit zoom are the device's: rml_assemble_features / rml_zoom_features)
+    shapes = []
     for i in range(3):
         if not proj_mask[i]:
-            planes.append(None)
+            shapes.append(None)
             continue
         shp = np.shape(samples[0][i])
         if len(shp) != 2:
@@ -309,7 +312,19 @@ def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
             if np.shape(s[i]) != shp:
                 # the reference's np.array([...]) raises on ragged rows
                 raise ValueError("setting an array element with a sequence: ragged projection shapes")
-        planes.append(np.stack([np.asarray(s[i], dtype=np.float32) for s in samples]))
+        shapes.append(tuple(int(v) for v in shp))
+    hostbuf = np.empty(sum(n * sh[0] * sh[1] for sh in shapes if sh is not None), dtype=np.float32)
+    planes, offs, off = [], [], 0
+    for i in range(3):
+        if shapes[i] is None:
+            planes.append(None); offs.append(None)
+            continue
+        cnt = n * shapes[i][0] * shapes[i][1]
+        view = hostbuf[off:off + cnt].reshape((n,) + shapes[i])
+        for si, smp in enumerate(samples):
+            view[si] = smp[i]
+        planes.append(view); offs.append((off, cnt))
+        off += cnt
     # grid sizes from the selected planes: xz (X,Z), yz (Y,Z), xy (X,Y)
     X = planes[0].shape[1] if planes[0] is not None else (planes[2].shape[1] if planes[2] is not None else 1)
     Z = planes[0].shape[2] if planes[0] is not None else (planes[1].shape[2] if planes[1] is not None else 1)
@@ -323,7 +338,8 @@ def process_samples(samples, proj_mask=ProjMask(xz=True, yz=True, xy=True),
     D = int(lib.rml_feature_len(X, Y, Z, bits))
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     ctx = _lib.context(dev)
-    dplanes = [None if p is None else torch.from_numpy(p).to(dev) for p in planes]
+    dbuf = torch.from_numpy(hostbuf).to(dev)
+    dplanes = [None if planes[i] is None else dbuf[offs[i][0]:offs[i][0] + offs[i][1]].view(planes[i].shape) for i in range(3)]
     if not unit:
         import ctypes as C
         # output shapes exactly as scipy.ndimage.zoom computes them: int(round(size * zoom)), Python round()
