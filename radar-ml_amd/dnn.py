@@ -752,10 +752,13 @@ class Classifier(_module_base()):
         kb = self.kblock_supported(int(xs[0].shape[-2]), int(xs[0].shape[-1]))
         return self.dense_tail(self._features_timed(xs, trunk_events, "kblock" if kb else "nhwc"), kblock=kb)
 
-    def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16", label_guard=LABEL_GUARD):
+    def predict(self, inputs, batch_size=8192, autocast_dtype="bfloat16", label_guard=LABEL_GUARD, fused=None):
         """Keras ``model.predict([xz, yz, xy])``: numpy (N,H,W,1) inputs -> (N, n_classes) float32 numpy.  Under autocast on the
         GPU the margin guard of :meth:`predict_volumes` applies: rows whose top-2 gap is below ``label_guard`` are scored again
-        in float64 from the same input planes, so ``argmax`` is the float64 label."""
+        in float64 from the same input planes, so ``argmax`` is the float64 label.  ``fused`` (default: where the planes fit the
+        fused kernels -- the 80 x 80 of dnn.py do -- and the dtype is bfloat16): the bf16 chain of :meth:`predict_volumes`
+        (csrc/dnn.hip trunk + csrc/dense.hip tail) instead of the PyTorch / MIOpen layers under autocast -- the same operand
+        precision, one launch per stage: dnn.py:373-381 predicts ONE target per call (round 6)."""
         import torch
         dev = next(self.parameters()).device
         dt = getattr(torch, autocast_dtype) if autocast_dtype else None
@@ -766,7 +769,13 @@ class Classifier(_module_base()):
         with torch.no_grad():
             for s in range(0, n, batch_size):
                 xs = [to_nchw(a[s:s + batch_size], dev) for a in inputs]
-                if dt is not None and dev.type == "cuda":
+                H, W = int(xs[0].shape[-2]), int(xs[0].shape[-1])
+                use_fused = (fused if fused is not None else True) and dt is torch.bfloat16 and dev.type == "cuda" \
+                    and all(tuple(x.shape[-2:]) == (H, W) and x.shape[1] == 1 for x in xs) and self.kblock_supported(H, W) and self.x3_supported(H, W)
+                if use_fused:
+                    p = self.forward_fused(*xs)
+                    p = self._guard(p.float(), label_guard, lambda idx, prec: self.forward_exact(*[x[idx] for x in xs], precision=prec))
+                elif dt is not None and dev.type == "cuda":
                     with torch.autocast("cuda", dtype=dt):
                         p = self(*xs)
                     p = self._guard(p.float(), label_guard, lambda idx, prec: self.forward_exact(*[x[idx] for x in xs], precision=prec))
