@@ -55,6 +55,7 @@ struct TrunkArgs {
     const float* b2;        // [3][32]
     uint16_t* feat;         // [B][OH2*OW2*96] bf16
     int kblock;             // k_dnn_trunk_rf: feat is [K/64][B][64] with K ordered (branch, pixel, channel) -- see rml_dnn_trunk_kblock
+    int split;              // k_dnn_trunk_rf, few samples: a WORKGROUP owns a sample and its eight waves take the sample's tiles eight apart
 };
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -446,7 +447,13 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
         const unsigned char* wl = smem + L.off_w + lane * 16;
         const f32x4* biasl = reinterpret_cast<const f32x4*>(smem + L.off_bias + h * 64);
 
-        for (int64_t b = (int64_t)blockIdx.x * RF_WAVES + wave; b < a.B; b += sstride) {
+        // few samples (a.split; dnn.py:373-381 predicts ONE target per call): a wave that owns a whole sample needs 116 us for it while
+        // 2 047 others idle -- the workgroup owns the sample instead, every wave keeps its own copy of the plane (no exchange, no
+        // barrier: the kernel's structure) and walks the tiles wave, wave + 8, ...: the same arithmetic per tile, an eighth of the time
+        const int64_t b_first = a.split ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * RF_WAVES + wave;
+        const int64_t b_step = a.split ? (int64_t)gridDim.x : sstride;
+        const int t_first = a.split ? wave : 0, t_step = a.split ? RF_WAVES : 1;
+        for (int64_t b = b_first; b < a.B; b += b_step) {
             // ---- the wave's plane: [0,H) x [0,W) of its LDS region (the border stays zero)
             {
                 const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(
@@ -460,14 +467,15 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
                     else d[0] = make_uint2(pk_bf16(__uint_as_float(v.x), __uint_as_float(v.y)), pk_bf16(__uint_as_float(v.z), __uint_as_float(v.w)));
                 }
             }
-            int pr = pr0, pc = pc0;
             // the lane's 32 bytes of a pixel's feature row: channels 16 h .. 16 h + 15 of this branch
             // (K-block layout: element (branch, pixel, channel) of sample b at block (branch * P + pixel) / 2 -- two pixels of 32
             // channels -- , i.e. the lanes (n, n + 1) x (h = 0, 1) fill one 128-byte line and a tile advances 16 blocks)
-            uint16_t* dst = a.kblock ? a.feat + ((int64_t)((br * P + n) >> 1) * a.B + b) * 64 + (n & 1) * 32 + 16 * h
-                                     : a.feat + (b * (int64_t)P + n) * 96 + br * 32 + 16 * h;
             const int64_t dstep = a.kblock ? 16 * a.B * 64 : 32 * 96;
-            for (int tile = 0; tile < NT; ++tile) {
+            uint16_t* dst = (a.kblock ? a.feat + ((int64_t)((br * P + n) >> 1) * a.B + b) * 64 + (n & 1) * 32 + 16 * h
+                                      : a.feat + (b * (int64_t)P + n) * 96 + br * 32 + 16 * h) + t_first * dstep;
+            int pr = pr0 + t_first * incr, pc = pc0 + t_first * incc;
+            pr += pc / OW2; pc -= (pc / OW2) * OW2;
+            for (int tile = t_first; tile < NT; tile += t_step) {
                 // ---- addresses of this tile's windows
                 const bool live = tile * 32 + n < P;
                 const int prc = live ? pr : OH2 - 1, pcc = live ? pc : OW2 - 1;
@@ -589,9 +597,9 @@ __global__ __launch_bounds__(64 * RF_WAVES, 2) void k_dnn_trunk_rf(TrunkArgs a) 
                     *reinterpret_cast<uint4*>(dst) = make_uint4(s00[0], s01[0], s00[1], s01[1]);
                     *reinterpret_cast<uint4*>(dst + 8) = make_uint4(s10[0], s11[0], s10[1], s11[1]);
                 }
-                dst += dstep;
-                pr += incr; pc += incc;
-                if (pc >= OW2) { pc -= OW2; pr += 1; }
+                dst += t_step * dstep;
+                pr += t_step * incr; pc += t_step * incc;
+                pr += pc / OW2; pc -= (pc / OW2) * OW2;
             }
         }
     }
@@ -602,8 +610,10 @@ int launch_trunk_rf(const TrunkArgs& a, int num_cu, hipStream_t stream) {
     const RfLayout L(a.H, a.W);
     if (L.total > 160 * 1024) return RML_ERR_UNSUPPORTED;
     RML_MAX_DYN_LDS(160 * 1024, &k_dnn_trunk_rf<INBF>);
-    const int64_t need = (a.B + RF_WAVES - 1) / RF_WAVES;
-    hipLaunchKernelGGL((k_dnn_trunk_rf<INBF>), dim3((unsigned)(need < num_cu ? need : num_cu)), dim3(64 * RF_WAVES), L.total, stream, a);
+    TrunkArgs as = a;
+    as.split = a.B <= 2 * (int64_t)num_cu ? 1 : 0;      // at most two samples per CU: a workgroup per sample (see the kernel)
+    const int64_t need = as.split ? a.B : (a.B + RF_WAVES - 1) / RF_WAVES;
+    hipLaunchKernelGGL((k_dnn_trunk_rf<INBF>), dim3((unsigned)(need < num_cu ? need : num_cu)), dim3(64 * RF_WAVES), L.total, stream, as);
     return RML_OK;
 }
 
