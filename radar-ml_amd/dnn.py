@@ -438,11 +438,20 @@ class Classifier(_module_base()):
             ctx, st = _lib.context(dev), _lib.stream_ptr(dev)
             g = torch.empty((N,), dtype=torch.float32, device=dev)
             _lib.check(lib.rml_dnn_top2_gap(ctx, _lib.ptr(proba), ld, N, C, _lib.ptr(g), st), "rml_dnn_top2_gap")
-            stats = torch.zeros((2,), dtype=torch.int32, device=dev)
+            stats = None
             while True:
-                cand = (g < thr).nonzero().squeeze(1)                       # device -> host: the candidate count
-                n = int(cand.numel())
+                if N <= 4096:
+                    # a few rows (dnn.py:373-381 predicts ONE target per call): the gaps cross to the host in one copy and the
+                    # candidates are picked there -- compare + nonzero on the device are three launches and a synchronisation
+                    idx = np.flatnonzero(g.cpu().numpy() < thr)
+                    n = int(idx.size)
+                    cand = torch.from_numpy(idx).to(dev) if n else None
+                else:
+                    cand = (g < thr).nonzero().squeeze(1)                   # device -> host: the candidate count
+                    n = int(cand.numel())
                 if n:
+                    if stats is None:
+                        stats = torch.zeros((2,), dtype=torch.int32, device=dev)
                     rounds += 1
                     p3 = rescore(cand, "x3").float().contiguous()
                     close = torch.empty((n,), dtype=torch.uint8, device=dev)
